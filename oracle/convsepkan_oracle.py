@@ -1,0 +1,290 @@
+"""CPU oracle for the ConvSepKAN hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file is the checker, never the product: only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import it.  It is a from-scratch functional
+restatement (plain torch ops on CPU tensors, fp32 or fp64) of the algorithm the
+reference implements with nn.Modules.  Parity is PINNED: tests/test_oracle_golden.py
+checks every function below against golden vectors produced by importing the
+reference itself (tests/golden/make_golden.py).
+
+Every function takes a flat ``params`` dict that uses the reference's own
+state_dict key names (e.g. ``layers.0.encoder.encoder.ffn2.gate.weight``), so a
+reference checkpoint is directly usable.
+
+Reference map (paths relative to the reference repository root):
+  knot_vector          conv_sep_kan/kan_layer.py:14-29   generate_control_points
+  bspline_basis        conv_sep_kan/bspline.py:4-28      compute_bspline
+  kan_eval             conv_sep_kan/kan_layer.py:68-84, 106-118, 153-162
+  kan_cell             conv_sep_kan/conv_sep_kan_cells.py:123-156
+  pixel_shuffle        conv_sep_kan/conv_sep_kan.py:18,38 (nn.PixelShuffle)
+  ffn                  conv_sep_kan/unet_blocks.py:212-241
+  gated_ffn            conv_sep_kan/unet_blocks.py:244-275
+  batch_tx_layer       conv_sep_kan/gazetr.py:35-66 (+ nn.MultiheadAttention, batch_first)
+  gazetr               conv_sep_kan/gazetr.py:100-119
+  bilinear_up          conv_sep_kan/conv_sep_kan.py:33-34 (F.interpolate bilinear)
+  conv_sep_kan_forward conv_sep_kan/conv_sep_kan.py:29-42
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+# --------------------------------------------------------------------------- spline
+def knot_vector(grid_size: int, spline_order: int, grid_range: Sequence[float],
+                dtype=torch.float32) -> torch.Tensor:
+    """Uniform knots t_j = j*h + lo, j = -k .. G+k, ALWAYS evaluated in fp32 as
+    (float32(j) * float32(h)) + lo (one rounding after the multiply, one after the
+    add) and only then cast to ``dtype``: the fp32 rounding of the knots is part of
+    the algorithm (e.g. t_6 = 0.20000005 for G=5), also for an fp64 evaluation."""
+    lo, hi = grid_range[0], grid_range[1]
+    h = (hi - lo) / grid_size
+    j = torch.arange(-spline_order, grid_size + spline_order + 1)
+    return (j * h + lo).to(dtype)   # int64 tensor * python float -> float32
+
+
+def bspline_basis(x: torch.Tensor, t: torch.Tensor, k: int) -> torch.Tensor:
+    """Cox-de Boor recursion on one shared knot vector.
+
+    x: [N, I]; t: [G+2k+1]; returns [N, I, G+k].  The order-0 indicator is the
+    half-open test t_j <= x < t_{j+1}; outside [t_0, t_last) every basis is 0.
+    The indicator carries no gradient; d/dx flows through the (x-t)/(dt) factors.
+    """
+    xe = x.unsqueeze(-1)                                   # [N, I, 1]
+    b = ((xe >= t[:-1]) & (xe < t[1:])).to(x.dtype)        # [N, I, M-1]
+    m = t.numel()
+    for p in range(1, k + 1):
+        n = m - (p + 1)
+        left = (xe - t[:n]) / (t[p:-1] - t[:n])
+        right = (t[p + 1:] - xe) / (t[p + 1:] - t[1:n + 1])
+        b = left * b[..., :-1] + right * b[..., 1:]
+    return b
+
+
+def kan_eval(x: torch.Tensor, coef: torch.Tensor, uw: torch.Tensor, rw: torch.Tensor,
+             t: torch.Tensor, k: int) -> torch.Tensor:
+    """Per-sample KAN layer.  x [N,I]; coef [N,O,I,K]; uw, rw [N,O,I] -> [N,O].
+
+    out[n,o] = sum_i ( rw[n,o,i]*silu(x[n,i]) + uw[n,o,i]*sum_g B_g(x[n,i])*coef[n,o,i,g] )
+    """
+    basis = bspline_basis(x, t, k)                          # [N, I, K]
+    spline = (basis.unsqueeze(1) * coef).sum(-1)            # [N, O, I]
+    phi = rw * F.silu(x).unsqueeze(1) + uw * spline
+    return phi.sum(-1)
+
+
+def kan_param_count(in_dim: int, out_dim: int, grid_size: int, spline_order: int) -> int:
+    """P = O*I*(G+k) coefficients + O*I spline weights + O*I residual weights."""
+    return out_dim * in_dim * (grid_size + spline_order + 2)
+
+
+def kan_cell(x: torch.Tensor, w: torch.Tensor, out_dim: int, grid_size: int,
+             spline_order: int, grid_range: Sequence[float]) -> torch.Tensor:
+    """x [B,I,H,W], w [B,P,H,W] -> [B,O,H,W].  Channel layout of w at each pixel:
+    [coef (o-major, then i, then g) | uw (o,i) | rw (o,i)]."""
+    B, I, H, W = x.shape
+    O, K = out_dim, grid_size + spline_order
+    wn = w.permute(0, 2, 3, 1).reshape(B * H * W, -1)
+    xn = x.permute(0, 2, 3, 1).reshape(B * H * W, I)
+    n_coef = O * I * K
+    coef = wn[:, :n_coef].reshape(-1, O, I, K)
+    uw = wn[:, n_coef:n_coef + O * I].reshape(-1, O, I)
+    rw = wn[:, n_coef + O * I:n_coef + 2 * O * I].reshape(-1, O, I)
+    t = knot_vector(grid_size, spline_order, grid_range, dtype=x.dtype)
+    y = kan_eval(xn, coef, uw, rw, t, spline_order)
+    return y.reshape(B, H, W, O).permute(0, 3, 1, 2)
+
+
+def pixel_shuffle(y: torch.Tensor, r: int) -> torch.Tensor:
+    """out[b, c, h*r+i, w*r+j] = y[b, c*r*r + i*r + j, h, w]."""
+    B, C, H, W = y.shape
+    c = C // (r * r)
+    return y.reshape(B, c, r, r, H, W).permute(0, 1, 4, 2, 5, 3).reshape(B, c, H * r, W * r)
+
+
+# --------------------------------------------------------------------------- convs
+def ffn(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """pointwise1 -> depthwise 3x3 (zero pad 1, groups=C) -> ReLU -> pointwise2."""
+    h = F.conv2d(x, p[prefix + "pointwise1.weight"], p[prefix + "pointwise1.bias"])
+    h = F.conv2d(h, p[prefix + "depthwise.weight"], p[prefix + "depthwise.bias"],
+                 padding=1, groups=h.shape[1])
+    h = torch.relu(h)
+    return F.conv2d(h, p[prefix + "pointwise2.weight"], p[prefix + "pointwise2.bias"])
+
+
+def gated_ffn(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """t = relu(fn_1(x)) [2C]; value = t[:C]; gate = dw3x3(t[C:]); fn_2(value*gate)."""
+    t = torch.relu(F.conv2d(x, p[prefix + "fn_1.0.weight"], p[prefix + "fn_1.0.bias"]))
+    c = t.shape[1] // 2
+    val, g = t[:, :c], t[:, c:]
+    g = F.conv2d(g, p[prefix + "gate.weight"], p[prefix + "gate.bias"], padding=1, groups=c)
+    return F.conv2d(val * g, p[prefix + "fn_2.weight"], p[prefix + "fn_2.bias"])
+
+
+# --------------------------------------------------------------------------- transformer over the batch axis
+def batch_tx_layer(s: torch.Tensor, p: Params, prefix: str, nhead: int = 2) -> torch.Tensor:
+    """Post-LN encoder layer, eval mode (dropout off).  s: [L, S, E] where L indexes
+    pixels and S is the (local) batch: attention mixes the S images at one pixel."""
+    L, S, E = s.shape
+    hd = E // nhead
+    qkv = s @ p[prefix + "self_attn.in_proj_weight"].t() + p[prefix + "self_attn.in_proj_bias"]
+    q, k, v = qkv.split(E, dim=-1)
+    q = q.reshape(L, S, nhead, hd).transpose(1, 2)           # [L, h, S, hd]
+    k = k.reshape(L, S, nhead, hd).transpose(1, 2)
+    v = v.reshape(L, S, nhead, hd).transpose(1, 2)
+    att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+    ctx = (att @ v).transpose(1, 2).reshape(L, S, E)
+    a = ctx @ p[prefix + "self_attn.out_proj.weight"].t() + p[prefix + "self_attn.out_proj.bias"]
+    s = F.layer_norm(s + a, (E,), p[prefix + "norm1.weight"], p[prefix + "norm1.bias"])
+    m = torch.relu(s @ p[prefix + "linear1.weight"].t() + p[prefix + "linear1.bias"])
+    m = m @ p[prefix + "linear2.weight"].t() + p[prefix + "linear2.bias"]
+    return F.layer_norm(s + m, (E,), p[prefix + "norm2.weight"], p[prefix + "norm2.bias"])
+
+
+def gazetr_features(x: torch.Tensor, p: Params, prefix: str, num_layers: int = 2) -> torch.Tensor:
+    """Hyper-encoder trunk up to (not including) the `feed` 1x1 conv. x [B,1,H,W] -> [B,64,H,W]."""
+    h = ffn(x, p, prefix + "ffn1.")
+    h = torch.sigmoid(gated_ffn(h, p, prefix + "ffn2."))
+    h = ffn(h, p, prefix + "ffn3.")
+    h = torch.sigmoid(gated_ffn(h, p, prefix + "ffn4."))
+    B, C, H, W = h.shape
+    s = h.permute(2, 3, 0, 1).reshape(H * W, B, C)          # (h w) b c
+    for i in range(num_layers):
+        s = batch_tx_layer(s, p, f"{prefix}encoder.layers.{i}.")
+    s = F.layer_norm(s, (C,), p[prefix + "encoder.norm.weight"], p[prefix + "encoder.norm.bias"])
+    return s.reshape(H, W, B, C).permute(2, 3, 0, 1)
+
+
+def gazetr(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    feat = gazetr_features(x, p, prefix)
+    return F.conv2d(feat, p[prefix + "feed.weight"], p[prefix + "feed.bias"])
+
+
+# --------------------------------------------------------------------------- chroma
+def bilinear_up(x: torch.Tensor, r: int) -> torch.Tensor:
+    """Bilinear upsample by integer factor r, align_corners=False, no antialias.
+    src = (dst + 0.5)/r - 0.5 clamped at 0; i0 = floor(src); i1 = min(i0+1, size-1)."""
+    B, C, H, W = x.shape
+
+    def axis(n_in: int):
+        d = torch.arange(n_in * r, dtype=x.dtype)
+        src = ((d + 0.5) * (1.0 / r) - 0.5).clamp(min=0)
+        i0 = src.floor().long().clamp(max=n_in - 1)
+        i1 = (i0 + 1).clamp(max=n_in - 1)
+        lam = src - i0.to(x.dtype)
+        return i0, i1, lam
+
+    y0, y1, ly = axis(H)
+    x0, x1, lx = axis(W)
+    rows0, rows1 = x[:, :, y0, :], x[:, :, y1, :]
+    top = rows0[..., x0] * (1 - lx) + rows0[..., x1] * lx
+    bot = rows1[..., x0] * (1 - lx) + rows1[..., x1] * lx
+    return top * (1 - ly)[:, None] + bot * ly[:, None]
+
+
+# --------------------------------------------------------------------------- whole model
+def conv_sep_kan_forward(x: torch.Tensor, p: Params, *, out_channels: Sequence[int],
+                         grid_size: int, spline_order: int, grid_range: Sequence[float],
+                         upscale: int, in_channels: Sequence[int] = (1,)) -> torch.Tensor:
+    """x [B,3,H,W] (Y,Cb,Cr) -> [B,3,rH,rW].  Every layer sees the Y plane; only the
+    last layer's output survives (the reference's loop overwrites y)."""
+    n_layers = len(out_channels)
+    li = n_layers - 1
+    prefix = f"layers.{li}.encoder.encoder."
+    yplane = x[:, :1]
+    w = gazetr(yplane, p, prefix)
+    y = kan_cell(yplane, w, out_channels[li], grid_size, spline_order, grid_range)
+    y = pixel_shuffle(y, upscale)
+    cb = bilinear_up(x[:, 1:2], upscale)
+    cr = bilinear_up(x[:, 2:3], upscale)
+    return torch.cat([y, cb, cr], dim=1)
+
+
+def init_like_training_setup(p: Params, seed: int = 0) -> Params:
+    """Restates the weight re-initialisation the training pipeline applies before
+    fitting (src/ml/pipelines/default.py:36-57): conv weights kaiming-normal
+    (fan_out, relu) with zero bias; nn.Linear weights N(0, 0.01) with zero bias
+    (this covers out_proj / linear1 / linear2 but NOT in_proj_weight/in_proj_bias,
+    which are plain Parameters, nor the LayerNorms)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, v in p.items():
+        v = v.clone()
+        if v.dim() == 4 and name.endswith(".weight"):
+            fan_out = v.shape[0] * v.shape[2] * v.shape[3]
+            v.normal_(0.0, math.sqrt(2.0 / fan_out), generator=g)
+        elif name.endswith(".bias") and (name[:-5] + ".weight") in p and p[name[:-5] + ".weight"].dim() == 4:
+            v.zero_()
+        elif any(name.endswith(s) for s in ("out_proj.weight", "linear1.weight", "linear2.weight")):
+            v.normal_(0.0, 0.01, generator=g)
+        elif any(name.endswith(s) for s in ("out_proj.bias", "linear1.bias", "linear2.bias")):
+            v.zero_()
+        out[name] = v
+    return out
+
+
+def param_shapes(out_dim: int, grid_size: int, spline_order: int, in_dim: int = 1,
+                 layer: int = 0) -> Dict[str, tuple]:
+    """Names and shapes of the 52 tensors of one ConvSepKanLayer, in state_dict order."""
+    P = kan_param_count(in_dim, out_dim, grid_size, spline_order)
+    pre = f"layers.{layer}.encoder.encoder."
+    C = 64
+    s: Dict[str, tuple] = {}
+
+    def conv(name, co, ci, kh):
+        s[pre + name + ".weight"] = (co, ci, kh, kh)
+        s[pre + name + ".bias"] = (co,)
+
+    conv("ffn1.pointwise1", in_dim, in_dim, 1)
+    conv("ffn1.depthwise", in_dim, 1, 3)
+    conv("ffn1.pointwise2", C, in_dim, 1)
+    for g in ("ffn2", "ffn4"):
+        conv(g + ".fn_1.0", 2 * C, C, 1)
+        conv(g + ".fn_2", C, C, 1)
+        conv(g + ".gate", C, 1, 3)
+        if g == "ffn2":
+            conv("ffn3.pointwise1", C, C, 1)
+            conv("ffn3.depthwise", C, 1, 3)
+            conv("ffn3.pointwise2", C, C, 1)
+    for l in range(2):
+        q = f"{pre}encoder.layers.{l}."
+        s[q + "self_attn.in_proj_weight"] = (3 * C, C)
+        s[q + "self_attn.in_proj_bias"] = (3 * C,)
+        s[q + "self_attn.out_proj.weight"] = (C, C)
+        s[q + "self_attn.out_proj.bias"] = (C,)
+        s[q + "linear1.weight"] = (32, C)
+        s[q + "linear1.bias"] = (32,)
+        s[q + "linear2.weight"] = (C, 32)
+        s[q + "linear2.bias"] = (C,)
+        for n in ("norm1", "norm2"):
+            s[q + n + ".weight"] = (C,)
+            s[q + n + ".bias"] = (C,)
+    s[pre + "encoder.norm.weight"] = (C,)
+    s[pre + "encoder.norm.bias"] = (C,)
+    conv("feed", P, C, 1)
+    return s
+
+
+def random_params(out_dim: int, grid_size: int, spline_order: int, seed: int = 0,
+                  scale: float = 1.0, dtype=torch.float32) -> Params:
+    """Deterministic, non-degenerate parameters (non-zero biases, non-unit LayerNorm
+    gains) for parity tests; NOT any initialisation the reference uses."""
+    g = torch.Generator().manual_seed(seed)
+    out: Params = {}
+    for name, shp in param_shapes(out_dim, grid_size, spline_order).items():
+        fan_in = 1
+        for d in shp[1:]:
+            fan_in *= d
+        if "norm" in name and name.endswith(".weight"):
+            v = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        elif name.endswith("bias"):
+            v = 0.1 * torch.randn(shp, generator=g)
+        else:
+            v = scale * torch.randn(shp, generator=g) / math.sqrt(max(fan_in, 1))
+        out[name] = v.to(dtype)
+    return out

@@ -1,0 +1,233 @@
+"""Generates the golden fixtures in this directory by IMPORTING THE REFERENCE.
+
+Run once, in the build container (the reference checkout is not available on the
+GPU machine):   PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Only data is written (inputs, weights, expected outputs / gradients as .npz).
+The one shim is `torch.Any = typing.Any`: the reference annotates three return
+types with torch.Any, which current torch no longer exposes.
+"""
+import os
+import sys
+import typing
+
+import numpy as np
+import torch
+
+REF = os.environ.get("KSR_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+torch.Any = typing.Any  # noqa
+
+from conv_sep_kan.bspline import compute_bspline                      # noqa: E402
+from conv_sep_kan.kan_layer import KANLayer, generate_control_points   # noqa: E402
+from conv_sep_kan.conv_sep_kan_cells import ConvSepKanCell             # noqa: E402
+from conv_sep_kan.unet_blocks import FFN, GatedFFN                     # noqa: E402
+from conv_sep_kan.gazetr import GazeTR                                 # noqa: E402
+from conv_sep_kan import ConvSepKan                                    # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items() if v.ndim} if len(out) < 12 else len(out))
+
+
+def perturb_norms(m, gen):
+    """Default LayerNorm params (1, 0) hide scale/shift bugs: randomise them."""
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.LayerNorm):
+            with torch.no_grad():
+                mod.weight.copy_(1 + 0.1 * torch.randn(mod.weight.shape, generator=gen))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=gen))
+
+
+# ---------------------------------------------------------------- (1) basis functions
+def gold_bspline():
+    cases = [(5, 3), (16, 3), (11, 3), (5, 1), (8, 2)]
+    gen = torch.Generator().manual_seed(11)
+    out = {}
+    for G, k in cases:
+        grid = generate_control_points(-1.0, 1.0, 1, 1, k, G)          # [1,1,M]
+        t = grid[0, 0]
+        ulp_up = torch.nextafter(t, torch.full_like(t, 10.0))
+        ulp_dn = torch.nextafter(t, torch.full_like(t, -10.0))
+        special = torch.tensor([-1.0, 1.0, 0.0, 0.2, 0.6, 1.25, 1.5, 2.2, -2.2, 2.3, -2.3])
+        xs = torch.cat([t, ulp_up, ulp_dn, special,
+                        torch.rand(256, generator=gen),
+                        torch.rand(256, generator=gen) * 5.0 - 2.5])
+        b = compute_bspline(xs[:, None], grid, k)                      # [N,1,1,K]
+        out[f"G{G}_k{k}_knots"] = t
+        out[f"G{G}_k{k}_x"] = xs
+        out[f"G{G}_k{k}_basis"] = b[:, 0, 0, :]
+    # the reference's own (broken) __main__ parameter set, bspline.py:45-52
+    G, k, I, O = 11, 3, 5, 7
+    grid = generate_control_points(-1.0, 1.0, I, O, k, G)
+    x = torch.ones(2, I) / 0.8
+    out["main_x"] = x
+    out["main_basis"] = compute_bspline(x, grid, k)                    # [2,O,I,K]
+    save("bspline", **out)
+
+
+# ---------------------------------------------------------------- (2) KAN layer + grads
+def gold_kan_layer():
+    gen = torch.Generator().manual_seed(22)
+    out = {}
+    for (O, I, G, k) in [(4, 1, 5, 3), (16, 1, 5, 3), (7, 5, 5, 3), (16, 1, 16, 3)]:
+        N, K = 64, G + k
+        layer = KANLayer(I, O, G, k, 0.1, [-1, 1])
+        x = (torch.rand(N, I, generator=gen) * 2.6 - 1.3).requires_grad_()
+        coef = torch.randn(N, O, I, K, generator=gen).requires_grad_()
+        uw = torch.randn(N, O, I, generator=gen).requires_grad_()
+        rw = torch.randn(N, O, I, generator=gen).requires_grad_()
+        y = layer(x, coef, uw, rw)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        tag = f"O{O}_I{I}_G{G}_k{k}_"
+        out.update({tag + "x": x, tag + "coef": coef, tag + "uw": uw, tag + "rw": rw,
+                    tag + "y": y, tag + "gy": gy, tag + "gx": x.grad, tag + "gcoef": coef.grad,
+                    tag + "guw": uw.grad, tag + "grw": rw.grad})
+    save("kan_layer", **out)
+
+
+# ---------------------------------------------------------------- (3) cell + shuffle
+def gold_cell():
+    gen = torch.Generator().manual_seed(33)
+    out = {}
+    for (r, G, k, I) in [(2, 5, 3, 1), (4, 5, 3, 1), (4, 16, 3, 1), (2, 5, 3, 3)]:
+        O = r * r
+        cell = ConvSepKanCell(I, O, G, k, 0.1, [-1, 1])
+        B, H, W = 2, 8, 8
+        x = (torch.rand(B, I, H, W, generator=gen) * 2.4 - 1.2).requires_grad_()
+        w = torch.randn(B, int(cell.size), H, W, generator=gen).requires_grad_()
+        y = torch.nn.PixelShuffle(r)(cell(x, w))
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        tag = f"r{r}_G{G}_k{k}_I{I}_"
+        out.update({tag + "x": x, tag + "w": w, tag + "y": y, tag + "gy": gy,
+                    tag + "gx": x.grad, tag + "gw": w.grad, tag + "size": int(cell.size),
+                    tag + "offsets": np.asarray(cell._kan_params_indices)})
+    save("kan_cell", **out)
+
+
+# ---------------------------------------------------------------- (4) FFN / GatedFFN
+def gold_ffn():
+    gen = torch.Generator().manual_seed(44)
+    torch.manual_seed(44)
+    out = {}
+    for name, mod, cin in [("ffn_1_64", FFN(1, 64), 1), ("ffn_64_64", FFN(64, 64), 64),
+                           ("gated", GatedFFN(64, 64, 3, torch.nn.ReLU()), 64)]:
+        x = torch.randn(2, cin, 9, 11, generator=gen).requires_grad_()
+        y = mod(x)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out.update({name + ".x": x, name + ".y": y, name + ".gy": gy, name + ".gx": x.grad})
+        for n, p in mod.named_parameters():
+            out[f"{name}.p.{n}"] = p
+            out[f"{name}.g.{n}"] = p.grad
+    save("ffn", **out)
+
+
+# ---------------------------------------------------------------- (5) GazeTR eval
+def gold_gazetr():
+    torch.manual_seed(55)
+    gen = torch.Generator().manual_seed(55)
+    P = 40
+    m = GazeTR(1, P).eval()
+    perturb_norms(m, gen)
+    out = {f"p.{n}": p for n, p in m.named_parameters()}
+    for B in (1, 2, 4):
+        m.zero_grad()
+        x = torch.rand(B, 1, 8, 8, generator=gen).requires_grad_()
+        y = m(x)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out.update({f"B{B}.x": x, f"B{B}.y": y, f"B{B}.gy": gy, f"B{B}.gx": x.grad})
+        for n, p in m.named_parameters():
+            out[f"B{B}.g.{n}"] = p.grad.clone()
+    save("gazetr", **out)
+
+
+# ---------------------------------------------------------------- (6)+(8) whole model
+def gold_model():
+    for (r, G, k) in [(2, 5, 3), (4, 5, 3), (4, 16, 3)]:
+        torch.manual_seed(600 + 10 * r + G)
+        gen = torch.Generator().manual_seed(600 + 10 * r + G)
+        m = ConvSepKan([1], [r * r], [3], G, k, 0.1, [-1, 1], r).eval()
+        perturb_norms(m, gen)
+        B, H, W = 2, 16, 16
+        x = torch.rand(B, 3, H, W, generator=gen)
+        y = m(x)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out = {"x": x, "y": y, "gy": gy}
+        for n, p in m.named_parameters():
+            out["p." + n] = p
+            out["g." + n] = p.grad
+        # fp64 run of the same graph to apportion fp32 rounding error
+        m64 = ConvSepKan([1], [r * r], [3], G, k, 0.1, [-1, 1], r).double().eval()
+        m64.load_state_dict({n: v.double() for n, v in m.state_dict().items()})
+        # the knot tensor is a plain attribute, not a buffer: convert it by hand
+        act = m64.layers[0].kan_cell.kan_layer.activation_fn
+        act.grid = generate_control_points(-1.0, 1.0, 1, r * r, k, G).double()
+        y64 = m64(x.double())
+        (y64 * gy.double()).sum().backward()
+        out["y64"] = y64
+        for n, p in m64.named_parameters():
+            out["g64." + n] = p.grad
+        save(f"model_r{r}_G{G}_k{k}", **out)
+
+
+# ---------------------------------------------------------------- (9) cfg-1 shaped smoke
+def gold_cfg1():
+    torch.manual_seed(9)
+    gen = torch.Generator().manual_seed(9)
+    m = ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2).eval()
+    perturb_norms(m, gen)
+    x = torch.rand(4, 3, 64, 64, generator=gen)
+    y = m(x)
+    out = {"x_seed": 9, "y_sum": y.double().sum(), "y_abs_sum": y.double().abs().sum(),
+           "y_corner": y[:, :, :4, :4], "y_row": y[1, 0, 77, :]}
+    for n, p in m.named_parameters():
+        out["p." + n] = p
+    out["x"] = x
+    save("cfg1_smoke", **out)
+
+
+# ---------------------------------------------------------------- train-mode statistics
+def gold_dropout_stats():
+    """Train-mode (dropout p=0.1 live) output mean/var over 64 RNG seeds."""
+    torch.manual_seed(77)
+    gen = torch.Generator().manual_seed(77)
+    m = ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2)
+    perturb_norms(m, gen)
+    x = torch.rand(4, 3, 8, 8, generator=gen)
+    m.eval()
+    y_eval = m(x)
+    m.train()
+    ys = []
+    for s in range(64):
+        torch.manual_seed(1000 + s)
+        ys.append(m(x).detach())
+    ys = torch.stack(ys)
+    out = {"x": x, "y_eval": y_eval, "y_train_mean": ys.mean(0), "y_train_var": ys.var(0)}
+    for n, p in m.named_parameters():
+        out["p." + n] = p
+    save("dropout_stats", **out)
+
+
+if __name__ == "__main__":
+    gold_bspline()
+    gold_kan_layer()
+    gold_cell()
+    gold_ffn()
+    gold_gazetr()
+    gold_model()
+    gold_cfg1()
+    gold_dropout_stats()

@@ -1,0 +1,154 @@
+"""Pins the CPU oracle against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  Runs without a GPU.
+
+Tolerances (fp32 vs reference fp32): forward max|d| <= 1e-5 + 1e-4*|ref|;
+gradients rel-L2 <= 1e-4 per tensor.  The basis functions are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2, t
+from oracle import convsepkan_oracle as orc
+
+FWD_ATOL, FWD_RTOL, GRAD_REL = 1e-5, 1e-4, 1e-4
+
+
+def assert_fwd(a, ref):
+    assert a.shape == ref.shape
+    err = (a - ref).abs()
+    bound = FWD_ATOL + FWD_RTOL * ref.abs()
+    assert bool((err <= bound).all()), f"max err {float(err.max()):.3e}"
+
+
+@pytest.mark.parametrize("G,k", [(5, 3), (16, 3), (11, 3), (5, 1), (8, 2)])
+def test_knots_and_basis_bit_exact(G, k):
+    g = load_golden("bspline")
+    knots = orc.knot_vector(G, k, [-1.0, 1.0])
+    assert np.array_equal(knots.numpy(), g[f"G{G}_k{k}_knots"])
+    x = t(g[f"G{G}_k{k}_x"])
+    b = orc.bspline_basis(x[:, None], knots, k)[:, 0]
+    assert np.array_equal(b.numpy(), g[f"G{G}_k{k}_basis"])
+
+
+def test_basis_known_values():
+    """Spot values measured on the reference: x=-1 -> [1/6,2/3,1/6,0..]; x=1.5 sums to
+    0.682 (partial support past the range); |x|>=2.2 -> all zero (G=5,k=3)."""
+    knots = orc.knot_vector(5, 3, [-1.0, 1.0])
+    b = orc.bspline_basis(torch.tensor([[-1.0], [1.5], [2.2], [-2.3]]), knots, 3)[:, 0]
+    assert torch.allclose(b[0, :3], torch.tensor([1 / 6, 2 / 3, 1 / 6]), atol=1e-6)
+    assert float(b[0, 3:].abs().max()) == 0.0
+    assert abs(float(b[1].sum()) - 0.682) < 1e-3
+    assert float(b[2:].abs().max()) == 0.0
+
+
+def test_basis_reference_main_parameters():
+    g = load_golden("bspline")
+    knots = orc.knot_vector(11, 3, [-1.0, 1.0])
+    b = orc.bspline_basis(t(g["main_x"]), knots, 3)          # [2, I, K]
+    ref = t(g["main_basis"])                                 # [2, O, I, K]
+    for o in range(ref.shape[1]):
+        assert torch.equal(b, ref[:, o])
+
+
+@pytest.mark.parametrize("O,I,G,k", [(4, 1, 5, 3), (16, 1, 5, 3), (7, 5, 5, 3), (16, 1, 16, 3)])
+def test_kan_layer_fwd_grads(O, I, G, k):
+    g = load_golden("kan_layer")
+    tag = f"O{O}_I{I}_G{G}_k{k}_"
+    x, coef, uw, rw = (t(g[tag + n]).requires_grad_() for n in ("x", "coef", "uw", "rw"))
+    y = orc.kan_eval(x, coef, uw, rw, orc.knot_vector(G, k, [-1, 1]), k)
+    # the reference's coef[None] broadcast leaves a leading singleton: [1, N, O]
+    assert_fwd(y.detach(), t(g[tag + "y"])[0])
+    (y * t(g[tag + "gy"])[0]).sum().backward()
+    for n, v in (("gx", x), ("gcoef", coef), ("guw", uw), ("grw", rw)):
+        assert rel_l2(v.grad, t(g[tag + n])) <= GRAD_REL, n
+
+
+@pytest.mark.parametrize("r,G,k,I", [(2, 5, 3, 1), (4, 5, 3, 1), (4, 16, 3, 1), (2, 5, 3, 3)])
+def test_kan_cell_shuffle(r, G, k, I):
+    g = load_golden("kan_cell")
+    tag = f"r{r}_G{G}_k{k}_I{I}_"
+    O = r * r
+    assert orc.kan_param_count(I, O, G, k) == int(g[tag + "size"])
+    K = G + k
+    assert list(g[tag + "offsets"]) == [0, O * I * K, O * I * (K + 1), O * I * (K + 2)]
+    x = t(g[tag + "x"]).requires_grad_()
+    w = t(g[tag + "w"]).requires_grad_()
+    y = orc.pixel_shuffle(orc.kan_cell(x, w, O, G, k, [-1, 1]), r)
+    assert_fwd(y.detach(), t(g[tag + "y"]))
+    (y * t(g[tag + "gy"])).sum().backward()
+    assert rel_l2(x.grad, t(g[tag + "gx"])) <= GRAD_REL
+    assert rel_l2(w.grad, t(g[tag + "gw"])) <= GRAD_REL
+
+
+@pytest.mark.parametrize("name,kind", [("ffn_1_64", "ffn"), ("ffn_64_64", "ffn"), ("gated", "gated")])
+def test_ffn_blocks(name, kind):
+    g = load_golden("ffn")
+    p = {k[len(name) + 3:]: t(v).requires_grad_() for k, v in g.items() if k.startswith(name + ".p.")}
+    x = t(g[name + ".x"]).requires_grad_()
+    y = orc.ffn(x, p, "") if kind == "ffn" else orc.gated_ffn(x, p, "")
+    assert_fwd(y.detach(), t(g[name + ".y"]))
+    (y * t(g[name + ".gy"])).sum().backward()
+    assert rel_l2(x.grad, t(g[name + ".gx"])) <= GRAD_REL
+    for n, v in p.items():
+        assert rel_l2(v.grad, t(g[f"{name}.g.{n}"])) <= GRAD_REL, n
+
+
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_gazetr_eval(B):
+    """Pins the batch-axis attention, including its B=1 collapse."""
+    g = load_golden("gazetr")
+    p = {k[2:]: t(v).requires_grad_() for k, v in g.items() if k.startswith("p.")}
+    x = t(g[f"B{B}.x"]).requires_grad_()
+    y = orc.gazetr(x, p, "")
+    assert_fwd(y.detach(), t(g[f"B{B}.y"]))
+    (y * t(g[f"B{B}.gy"])).sum().backward()
+    assert rel_l2(x.grad, t(g[f"B{B}.gx"])) <= GRAD_REL
+    for n, v in p.items():
+        assert rel_l2(v.grad, t(g[f"B{B}.g.{n}"])) <= GRAD_REL, n
+
+
+@pytest.mark.parametrize("r,G,k", [(2, 5, 3), (4, 5, 3), (4, 16, 3)])
+def test_full_model(r, G, k):
+    g = load_golden(f"model_r{r}_G{G}_k{k}")
+    p = {n[2:]: t(v).requires_grad_() for n, v in g.items() if n.startswith("p.")}
+    assert {n: tuple(v.shape) for n, v in p.items()} == orc.param_shapes(r * r, G, k)
+    x = t(g["x"])
+    y = orc.conv_sep_kan_forward(x, p, out_channels=[r * r], grid_size=G, spline_order=k,
+                                 grid_range=[-1, 1], upscale=r)
+    assert_fwd(y.detach(), t(g["y"]))
+    (y * t(g["gy"])).sum().backward()
+    for n, v in p.items():
+        ref, ref64 = t(g["g." + n]), t(g["g64." + n])
+        assert rel_l2(v.grad, ref) <= GRAD_REL, n
+        # error against the fp64 graph is no worse than twice the reference's own
+        e_me = float((v.grad.double() - ref64).norm())
+        e_ref = float((ref.double() - ref64).norm())
+        assert e_me <= 2 * e_ref + 1e-6 * float(ref64.norm()) + 1e-9, n
+
+
+def test_full_model_fp64_matches_reference_fp64():
+    g = load_golden("model_r4_G5_k3")
+    p = {n[2:]: t(v).double() for n, v in g.items() if n.startswith("p.")}
+    y = orc.conv_sep_kan_forward(t(g["x"]).double(), p, out_channels=[16], grid_size=5,
+                                 spline_order=3, grid_range=[-1, 1], upscale=4)
+    assert float((y - t(g["y64"])).abs().max()) < 1e-9
+
+
+def test_bilinear_matches_chroma_planes():
+    g = load_golden("model_r4_G5_k3")
+    x = t(g["x"])
+    up = orc.bilinear_up(x[:, 1:], 4)
+    assert_fwd(up, t(g["y"])[:, 1:])
+
+
+def test_cfg1_shape_smoke():
+    g = load_golden("cfg1_smoke")
+    p = {n[2:]: t(v) for n, v in g.items() if n.startswith("p.")}
+    with torch.no_grad():
+        y = orc.conv_sep_kan_forward(t(g["x"]), p, out_channels=[4], grid_size=5, spline_order=3,
+                                     grid_range=[-1, 1], upscale=2)
+    assert y.shape == (4, 3, 128, 128)
+    assert_fwd(y[:, :, :4, :4], t(g["y_corner"]))
+    assert_fwd(y[1, 0, 77], t(g["y_row"]))
+    assert abs(float(y.double().sum()) - float(g["y_sum"])) < 1e-2
