@@ -1,0 +1,106 @@
+// Shared device/host helpers for libksr (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define KSR_OK 0
+#define KSR_ERR_ARG (-1)
+#define KSR_ERR_UNSUPPORTED (-2)
+#define KSR_ERR_HIP (-3)
+#define KSR_ERR_COMM (-4)
+
+#define KSR_MAX_KNOTS 64
+#define KSR_MAX_ORDER 3
+
+// thread-local last-error text (read through ksr_last_error())
+void ksr_set_error(const char* fmt, ...);
+
+#define KSR_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ksr_set_error(__VA_ARGS__);          \
+            return KSR_ERR_ARG;                  \
+        }                                        \
+    } while (0)
+
+#define KSR_UNSUPPORTED(cond, ...)               \
+    do {                                         \
+        if (cond) {                              \
+            ksr_set_error(__VA_ARGS__);          \
+            return KSR_ERR_UNSUPPORTED;          \
+        }                                        \
+    } while (0)
+
+#define KSR_LAUNCH_CHECK(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            ksr_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return KSR_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+
+struct KsrKnots {
+    float t[KSR_MAX_KNOTS];
+    int M;  // number of knots = G + 2k + 1
+    int k;  // spline order
+};
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#if defined(__HIPCC__)
+
+// ---------------------------------------------------------------------------------------------
+// B-spline basis, local form.  For x in [t_m, t_{m+1}) only the k+1 functions B_{m-k..m} are
+// non-zero.  N[a] (a = 0..K) receives B_{m-K+a, K}(x); entries whose index falls outside
+// [0, M-2-K] are 0 and must not be used.  The arithmetic follows the textbook recursion
+//   B_{j,p} = ((x - t_j) / (t_{j+p} - t_j)) * B_{j,p-1} + ((t_{j+p+1} - x) / (t_{j+p+1} - t_{j+1})) * B_{j+1,p-1}
+// with separately rounded divide, multiply and add (no FMA contraction), so the values are
+// bit-identical to an fp32 evaluation of the dense recursion.  dN (optional) is d/dx with the
+// order-0 indicator held constant.  Returns m, or -1 when x lies in no interval (all zero).
+template <int K, bool WITH_D>
+__device__ __forceinline__ int ksr_bspline_local(float x, const float* __restrict__ t, int M,
+                                                 float (&N)[K + 1], float (&dN)[K + 1]) {
+#pragma clang fp contract(off)
+    int cnt = 0;
+    for (int j = 0; j < M; ++j) cnt += (x >= t[j]) ? 1 : 0;
+    const int m = cnt - 1;
+#pragma unroll
+    for (int a = 0; a <= K; ++a) { N[a] = 0.f; dN[a] = 0.f; }
+    if (m < 0 || m >= M - 1 || !(x < t[m + 1])) return -1;
+    // order 0: single non-zero at local slot 0 (j = m); keep values right-aligned per order:
+    // at order p the live slots are [0..p] with j = m - p + a.
+    N[0] = 1.f;
+#pragma unroll
+    for (int p = 1; p <= K; ++p) {
+#pragma unroll
+        for (int a = p; a >= 0; --a) {
+            const int j = m - p + a;
+            const bool valid = (j >= 0) && (j <= M - 2 - p);
+            const int jc = valid ? j : 0;
+            const float tj = t[jc], tjp = t[jc + p], tjp1 = t[jc + p + 1], tj1 = t[jc + 1];
+            const float oldL = (a >= 1) ? N[a - 1] : 0.f;   // B_{j,p-1}
+            const float oldR = (a <= p - 1) ? N[a] : 0.f;   // B_{j+1,p-1}
+            const float d1 = __fsub_rn(tjp, tj), d2 = __fsub_rn(tjp1, tj1);
+            const float L = __fdiv_rn(__fsub_rn(x, tj), d1);
+            const float R = __fdiv_rn(__fsub_rn(tjp1, x), d2);
+            float v = __fadd_rn(__fmul_rn(L, oldL), __fmul_rn(R, oldR));
+            if (WITH_D) {
+                const float doldL = (a >= 1) ? dN[a - 1] : 0.f;
+                const float doldR = (a <= p - 1) ? dN[a] : 0.f;
+                float dv = __fdiv_rn(oldL, d1) + L * doldL - __fdiv_rn(oldR, d2) + R * doldR;
+                dN[a] = valid ? dv : 0.f;
+            }
+            N[a] = valid ? v : 0.f;
+        }
+    }
+    return m;
+}
+
+__device__ __forceinline__ float ksr_silu(float x) { return x / (1.f + expf(-x)); }
+__device__ __forceinline__ float ksr_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+#endif  // __HIPCC__

@@ -1,0 +1,290 @@
+// Stand-alone KAN-cell op (coefficient tensor materialised) and the chroma bilinear upsampler.
+//
+// kan_cell: per LR pixel n and output o
+//   out[n,o] = sum_i rw[n,o,i]*silu(x[n,i]) + uw[n,o,i] * sum_g B_g(x[n,i]) * coef[n,o,i,g]
+// with the per-pixel parameter vector w[n, :] = [coef (o,i,g) | uw (o,i) | rw (o,i)], optionally
+// followed by the pixel shuffle out[b, 0, h*r+o/r, w*r+o%r].  HBM-bound: one thread per pixel,
+// only the k+1 live coefficients per (o,i) are read.
+#include "ksr_common.h"
+
+namespace {
+
+struct CellArgs {
+    const float* x;   // [B, I, H, W]
+    const float* w;   // NCHW [B, P, H, W] or NHWC [B*H*W, P]
+    float* out;       // [B, O, H, W] or shuffled [B, O/r^2, rH, rW]
+    const float* gout;  // backward: gradient of out (same layout as out)
+    float* gw;        // backward: gradient of w (same layout as w)
+    float* gx;        // backward: gradient of x (may be null)
+    int B, I, O, H, W, Kc, P;
+    int w_nhwc;
+    int r;            // 0: no shuffle
+    long out_bstride;  // elements between images in out (allows writing into a wider tensor)
+};
+
+__device__ __forceinline__ long w_index(const CellArgs& a, int b, int hw, int p, int HW) {
+    return a.w_nhwc ? ((long)(b * (long)HW + hw) * a.P + p) : (((long)b * a.P + p) * HW + hw);
+}
+
+__device__ __forceinline__ long out_index(const CellArgs& a, int b, int o, int h, int w) {
+    if (a.r > 0) {
+        const int rr = a.r * a.r;
+        const int c = o / rr, q = o % rr;
+        const int oy = h * a.r + q / a.r, ox = w * a.r + q % a.r;
+        return (long)b * a.out_bstride + ((long)c * (a.H * a.r) + oy) * (long)(a.W * a.r) + ox;
+    }
+    return (long)b * a.out_bstride + ((long)o * a.H + h) * a.W + w;
+}
+
+template <int K, int OMAX>
+__global__ void __launch_bounds__(256) kan_cell_fwd_kernel(CellArgs a, KsrKnots kn) {
+    __shared__ float t[KSR_MAX_KNOTS];
+    if (threadIdx.x < KSR_MAX_KNOTS) t[threadIdx.x] = kn.t[threadIdx.x < kn.M ? threadIdx.x : 0];
+    __syncthreads();
+    const int HW = a.H * a.W;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (long)a.B * HW) return;
+    const int b = (int)(n / HW), hw = (int)(n % HW);
+    float acc[OMAX];
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) acc[o] = 0.f;
+    const int uw_off = a.O * a.I * a.Kc, rw_off = uw_off + a.O * a.I;
+    for (int i = 0; i < a.I; ++i) {
+        const float x = a.x[((long)b * a.I + i) * HW + hw];
+        float N[K + 1], dN[K + 1];
+        const int m = ksr_bspline_local<K, false>(x, t, kn.M, N, dN);
+        const float sl = ksr_silu(x);
+#pragma unroll
+        for (int o = 0; o < OMAX; ++o) {
+            if (o < a.O) {
+                float S = 0.f;
+                if (m >= 0) {
+#pragma unroll
+                    for (int q = 0; q <= K; ++q) {
+                        const int g = m - K + q;
+                        if (g >= 0 && g < a.Kc) S += N[q] * a.w[w_index(a, b, hw, (o * a.I + i) * a.Kc + g, HW)];
+                    }
+                }
+                const float uw = a.w[w_index(a, b, hw, uw_off + o * a.I + i, HW)];
+                const float rw = a.w[w_index(a, b, hw, rw_off + o * a.I + i, HW)];
+                acc[o] += rw * sl + uw * S;
+            }
+        }
+    }
+    const int h = hw / a.W, wx = hw % a.W;
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o)
+        if (o < a.O) a.out[out_index(a, b, o, h, wx)] = acc[o];
+}
+
+template <int K, int OMAX>
+__global__ void __launch_bounds__(256) kan_cell_bwd_kernel(CellArgs a, KsrKnots kn) {
+    __shared__ float t[KSR_MAX_KNOTS];
+    if (threadIdx.x < KSR_MAX_KNOTS) t[threadIdx.x] = kn.t[threadIdx.x < kn.M ? threadIdx.x : 0];
+    __syncthreads();
+    const int HW = a.H * a.W;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (long)a.B * HW) return;
+    const int b = (int)(n / HW), hw = (int)(n % HW);
+    const int h = hw / a.W, wx = hw % a.W;
+    float go[OMAX];
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) go[o] = (o < a.O) ? a.gout[out_index(a, b, o, h, wx)] : 0.f;
+    const int uw_off = a.O * a.I * a.Kc, rw_off = uw_off + a.O * a.I;
+    for (int i = 0; i < a.I; ++i) {
+        const float x = a.x[((long)b * a.I + i) * HW + hw];
+        float N[K + 1], dN[K + 1];
+        const int m = ksr_bspline_local<K, true>(x, t, kn.M, N, dN);
+        const float sg = ksr_sigmoid(x);
+        const float sl = x * sg;
+        const float dsl = sg * (1.f + x * (1.f - sg));
+        float gxi = 0.f;
+#pragma unroll
+        for (int o = 0; o < OMAX; ++o) {
+            if (o < a.O) {
+                const long iuw = w_index(a, b, hw, uw_off + o * a.I + i, HW);
+                const long irw = w_index(a, b, hw, rw_off + o * a.I + i, HW);
+                const float uw = a.w[iuw], rw = a.w[irw];
+                float S = 0.f, dS = 0.f;
+                for (int g = 0; g < a.Kc; ++g) {
+                    const int q = g - (m - K);
+                    float bg = 0.f, dbg = 0.f;
+                    if (m >= 0) {
+#pragma unroll
+                        for (int qq = 0; qq <= K; ++qq)
+                            if (qq == q) { bg = N[qq]; dbg = dN[qq]; }
+                    }
+                    const long ic = w_index(a, b, hw, (o * a.I + i) * a.Kc + g, HW);
+                    if (bg != 0.f || dbg != 0.f) {
+                        const float c = a.w[ic];
+                        S += bg * c;
+                        dS += dbg * c;
+                    }
+                    a.gw[ic] = go[o] * uw * bg;
+                }
+                a.gw[iuw] = go[o] * S;
+                a.gw[irw] = go[o] * sl;
+                gxi += go[o] * (rw * dsl + uw * dS);
+            }
+        }
+        if (a.gx) a.gx[((long)b * a.I + i) * HW + hw] = gxi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ bilinear
+// out[b, oc0 + c, :, :] = bilinear_up(in[b, ic0 + c, :, :], r), c < nc.  align_corners = false.
+struct BilArgs {
+    const float* in;
+    float* out;
+    int B, nc, H, W, r;
+    long in_bstride, in_cstride, out_bstride, out_cstride;
+    int ic0, oc0;
+};
+
+__global__ void __launch_bounds__(256) bilinear_up_kernel(BilArgs a) {
+    const int OW = a.W * a.r, OH = a.H * a.r;
+    const int OW4 = OW / 4;  // r in {2,4,...}: OW % 4 == 0 is checked by the host
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * a.nc * OH * OW4;
+    if (idx >= total) return;
+    const int x4 = (int)(idx % OW4);
+    const int oy = (int)((idx / OW4) % OH);
+    const int c = (int)((idx / ((long)OW4 * OH)) % a.nc);
+    const int b = (int)(idx / ((long)OW4 * OH * a.nc));
+    const float sc = 1.0f / (float)a.r;
+    float sy = sc * ((float)oy + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+    const float* p = a.in + (long)b * a.in_bstride + (long)(a.ic0 + c) * a.in_cstride;
+    const float* r0 = p + (long)y0 * a.W;
+    const float* r1 = p + (long)y1 * a.W;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ox = x4 * 4 + e;
+        float sx = sc * ((float)ox + 0.5f) - 0.5f;
+        sx = sx < 0.f ? 0.f : sx;
+        const int x0 = (int)sx;
+        const int x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+        const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+        v[e] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+    }
+    float* o = a.out + (long)b * a.out_bstride + (long)(a.oc0 + c) * a.out_cstride + (long)oy * OW + x4 * 4;
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+__global__ void __launch_bounds__(256) bilinear_up_scalar_kernel(BilArgs a) {
+    const int OW = a.W * a.r, OH = a.H * a.r;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * a.nc * OH * OW;
+    if (idx >= total) return;
+    const int ox = (int)(idx % OW);
+    const int oy = (int)((idx / OW) % OH);
+    const int c = (int)((idx / ((long)OW * OH)) % a.nc);
+    const int b = (int)(idx / ((long)OW * OH * a.nc));
+    const float sc = 1.0f / (float)a.r;
+    float sy = sc * ((float)oy + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    float sx = sc * ((float)ox + 0.5f) - 0.5f;
+    sx = sx < 0.f ? 0.f : sx;
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0), x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+    const float ly1 = sy - (float)y0, ly0 = 1.f - ly1, lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+    const float* p = a.in + (long)b * a.in_bstride + (long)(a.ic0 + c) * a.in_cstride;
+    a.out[(long)b * a.out_bstride + (long)(a.oc0 + c) * a.out_cstride + (long)oy * OW + ox] =
+        ly0 * (lx0 * p[(long)y0 * a.W + x0] + lx1 * p[(long)y0 * a.W + x1]) +
+        ly1 * (lx0 * p[(long)y1 * a.W + x0] + lx1 * p[(long)y1 * a.W + x1]);
+}
+
+template <int K>
+int launch_cell(bool bwd, const CellArgs& a, const KsrKnots& kn, hipStream_t s) {
+    const long n = (long)a.B * a.H * a.W;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+#define KSR_CELL_DISPATCH(OM)                                                        \
+    do {                                                                             \
+        if (bwd) hipLaunchKernelGGL((kan_cell_bwd_kernel<K, OM>), grid, block, 0, s, a, kn); \
+        else hipLaunchKernelGGL((kan_cell_fwd_kernel<K, OM>), grid, block, 0, s, a, kn);     \
+    } while (0)
+    if (a.O <= 4) KSR_CELL_DISPATCH(4);
+    else if (a.O <= 16) KSR_CELL_DISPATCH(16);
+    else KSR_CELL_DISPATCH(64);
+#undef KSR_CELL_DISPATCH
+    KSR_LAUNCH_CHECK("kan_cell");
+    return KSR_OK;
+}
+
+int fill_knots(KsrKnots& kn, const float* knots, int n_knots, int k, int Kc) {
+    KSR_CHECK_ARG(knots != nullptr, "knots is null");
+    KSR_UNSUPPORTED(k < 0 || k > KSR_MAX_ORDER, "spline_order %d not supported (0..%d)", k, KSR_MAX_ORDER);
+    KSR_UNSUPPORTED(n_knots > KSR_MAX_KNOTS, "%d knots exceed the limit of %d", n_knots, KSR_MAX_KNOTS);
+    KSR_CHECK_ARG(n_knots == Kc + k + 1, "n_knots (%d) must equal grid_size + 2*spline_order + 1 = %d", n_knots, Kc + k + 1);
+    for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = i < n_knots ? knots[i] : knots[n_knots - 1];
+    kn.M = n_knots;
+    kn.k = k;
+    return KSR_OK;
+}
+
+int cell_common(bool bwd, CellArgs& a, const float* knots, int n_knots, int k, hipStream_t s) {
+    KSR_CHECK_ARG(a.B > 0 && a.I > 0 && a.O > 0 && a.H > 0 && a.W > 0 && a.Kc > 0, "kan_cell: non-positive dimension");
+    KSR_UNSUPPORTED(a.O > 64, "kan_cell: out_dim %d > 64 not supported", a.O);
+    KSR_CHECK_ARG(a.r == 0 || a.O % (a.r * a.r) == 0, "kan_cell: out_dim %d not divisible by r^2 (r=%d)", a.O, a.r);
+    a.P = a.O * a.I * (a.Kc + 2);
+    KsrKnots kn;
+    int rc = fill_knots(kn, knots, n_knots, k, a.Kc);
+    if (rc) return rc;
+    switch (k) {
+        case 0: return launch_cell<0>(bwd, a, kn, s);
+        case 1: return launch_cell<1>(bwd, a, kn, s);
+        case 2: return launch_cell<2>(bwd, a, kn, s);
+        default: return launch_cell<3>(bwd, a, kn, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int ksr_kan_cell_fwd(const float* x, const float* w, float* out, int B, int I, int O, int H, int W,
+                                int n_coef, const float* knots, int n_knots, int spline_order, int w_nhwc,
+                                int shuffle_r, int64_t out_batch_stride, hipStream_t stream) {
+    KSR_CHECK_ARG(x && w && out, "kan_cell_fwd: null pointer");
+    CellArgs a{};
+    a.x = x; a.w = w; a.out = out;
+    a.B = B; a.I = I; a.O = O; a.H = H; a.W = W; a.Kc = n_coef; a.w_nhwc = w_nhwc; a.r = shuffle_r;
+    a.out_bstride = out_batch_stride > 0 ? out_batch_stride : (long)O * H * W;
+    return cell_common(false, a, knots, n_knots, spline_order, stream);
+}
+
+extern "C" int ksr_kan_cell_bwd(const float* x, const float* w, const float* gout, float* gw, float* gx, int B, int I,
+                                int O, int H, int W, int n_coef, const float* knots, int n_knots, int spline_order,
+                                int w_nhwc, int shuffle_r, int64_t gout_batch_stride, hipStream_t stream) {
+    KSR_CHECK_ARG(x && w && gout && gw, "kan_cell_bwd: null pointer");
+    CellArgs a{};
+    a.x = x; a.w = w; a.gout = gout; a.gw = gw; a.gx = gx;
+    a.B = B; a.I = I; a.O = O; a.H = H; a.W = W; a.Kc = n_coef; a.w_nhwc = w_nhwc; a.r = shuffle_r;
+    a.out_bstride = gout_batch_stride > 0 ? gout_batch_stride : (long)O * H * W;
+    return cell_common(true, a, knots, n_knots, spline_order, stream);
+}
+
+extern "C" int ksr_bilinear_up(const float* in, float* out, int B, int n_channels, int H, int W, int r,
+                               int64_t in_batch_stride, int in_channel0, int64_t out_batch_stride,
+                               int out_channel0, hipStream_t stream) {
+    KSR_CHECK_ARG(in && out, "bilinear_up: null pointer");
+    KSR_CHECK_ARG(B > 0 && n_channels > 0 && H > 0 && W > 0 && r >= 1, "bilinear_up: bad dimension");
+    BilArgs a{};
+    a.in = in; a.out = out; a.B = B; a.nc = n_channels; a.H = H; a.W = W; a.r = r;
+    a.in_bstride = in_batch_stride; a.in_cstride = (long)H * W;
+    a.out_bstride = out_batch_stride; a.out_cstride = (long)H * r * (long)W * r;
+    a.ic0 = in_channel0; a.oc0 = out_channel0;
+    const bool vec = ((W * r) % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                     (out_batch_stride % 4 == 0);
+    if (vec) {
+        const long total = (long)B * n_channels * (H * r) * (long)(W * r / 4);
+        hipLaunchKernelGGL(bilinear_up_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    } else {
+        const long total = (long)B * n_channels * (H * r) * (long)(W * r);
+        hipLaunchKernelGGL(bilinear_up_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
+    }
+    KSR_LAUNCH_CHECK("bilinear_up");
+    return KSR_OK;
+}

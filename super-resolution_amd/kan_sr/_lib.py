@@ -1,0 +1,77 @@
+"""ctypes binding of libksr.so (the C ABI declared in include/ksr.h).
+
+There is exactly one compute path: the HIP library.  Importing this module without the
+built library, or calling an op on a non-GPU tensor, raises; nothing falls back to
+PyTorch or CPU code.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libksr.so")
+
+_lib = None
+
+
+class KsrError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KsrError(
+                f"{LIB_PATH} is missing: build it with `make -C super-resolution_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_FP = POINTER(c_float)
+
+
+def _declare(L: ctypes.CDLL) -> None:
+    L.ksr_version.restype = c_int
+    L.ksr_last_error.restype = c_char_p
+    for name in EXPORTS:
+        getattr(L, name).restype = c_int
+
+
+# every symbol include/ksr.h declares (checked by tests/test_abi_symbols.py)
+EXPORTS = [
+    "ksr_version", "ksr_last_error",
+    "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",
+]
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ksr_last_error().decode(errors="replace")
+        raise KsrError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t: torch.Tensor | None) -> c_void_p:
+    """Device pointer of a contiguous fp32 GPU tensor (None -> NULL)."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise KsrError("libksr ops need GPU tensors (the HIP path is the only path)")
+    if not t.is_contiguous():
+        raise KsrError("libksr ops need contiguous tensors")
+    return c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def host_floats(values) -> ctypes.Array:
+    arr = (c_float * len(values))(*[float(v) for v in values])
+    return arr
