@@ -1,0 +1,258 @@
+// Separable-conv trunk of the hyper-encoder, forward: every kernel is
+//     [prologue that builds a 64-channel operand per pixel]  ->  1x1-conv GEMM on MFMA  ->  activation
+// on NHWC activations, one pixel per lane (see ksr_gemm.h).
+//
+//   PRO_PLAIN  : operand = in[n, 0:64]
+//   PRO_STEM   : operand = pointwise2(relu(dw3x3(pointwise1(Y))))  - the whole first FFN (1 -> 1 -> 64),
+//                read straight from the Y plane of the NCHW input image
+//   PRO_DWRELU : operand = relu(dw3x3(in) + b)                     - FFN middle (depthwise + ReLU)
+//   PRO_GATE   : operand = in[n, 0:64] * (dw3x3(in[:, 64:128]) + b) - GatedFFN value * gated half
+// The depthwise 3x3 (zero padding 1) reads a 6 x 34 pixel halo tile of its 64 input channels staged in
+// LDS with coalesced 16-byte loads; the workgroup's 4 waves each take one 32-pixel row of a 4 x 32 tile.
+#include "ksr_gemm.h"
+
+namespace {
+
+enum { PRO_PLAIN = 0, PRO_STEM = 1, PRO_DWRELU = 2, PRO_GATE = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_SIGMOID = 2 };
+
+struct ConvArgs {
+    const float* in;      // NHWC [N, in_ld] (PLAIN/DWRELU/GATE) or NCHW image (STEM, plane 0 is Y)
+    long img_bstride;     // STEM: elements between images
+    int in_ld;            // channels per pixel of `in`
+    const float* wt;      // [NOUT, 64]
+    const float* bias;    // [NOUT]
+    const float* dw_w;    // [64, 9]   (DWRELU/GATE)  |  STEM: [9]
+    const float* dw_b;    // [64]                      |  STEM: [1]
+    const float* p1;      // STEM: pointwise1 {w, b} as two pointers
+    const float* p1b;
+    const float* p2w;     // STEM: pointwise2 weight [64], bias [64]
+    const float* p2b;
+    float* out;           // NHWC [N, NOUT]
+    float* save;          // training: STEM v [N]; DWRELU operand [N,64]; GATE gate G [N,64]; else null
+    int B, H, W;
+};
+
+constexpr int HALO_W = 34, HALO_H = 6, HALO_LD = 68;  // 64 channels + 4 floats pad per pixel
+
+template <int PRO, int NB>
+struct __attribute__((aligned(16))) ConvSmem {
+    float frag[NB * 32 * 64];
+    float biasfrag[NB * 32];
+    float dww[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? 9 * 64 : 16];
+    float dwb[64];
+    float p2w[64];
+    float p2b[64];
+    float halo[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? HALO_H * HALO_W * HALO_LD : 4];
+};
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float v) {
+    if (ACT == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (ACT == ACT_SIGMOID) return ksr_sigmoid(v);
+    return v;
+}
+
+template <int PRO, int NOUT, int ACT>
+__global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
+    constexpr int NB = NOUT / 32;   // 16-register blocks per lane half (NOUT/2 outputs per half)
+    __shared__ ConvSmem<PRO, NB> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+
+    ksr_stage_weights<32, NB, false>(sm.frag, sm.biasfrag, a.wt, 64, a.bias, MapHL{NOUT / 2}, MapHL{32}, tid, 256);
+    if (PRO == PRO_DWRELU || PRO == PRO_GATE) {
+        for (int i = tid; i < 9 * 64; i += 256) sm.dww[i] = a.dw_w[(i & 63) * 9 + (i >> 6)];  // [tap][c]
+        if (tid < 64) sm.dwb[tid] = a.dw_b[tid];
+    }
+    if (PRO == PRO_STEM) {
+        if (tid < 64) { sm.p2w[tid] = a.p2w[tid]; sm.p2b[tid] = a.p2b[tid]; }
+        if (tid < 9) sm.dww[tid] = a.dw_w[tid];
+    }
+    __syncthreads();
+
+    const int HW = a.H * a.W;
+    const long N = (long)a.B * HW;
+    const bool spatial = (PRO == PRO_DWRELU || PRO == PRO_GATE);
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
+    const long ntiles = spatial ? (long)a.B * tiles_y * tiles_x : (N + 127) / 128;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        int b, y, x;
+        bool live;
+        long n;
+        if (spatial) {
+            const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+            b = (int)(tile / ((long)tiles_x * tiles_y));
+            const int y0 = ty * 4, x0 = tx * 32;
+            y = y0 + wv; x = x0 + tok;
+            live = (y < a.H) && (x < a.W);
+            n = (long)b * HW + (long)y * a.W + x;
+            // ---- stage the halo tile (rows y0-1..y0+4, cols x0-1..x0+32, 64 channels) ----
+            const int c0 = (PRO == PRO_GATE) ? 64 : 0;
+            __syncthreads();   // previous tile's readers are done
+            for (int c = tid; c < HALO_H * HALO_W * 16; c += 256) {
+                const int q = c & 15, pix = c >> 4;
+                const int hx = pix % HALO_W, hy = pix / HALO_W;
+                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+                    v = *reinterpret_cast<const float4*>(a.in + ((long)b * HW + (long)gy * a.W + gx) * a.in_ld + c0 + 4 * q);
+                *reinterpret_cast<float4*>(&sm.halo[pix * HALO_LD + 4 * q]) = v;
+            }
+            __syncthreads();
+        } else {
+            n = tile * 128 + wv * 32 + tok;
+            live = n < N;
+            const long nn = live ? n : 0;
+            b = (int)(nn / HW);
+            const int hw = (int)(nn % HW);
+            y = hw / a.W; x = hw % a.W;
+        }
+
+        float op[32];
+        if (PRO == PRO_PLAIN) {
+            if (live) ksr_load32(a.in + n * a.in_ld + 32 * h, op);
+            else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) op[i] = 0.f;
+            }
+        } else if (PRO == PRO_STEM) {
+            const float w1 = a.p1[0], b1 = a.p1b[0];
+            const float* Y = a.in + (long)b * a.img_bstride;
+            float v = a.dw_b[0];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = y + dy, xx = x + dx;
+                    float u = 0.f;
+                    if (live && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) u = w1 * Y[(long)yy * a.W + xx] + b1;
+                    v += sm.dww[(dy + 1) * 3 + (dx + 1)] * u;
+                }
+            v = v > 0.f ? v : 0.f;
+            if (a.save && live && h == 0) a.save[n] = v;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) op[i] = sm.p2w[32 * h + i] * v + sm.p2b[32 * h + i];
+        } else {
+            // depthwise 3x3 over the halo tile, this lane's 32 channels
+            float g[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) g[i] = sm.dwb[32 * h + i];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float* hp = &sm.halo[((wv + dy) * HALO_W + (tok + dx)) * HALO_LD + 32 * h];
+                    const float* wp = &sm.dww[(dy * 3 + dx) * 64 + 32 * h];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x4 tv = *reinterpret_cast<const f32x4*>(hp + 4 * q);
+                        const f32x4 wq = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+                        g[4 * q + 0] += wq[0] * tv[0]; g[4 * q + 1] += wq[1] * tv[1];
+                        g[4 * q + 2] += wq[2] * tv[2]; g[4 * q + 3] += wq[3] * tv[3];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one tap at a time: bounds live registers
+                }
+            if (PRO == PRO_DWRELU) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) op[i] = g[i] > 0.f ? g[i] : 0.f;
+                if (a.save && live) ksr_store32(a.save + n * 64 + 32 * h, op);
+            } else {
+                if (a.save && live) ksr_store32(a.save + n * 64 + 32 * h, g);
+                float val[32];
+                if (live) ksr_load32(a.in + n * a.in_ld + 32 * h, val);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) val[i] = 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < 32; ++i) op[i] = val[i] * g[i];
+            }
+        }
+
+        f32x16 acc[NB];
+        ksr_wave_gemm<32, NB>(sm.frag, sm.biasfrag, op, acc, lane);
+
+        if (live) {
+#pragma unroll
+            for (int grp = 0; grp < NB / 2; ++grp) {
+                float o[32];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    o[q] = apply_act<ACT>(acc[2 * grp][q]);
+                    o[16 + q] = apply_act<ACT>(acc[2 * grp + 1][q]);
+                }
+                ksr_store32(a.out + n * NOUT + 64 * grp + 32 * h, o);
+            }
+        }
+    }
+}
+
+template <int PRO, int NOUT, int ACT>
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    const bool spatial = (PRO == PRO_DWRELU || PRO == PRO_GATE);
+    const long N = (long)a.B * a.H * a.W;
+    const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
+    const long cap = spatial ? 512 : 1024;
+    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+    hipLaunchKernelGGL((conv_fwd_kernel<PRO, NOUT, ACT>), dim3(grid), dim3(256), 0, s, a);
+    KSR_LAUNCH_CHECK("conv_fwd");
+    return KSR_OK;
+}
+
+int check_dims(int B, int H, int W, const char* who) {
+    KSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "%s: non-positive dimension", who);
+    KSR_CHECK_ARG((long)B * H * W < (1L << 31), "%s: more than 2^31 pixels", who);
+    return KSR_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int ksr_stem_fwd(const float* x_img, int64_t img_batch_stride, const float* pw1_w, const float* pw1_b,
+                            const float* dw_w, const float* dw_b, const float* pw2_w, const float* pw2_b,
+                            const float* fn1_w, const float* fn1_b, float* t_out, float* save_v, int B, int H,
+                            int W, hipStream_t stream) {
+    KSR_CHECK_ARG(x_img && pw1_w && pw1_b && dw_w && dw_b && pw2_w && pw2_b && fn1_w && fn1_b && t_out, "stem_fwd: null pointer");
+    if (int rc = check_dims(B, H, W, "stem_fwd")) return rc;
+    ConvArgs a{};
+    a.in = x_img; a.img_bstride = img_batch_stride; a.wt = fn1_w; a.bias = fn1_b;
+    a.dw_w = dw_w; a.dw_b = dw_b; a.p1 = pw1_w; a.p1b = pw1_b; a.p2w = pw2_w; a.p2b = pw2_b;
+    a.out = t_out; a.save = save_v; a.B = B; a.H = H; a.W = W;
+    return launch_conv<PRO_STEM, 128, ACT_RELU>(a, stream);
+}
+
+extern "C" int ksr_pointwise_fwd(const float* in, const float* w, const float* bias, float* out, int n_out,
+                                 int act, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(in && w && bias && out, "pointwise_fwd: null pointer");
+    if (int rc = check_dims(B, H, W, "pointwise_fwd")) return rc;
+    ConvArgs a{};
+    a.in = in; a.in_ld = 64; a.wt = w; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W;
+    if (n_out == 64 && act == ACT_NONE) return launch_conv<PRO_PLAIN, 64, ACT_NONE>(a, stream);
+    if (n_out == 128 && act == ACT_RELU) return launch_conv<PRO_PLAIN, 128, ACT_RELU>(a, stream);
+    ksr_set_error("pointwise_fwd: unsupported (n_out=%d, act=%d)", n_out, act);
+    return KSR_ERR_UNSUPPORTED;
+}
+
+extern "C" int ksr_dwrelu_pw_fwd(const float* in, const float* dw_w, const float* dw_b, const float* w,
+                                 const float* bias, float* out, float* save_operand, int B, int H, int W,
+                                 hipStream_t stream) {
+    KSR_CHECK_ARG(in && dw_w && dw_b && w && bias && out, "dwrelu_pw_fwd: null pointer");
+    if (int rc = check_dims(B, H, W, "dwrelu_pw_fwd")) return rc;
+    ConvArgs a{};
+    a.in = in; a.in_ld = 64; a.dw_w = dw_w; a.dw_b = dw_b; a.wt = w; a.bias = bias; a.out = out;
+    a.save = save_operand; a.B = B; a.H = H; a.W = W;
+    return launch_conv<PRO_DWRELU, 64, ACT_NONE>(a, stream);
+}
+
+extern "C" int ksr_gate_pw_fwd(const float* t_in, const float* gate_w, const float* gate_b, const float* w,
+                               const float* bias, float* out, float* save_gate, int B, int H, int W,
+                               hipStream_t stream) {
+    KSR_CHECK_ARG(t_in && gate_w && gate_b && w && bias && out, "gate_pw_fwd: null pointer");
+    if (int rc = check_dims(B, H, W, "gate_pw_fwd")) return rc;
+    ConvArgs a{};
+    a.in = t_in; a.in_ld = 128; a.dw_w = gate_w; a.dw_b = gate_b; a.wt = w; a.bias = bias; a.out = out;
+    a.save = save_gate; a.B = B; a.H = H; a.W = W;
+    return launch_conv<PRO_GATE, 64, ACT_SIGMOID>(a, stream);
+}

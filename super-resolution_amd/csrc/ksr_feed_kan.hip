@@ -1,0 +1,170 @@
+// feed (1x1 conv 64 -> P) + per-pixel KAN evaluation + pixel shuffle, fused: the [N, P] tensor of
+// per-pixel spline coefficients lives only in MFMA accumulators.
+//
+// The P = O*(Kc+2) output channels of `feed` are assigned to the two lanes of a pixel so that lane
+// half h receives, for each of ITS O/2 outputs o, the complete parameter set (coef[o,0..Kc-1],
+// uw[o], rw[o]) (MapKan in ksr_gemm.h).  The KAN layer is then lane-local:
+//   y[o] = rw[o]*silu(x) + uw[o] * sum_g B_g(x) coef[o,g]
+// and with O = r*r the lane's outputs are r/2 rows of r contiguous pixels of the x r image, written
+// with one 8/16-byte store per row directly into the Y plane of the [B,3,rH,rW] result.
+#include "ksr_gemm.h"
+
+namespace {
+
+struct FeedArgs {
+    const float* feat;     // [N, 64]
+    const float* x_img;    // NCHW image, plane 0 = Y
+    long img_bstride;
+    const float* w;        // [P, 64]
+    const float* bias;     // [P]
+    float* out;            // [B, C_out, rH, rW]; plane 0 is written
+    long out_bstride;
+    float* save_us;        // training: [N, O, 2] = (uw, spline sum) per output, may be null
+    // backward
+    const float* gout;     // gradient of out (same layout/strides as out)
+    float* gfeat;          // [N, 64]
+    float* gparam;         // [N, 2, NB*16] gradient of the feed output in lane order (half, e)
+    int B, H, W;
+};
+
+template <int KC>
+__device__ __forceinline__ void dense_basis(int m, const float (&Nv)[KSR_MAX_ORDER + 1], int K, float (&bv)[KC]) {
+#pragma unroll
+    for (int g = 0; g < KC; ++g) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q <= KSR_MAX_ORDER; ++q) v = (m >= 0 && q <= K && g == m - K + q) ? Nv[q] : v;
+        bv[g] = v;
+    }
+}
+
+template <int KORD>
+__device__ __forceinline__ int basis_any(float x, const float* t, int M, float (&Nv)[KSR_MAX_ORDER + 1]) {
+    float N[KORD + 1], dN[KORD + 1];
+    const int m = ksr_bspline_local<KORD, false>(x, t, M, N, dN);
+#pragma unroll
+    for (int q = 0; q <= KSR_MAX_ORDER; ++q) Nv[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q <= KORD; ++q) Nv[q] = N[q];
+    return m;
+}
+
+template <int R, int KC>
+struct FeedCfg {
+    static constexpr int O = R * R, OH = O / 2, PER = KC + 2, NH = OH * PER;
+    static constexpr int NB = (NH + 15) / 16;
+};
+
+template <int NB>
+struct __attribute__((aligned(16))) FeedSmem {
+    float frag[NB * 32 * 64];
+    float biasfrag[NB * 32];
+    float knots[KSR_MAX_KNOTS];
+};
+
+template <int R, int KC, int KORD>
+__global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKnots kn) {
+    using C = FeedCfg<R, KC>;
+    constexpr int NB = C::NB;
+    __shared__ FeedSmem<NB> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<32, NB, false>(sm.frag, sm.biasfrag, a.w, 64, a.bias, MapKan{C::O, KC}, MapHL{32}, tid, 256);
+    if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
+    __syncthreads();
+
+    const int HW = a.H * a.W;
+    const long N = (long)a.B * HW;
+    const long ntiles = (N + 127) / 128;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n = tile * 128 + wv * 32 + tok;
+        const bool live = n < N;
+        const long nn = live ? n : 0;
+        const int b = (int)(nn / HW), hw = (int)(nn % HW);
+        const int y = hw / a.W, x = hw % a.W;
+
+        float f[32];
+        if (live) ksr_load32(a.feat + n * 64 + 32 * h, f);
+        else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) f[i] = 0.f;
+        }
+        f32x16 acc[NB];
+        ksr_wave_gemm<32, NB>(sm.frag, sm.biasfrag, f, acc, lane);
+
+        const float xv = live ? a.x_img[(long)b * a.img_bstride + hw] : 0.f;
+        float Nv[KSR_MAX_ORDER + 1], bv[KC];
+        const int m = basis_any<KORD>(xv, sm.knots, kn.M, Nv);
+        dense_basis<KC>(m, Nv, KORD, bv);
+        const float sl = ksr_silu(xv);
+
+        float yv[C::OH];
+#pragma unroll
+        for (int ol = 0; ol < C::OH; ++ol) {
+            float S = 0.f;
+#pragma unroll
+            for (int g = 0; g < KC; ++g) {
+                constexpr int dummy = 0; (void)dummy;
+                const int e = ol * C::PER + g;
+                S += bv[g] * acc[e / 16][e % 16];
+            }
+            const int eu = ol * C::PER + KC, er = eu + 1;
+            const float uw = acc[eu / 16][eu % 16], rw = acc[er / 16][er % 16];
+            yv[ol] = rw * sl + uw * S;
+            if (a.save_us && live) {
+                a.save_us[(n * C::O + h * C::OH + ol) * 2 + 0] = uw;
+                a.save_us[(n * C::O + h * C::OH + ol) * 2 + 1] = S;
+            }
+        }
+        if (live) {
+            // lane half h owns outputs o = h*OH + ol  ->  rows h*(R/2) + ol/R, columns ol%R
+            float* op = a.out + (long)b * a.out_bstride + ((long)(y * R + h * (R / 2))) * (a.W * R) + (long)x * R;
+#pragma unroll
+            for (int rr = 0; rr < R / 2; ++rr) {
+                if (R == 4)
+                    *reinterpret_cast<float4*>(op + (long)rr * a.W * R) =
+                        make_float4(yv[rr * R + 0], yv[rr * R + 1], yv[rr * R + 2], yv[rr * R + 3]);
+                else
+                    *reinterpret_cast<float2*>(op + (long)rr * a.W * R) = make_float2(yv[rr * R + 0], yv[rr * R + 1]);
+            }
+        }
+    }
+}
+
+template <int R, int KC, int KORD>
+int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
+    const long N = (long)a.B * a.H * a.W;
+    const long ntiles = (N + 127) / 128;
+    const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);
+    hipLaunchKernelGGL((feed_kan_fwd_kernel<R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
+    KSR_LAUNCH_CHECK("feed_kan_fwd");
+    return KSR_OK;
+}
+
+}  // namespace
+
+extern "C" int ksr_feed_kan_supported(int upscale, int n_coef, int spline_order) {
+    return (spline_order == 3) && ((upscale == 2 && n_coef == 8) || (upscale == 4 && (n_coef == 8 || n_coef == 19)));
+}
+
+extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
+                                const float* feed_b, float* out, int64_t out_batch_stride, float* save_us, int B,
+                                int H, int W, int upscale, int n_coef, const float* knots, int n_knots,
+                                int spline_order, hipStream_t stream) {
+    KSR_CHECK_ARG(feat && x_img && feed_w && feed_b && out && knots, "feed_kan_fwd: null pointer");
+    KSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "feed_kan_fwd: non-positive dimension");
+    KSR_CHECK_ARG(n_knots == n_coef + spline_order + 1 && n_knots <= KSR_MAX_KNOTS, "feed_kan_fwd: bad knot count %d", n_knots);
+    KSR_UNSUPPORTED(!ksr_feed_kan_supported(upscale, n_coef, spline_order),
+                    "feed_kan_fwd: (upscale=%d, grid_size+spline_order=%d, spline_order=%d) has no fused kernel",
+                    upscale, n_coef, spline_order);
+    KSR_CHECK_ARG((reinterpret_cast<uintptr_t>(out) & 15) == 0 && out_batch_stride % 4 == 0, "feed_kan_fwd: out must be 16-byte aligned");
+    FeedArgs a{};
+    a.feat = feat; a.x_img = x_img; a.img_bstride = img_batch_stride; a.w = feed_w; a.bias = feed_b;
+    a.out = out; a.out_bstride = out_batch_stride; a.save_us = save_us; a.B = B; a.H = H; a.W = W;
+    KsrKnots kn;
+    for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
+    kn.M = n_knots; kn.k = spline_order;
+    if (upscale == 2) return launch_feed_fwd<2, 8, 3>(a, kn, stream);
+    if (n_coef == 8) return launch_feed_fwd<4, 8, 3>(a, kn, stream);
+    return launch_feed_fwd<4, 19, 3>(a, kn, stream);
+}

@@ -1,0 +1,180 @@
+// Wave-level "token per lane" GEMM primitive for gfx950 (fp32 in / fp32 accumulate MFMA).
+//
+// Every 1x1 convolution / linear layer of the hyper-encoder has 16..192 channels, so one
+// pixel's ("token's") whole activation vector fits in registers.  A wave owns 32 tokens; lane
+// l = (tok = l & 31, h = l >> 5) holds HALF of its token's channels ("half layout", HL):
+//   64-channel tensor : lane half h holds channels 32h .. 32h+31, register s <-> channel 32h+s
+//   64*g-channel tensor: g groups of that shape (register 32*grp + s <-> channel 64*grp+32h+s)
+//
+// The product is computed transposed, D[row = out channel][col = token] = W * X^T, with
+// v_mfma_f32_32x32x2_f32: the weight matrix is the A operand (rows on lanes, read from LDS in a
+// pre-arranged fragment order), the activations are the B operand (one VGPR per k-step, straight
+// from the registers above).  D has the token on the lane and 16 rows per register block; the
+// row->channel assignment is chosen when the fragments are staged so that the OUTPUT is in half
+// layout again: a chain of layers never leaves the register file and never transposes.
+//
+// Exact fp32: the MFMA is a k-ordered fmaf chain (one rounding per product).
+#pragma once
+#include "ksr_common.h"
+
+#if defined(__HIPCC__)
+
+#define KSR_WAVE 64
+
+// D row of a 32x32 MFMA block held by (lane half h, register q): (q&3) + 8*(q>>2) + 4*h.
+// Inverse: for A-operand row rho, the result lands on half (rho>>2)&1, register (rho&3)+4*(rho>>3).
+__device__ __forceinline__ int ksr_row_half(int rho) { return (rho >> 2) & 1; }
+__device__ __forceinline__ int ksr_row_reg(int rho) { return (rho & 3) + 4 * (rho >> 3); }
+
+// ---- channel maps: (lane half h, per-half index e) -> channel, or -1 for padding -------------
+struct MapHL {       // channels multiple of 64, nh = C/2 entries per half
+    int nh;
+    __device__ __forceinline__ int operator()(int h, int e) const {
+        return e < nh ? 64 * (e >> 5) + 32 * h + (e & 31) : -1;
+    }
+};
+struct MapSplit {    // C channels, half h holds [h*C/2, (h+1)*C/2)
+    int nh;
+    __device__ __forceinline__ int operator()(int h, int e) const { return e < nh ? h * nh + e : -1; }
+};
+// Per-pixel KAN parameter vector: half h evaluates outputs o in [h*Oh, (h+1)*Oh), Oh = O/2, and holds
+// for each of them (coef[0..Kc-1], uw, rw) at e = ol*(Kc+2) + gi.  Channel numbering of the
+// reference: coef (o*Kc + g) | uw (O*Kc + o) | rw (O*Kc + O + o)   (in_dim = 1).
+struct MapKan {
+    int O, Kc;
+    __device__ __forceinline__ int operator()(int h, int e) const {
+        const int Oh = O >> 1, per = Kc + 2;
+        if (e >= Oh * per) return -1;
+        const int ol = e / per, gi = e - ol * per, o = h * Oh + ol;
+        return gi < Kc ? o * Kc + gi : (gi == Kc ? O * Kc + o : O * Kc + O + o);
+    }
+};
+
+// Number of floats of LDS a staged GEMM needs: NB blocks x KH steps x 64 lanes (+ NB*32 bias).
+__host__ __device__ constexpr int ksr_frag_floats(int KH, int NB) { return NB * KH * 64; }
+__host__ __device__ constexpr int ksr_bias_floats(int NB) { return NB * 32; }
+
+// Stage W (row-major [rows][ldw]; element (o, i) at W[o*ldw+i], or W[i*ldw+o] when TRANS) into
+// fragment order.  frag[((blk*(KH/4) + s/4)*64 + lane)*4 + s%4] = W(out(h(rho), 16*blk+q(rho)), in(hh, s))
+// for lane = rho + 32*hh.  biasfrag[(blk*2 + h)*16 + q] = bias[out(h, 16*blk+q)].
+// Called by all threads of the workgroup; caller synchronises afterwards.
+template <int KH, int NB, bool TRANS, class OutMap, class InMap>
+__device__ __forceinline__ void ksr_stage_weights(float* __restrict__ frag, float* __restrict__ biasfrag,
+                                                  const float* __restrict__ W, int ldw,
+                                                  const float* __restrict__ bias, OutMap om, InMap im,
+                                                  int tid, int nthreads) {
+    static_assert(KH % 4 == 0, "KH must be a multiple of 4");
+    const int total = NB * KH * 64;
+    for (int idx = tid; idx < total; idx += nthreads) {
+        const int s_lo = idx & 3;
+        const int lane = (idx >> 2) & 63;
+        const int rest = idx >> 8;             // blk*(KH/4) + s/4
+        const int s = (rest % (KH / 4)) * 4 + s_lo;
+        const int blk = rest / (KH / 4);
+        const int rho = lane & 31, hh = lane >> 5;
+        const int o = om(ksr_row_half(rho), 16 * blk + ksr_row_reg(rho));
+        const int i = im(hh, s);
+        float v = 0.f;
+        if (o >= 0 && i >= 0) v = TRANS ? W[(long)i * ldw + o] : W[(long)o * ldw + i];
+        frag[idx] = v;
+    }
+    if (biasfrag) {
+        for (int idx = tid; idx < NB * 32; idx += nthreads) {
+            const int q = idx & 15, h = (idx >> 4) & 1, blk = idx >> 5;
+            const int o = om(h, 16 * blk + q);
+            biasfrag[idx] = (bias && o >= 0) ? bias[o] : 0.f;
+        }
+    }
+}
+
+// acc[blk] = bias + sum_s W_frag * x.  x[s] is this lane's input for k-step s.
+template <int KH, int NB>
+__device__ __forceinline__ void ksr_wave_gemm(const float* __restrict__ frag, const float* __restrict__ biasfrag,
+                                              const float (&x)[KH], f32x16 (&acc)[NB], int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+        if (biasfrag) {
+            const f32x4* b4 = reinterpret_cast<const f32x4*>(biasfrag + (blk * 2 + h) * 16);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 b = b4[q4];
+                acc[blk][4 * q4 + 0] = b[0]; acc[blk][4 * q4 + 1] = b[1];
+                acc[blk][4 * q4 + 2] = b[2]; acc[blk][4 * q4 + 3] = b[3];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[blk][q] = 0.f;
+        }
+    }
+    // One 16-byte LDS read feeds four MFMAs (256 cycles of matrix pipe); the next read is issued
+    // one group ahead.  The scheduling barrier keeps the compiler from hoisting every fragment read
+    // of the unrolled loop to the top (which costs > 256 VGPRs).
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(frag) + lane;
+    f32x4 w = w4[0];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+        for (int s4 = 0; s4 < KH / 4; ++s4) {
+            constexpr int last = NB * (KH / 4) - 1;
+            const int cur = blk * (KH / 4) + s4;
+            const f32x4 wn = w4[(cur < last ? cur + 1 : last) * 64];
+            acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], x[4 * s4 + 0], acc[blk], 0, 0, 0);
+            acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], x[4 * s4 + 1], acc[blk], 0, 0, 0);
+            acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], x[4 * s4 + 2], acc[blk], 0, 0, 0);
+            acc[blk] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], x[4 * s4 + 3], acc[blk], 0, 0, 0);
+            w = wn;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ---- HL loads / stores of one token's half (32 channels, 128 contiguous bytes) ----------------
+__device__ __forceinline__ void ksr_load32(const float* __restrict__ p, float* __restrict__ x) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 v = p4[q];
+        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void ksr_store32(float* __restrict__ p, const float* __restrict__ x) {
+    float4* p4 = reinterpret_cast<float4*>(p);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) p4[q] = make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+__device__ __forceinline__ void ksr_load16(const float* __restrict__ p, float* __restrict__ x) {
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = p4[q];
+        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void ksr_store16(float* __restrict__ p, const float* __restrict__ x) {
+    float4* p4 = reinterpret_cast<float4*>(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) p4[q] = make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+}
+
+// Sum of v over the two lanes that share a token (lanes l and l^32).
+__device__ __forceinline__ float ksr_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// LayerNorm over the 64 channels of a token held as x[32] on each of the two half-lanes.
+// Writes xhat (normalised, before gain/shift) and returns rstd.
+__device__ __forceinline__ float ksr_layernorm64(const float (&x)[32], float (&xhat)[32], float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += x[i];
+    const float mean = ksr_pair_sum(s) * (1.f / 64.f);
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { const float d = x[i] - mean; v += d * d; }
+    const float var = ksr_pair_sum(v) * (1.f / 64.f);
+    const float rstd = 1.f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) xhat[i] = (x[i] - mean) * rstd;
+    return rstd;
+}
+
+#endif  // __HIPCC__

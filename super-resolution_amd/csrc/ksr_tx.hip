@@ -1,0 +1,272 @@
+// Post-LN transformer encoder layer whose attention runs over the BATCH axis: the sequence at
+// pixel p is the S = B_local feature vectors {x[b, p, :]}, E = 64, 2 heads of 32, FFN width 32.
+//
+// One lane owns one token (pixel, image) half: lane (tok, h) holds channels 32h..32h+31, which
+// is exactly attention head h.  QKV / out-proj / MLP run on MFMA through ksr_wave_gemm with every
+// weight staged once per (persistent) workgroup in LDS; the residual stream, LayerNorms, softmax and
+// both heads stay in registers.  Only K and V cross lanes, through a padded LDS exchange buffer:
+// lane (tok, h) walks the S keys of its own pixel and head with an online softmax.
+//
+// A workgroup handles 128 token slots = PPW pixels x S images (PPW = 128 / S); slot = b * PPW + pl so
+// that neighbouring lanes read neighbouring pixels (contiguous 256-byte rows).
+#include "ksr_gemm.h"
+
+namespace {
+
+struct TxArgs {
+    const float* in;    // [S, HW, 64]
+    float* out;         // [S, HW, 64]
+    const float *in_w, *in_b;     // [192, 64], [192]
+    const float *out_w, *out_b;   // [64, 64], [64]
+    const float *l1_w, *l1_b;     // [32, 64], [32]
+    const float *l2_w, *l2_b;     // [64, 32], [64]
+    const float *n1_w, *n1_b, *n2_w, *n2_b;   // [64] each
+    const float *nf_w, *nf_b;     // optional final LayerNorm applied to the output (may be null)
+    // training-mode saves (all optional): q|k|v [N,192], ctx [N,64], xhat1 [N,64], rstd1 [N],
+    // s1 [N,64], hmid [N,32], xhat2 [N,64], rstd2 [N]
+    float *sv_qkv, *sv_ctx, *sv_xhat1, *sv_rstd1, *sv_s1, *sv_hmid, *sv_xhat2, *sv_rstd2;
+    float *sv_xhatf, *sv_rstdf;   // final LayerNorm (only with nf_w)
+    int S, HW;
+    float eps;
+    float p_drop;                 // 0 in eval mode
+    unsigned long long seed;      // dropout stream id
+};
+
+constexpr int KV_LD = 132;        // floats per slot: [h0: k32 v32][h1: k32 v32] + 4 pad
+
+struct __attribute__((aligned(16))) TxSmem {
+    float f_in[6 * 32 * 64];      // 64 -> 192
+    float f_out[2 * 32 * 64];     // 64 -> 64
+    float f_l1[1 * 32 * 64];      // 64 -> 32
+    float f_l2[2 * 16 * 64];      // 32 -> 64
+    float b_in[6 * 32], b_out[2 * 32], b_l1[32], b_l2[2 * 32];
+    float ln[6][64];              // n1_w, n1_b, n2_w, n2_b, nf_w, nf_b
+    float kv[128 * KV_LD];
+};
+
+// counter-based uniform in [0,1): hash of (seed, stream, element index)
+__device__ __forceinline__ float ksr_uniform(unsigned long long seed, unsigned stream, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (idx * 8ULL + stream + 1ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* __restrict__ g,
+                                          const float* __restrict__ b, int h, float (&y)[32]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const f32x4 gw = *reinterpret_cast<const f32x4*>(g + 32 * h + 4 * q);
+        const f32x4 bw = *reinterpret_cast<const f32x4*>(b + 32 * h + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[4 * q + e] = xhat[4 * q + e] * gw[e] + bw[e];
+    }
+}
+
+template <bool TRAIN>
+__global__ void __launch_bounds__(256, 1) tx_layer_fwd_kernel(TxArgs a) {
+    __shared__ TxSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+
+    ksr_stage_weights<32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
+    ksr_stage_weights<32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, 256);
+    ksr_stage_weights<32, 1, false>(sm.f_l1, sm.b_l1, a.l1_w, 64, a.l1_b, MapSplit{16}, MapHL{32}, tid, 256);
+    ksr_stage_weights<16, 2, false>(sm.f_l2, sm.b_l2, a.l2_w, 32, a.l2_b, MapHL{32}, MapSplit{16}, tid, 256);
+    if (tid < 64) {
+        sm.ln[0][tid] = a.n1_w[tid]; sm.ln[1][tid] = a.n1_b[tid];
+        sm.ln[2][tid] = a.n2_w[tid]; sm.ln[3][tid] = a.n2_b[tid];
+        sm.ln[4][tid] = a.nf_w ? a.nf_w[tid] : 1.f; sm.ln[5][tid] = a.nf_b ? a.nf_b[tid] : 0.f;
+    }
+    __syncthreads();
+
+    const int S = a.S, HW = a.HW;
+    const int PPW = 128 / S;                          // pixels per workgroup tile (S <= 128)
+    const int ntiles = (HW + PPW - 1) / PPW;
+    const int slot = wv * 32 + tok;
+    const int b = slot / PPW, pl = slot - b * PPW;
+    const float scale = 0.17677669529663687f;         // 1/sqrt(32)
+    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int p = tile * PPW + pl;
+        const bool live = (b < S) && (p < HW);
+        const long n = live ? ((long)b * HW + p) : 0;
+
+        float s0[32];
+        if (live) ksr_load32(a.in + n * 64 + 32 * h, s0);
+        else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) s0[i] = 0.f;
+        }
+
+        // ---- QKV projection -------------------------------------------------------------
+        float q[32];
+        {
+            f32x16 acc[6];
+            ksr_wave_gemm<32, 6>(sm.f_in, sm.b_in, s0, acc, lane);
+            float kvr[64];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                q[i] = acc[0][i]; q[16 + i] = acc[1][i];
+                kvr[i] = acc[2][i]; kvr[16 + i] = acc[3][i];
+                kvr[32 + i] = acc[4][i]; kvr[48 + i] = acc[5][i];
+            }
+            if (TRAIN && a.sv_qkv && live) {
+                ksr_store32(a.sv_qkv + n * 192 + 32 * h, q);
+                ksr_store32(a.sv_qkv + n * 192 + 64 + 32 * h, kvr);
+                ksr_store32(a.sv_qkv + n * 192 + 128 + 32 * h, kvr + 32);
+            }
+            __syncthreads();                          // previous tile's K/V readers are done
+            float* dst = &sm.kv[slot * KV_LD + 64 * h];
+#pragma unroll
+            for (int c = 0; c < 16; ++c)
+                *reinterpret_cast<f32x4*>(dst + 4 * c) =
+                    f32x4{kvr[4 * c], kvr[4 * c + 1], kvr[4 * c + 2], kvr[4 * c + 3]};
+#pragma unroll
+            for (int i = 0; i < 32; ++i) q[i] *= scale;
+        }
+        __syncthreads();
+
+        // ---- attention over the S images at this pixel, head h --------------------------
+        float ctx[32];
+        {
+            float m = -INFINITY, l = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) ctx[i] = 0.f;
+            for (int j = 0; j < S; ++j) {
+                const float* kp = &sm.kv[(j * PPW + pl) * KV_LD + 64 * h];
+                float sc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * c);
+                    sc += q[4 * c] * kk[0] + q[4 * c + 1] * kk[1] + q[4 * c + 2] * kk[2] + q[4 * c + 3] * kk[3];
+                }
+                const float mn = fmaxf(m, sc);
+                const float alpha = expf(m - mn);
+                float pj = expf(sc - mn);
+                l = l * alpha + pj;
+                if (TRAIN && a.p_drop > 0.f) {
+                    // dropout on the attention probabilities (after normalisation in the reference;
+                    // the mask commutes with the 1/l scaling)
+                    const unsigned long long e = (((unsigned long long)n * 2 + h) << 8) + (unsigned)j;
+                    pj = ksr_uniform(a.seed, 0u, e) < keep ? pj * inv_keep : 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const f32x4 vv = *reinterpret_cast<const f32x4*>(kp + 32 + 4 * c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ctx[4 * c + e] = ctx[4 * c + e] * alpha + pj * vv[e];
+                }
+                m = mn;
+            }
+            const float inv_l = 1.f / l;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) ctx[i] *= inv_l;
+            if (TRAIN && a.sv_ctx && live) ksr_store32(a.sv_ctx + n * 64 + 32 * h, ctx);
+        }
+
+        // ---- out projection + residual + LayerNorm 1 -------------------------------------
+        float s1[32];
+        {
+            f32x16 acc[2];
+            ksr_wave_gemm<32, 2>(sm.f_out, sm.b_out, ctx, acc, lane);
+            float u[32], xhat[32];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { u[i] = acc[0][i]; u[16 + i] = acc[1][i]; }
+            if (TRAIN && a.p_drop > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    u[i] = ksr_uniform(a.seed, 1u, (unsigned long long)n * 64 + 32 * h + i) < keep ? u[i] * inv_keep : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) u[i] += s0[i];
+            const float rstd = ksr_layernorm64(u, xhat, a.eps);
+            ln_affine(xhat, sm.ln[0], sm.ln[1], h, s1);
+            if (TRAIN && live) {
+                if (a.sv_xhat1) ksr_store32(a.sv_xhat1 + n * 64 + 32 * h, xhat);
+                if (a.sv_s1) ksr_store32(a.sv_s1 + n * 64 + 32 * h, s1);
+                if (a.sv_rstd1 && h == 0) a.sv_rstd1[n] = rstd;
+            }
+        }
+
+        // ---- MLP 64 -> 32 -> 64 + residual + LayerNorm 2 ----------------------------------
+        float s2[32];
+        {
+            f32x16 acc1[1];
+            ksr_wave_gemm<32, 1>(sm.f_l1, sm.b_l1, s1, acc1, lane);
+            float hm[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hm[i] = acc1[0][i] > 0.f ? acc1[0][i] : 0.f;
+            if (TRAIN && a.p_drop > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    hm[i] = ksr_uniform(a.seed, 2u, (unsigned long long)n * 32 + 16 * h + i) < keep ? hm[i] * inv_keep : 0.f;
+            }
+            if (TRAIN && a.sv_hmid && live) ksr_store16(a.sv_hmid + n * 32 + 16 * h, hm);
+            f32x16 acc2[2];
+            ksr_wave_gemm<16, 2>(sm.f_l2, sm.b_l2, hm, acc2, lane);
+            float u[32], xhat[32];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { u[i] = acc2[0][i]; u[16 + i] = acc2[1][i]; }
+            if (TRAIN && a.p_drop > 0.f) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i)
+                    u[i] = ksr_uniform(a.seed, 3u, (unsigned long long)n * 64 + 32 * h + i) < keep ? u[i] * inv_keep : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) u[i] += s1[i];
+            const float rstd = ksr_layernorm64(u, xhat, a.eps);
+            ln_affine(xhat, sm.ln[2], sm.ln[3], h, s2);
+            if (TRAIN && live) {
+                if (a.sv_xhat2) ksr_store32(a.sv_xhat2 + n * 64 + 32 * h, xhat);
+                if (a.sv_rstd2 && h == 0) a.sv_rstd2[n] = rstd;
+            }
+        }
+
+        // ---- optional final LayerNorm of the encoder stack --------------------------------
+        if (a.nf_w) {
+            float xhat[32], y[32];
+            const float rstd = ksr_layernorm64(s2, xhat, a.eps);
+            ln_affine(xhat, sm.ln[4], sm.ln[5], h, y);
+            if (TRAIN && live) {
+                if (a.sv_xhatf) ksr_store32(a.sv_xhatf + n * 64 + 32 * h, xhat);
+                if (a.sv_rstdf && h == 0) a.sv_rstdf[n] = rstd;
+            }
+            if (live) ksr_store32(a.out + n * 64 + 32 * h, y);
+        } else {
+            if (live) ksr_store32(a.out + n * 64 + 32 * h, s2);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* const* params, float* const* saves,
+                                      int S, int HW, float eps, float p_drop, uint64_t seed, hipStream_t stream) {
+    KSR_CHECK_ARG(in && out && params, "batch_tx_layer_fwd: null pointer");
+    KSR_CHECK_ARG(S > 0 && HW > 0, "batch_tx_layer_fwd: non-positive dimension");
+    KSR_UNSUPPORTED(S > 128, "batch_tx_layer_fwd: local batch %d > 128 not supported", S);
+    KSR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "batch_tx_layer_fwd: dropout p must be in [0,1)");
+    for (int i = 0; i < 12; ++i) KSR_CHECK_ARG(params[i] != nullptr, "batch_tx_layer_fwd: params[%d] is null", i);
+    TxArgs a{};
+    a.in = in; a.out = out;
+    a.in_w = params[0]; a.in_b = params[1]; a.out_w = params[2]; a.out_b = params[3];
+    a.l1_w = params[4]; a.l1_b = params[5]; a.l2_w = params[6]; a.l2_b = params[7];
+    a.n1_w = params[8]; a.n1_b = params[9]; a.n2_w = params[10]; a.n2_b = params[11];
+    a.nf_w = params[12]; a.nf_b = params[13];
+    KSR_CHECK_ARG((a.nf_w == nullptr) == (a.nf_b == nullptr), "batch_tx_layer_fwd: final norm needs weight and bias");
+    if (saves) {
+        a.sv_qkv = saves[0]; a.sv_ctx = saves[1]; a.sv_xhat1 = saves[2]; a.sv_rstd1 = saves[3]; a.sv_s1 = saves[4];
+        a.sv_hmid = saves[5]; a.sv_xhat2 = saves[6]; a.sv_rstd2 = saves[7]; a.sv_xhatf = saves[8]; a.sv_rstdf = saves[9];
+    }
+    a.S = S; a.HW = HW; a.eps = eps; a.p_drop = p_drop; a.seed = seed;
+    const int PPW = 128 / S;
+    const int ntiles = (HW + PPW - 1) / PPW;
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    if (saves || p_drop > 0.f) hipLaunchKernelGGL(tx_layer_fwd_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(tx_layer_fwd_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("batch_tx_layer_fwd");
+    return KSR_OK;
+}

@@ -38,16 +38,17 @@ _FP = POINTER(c_float)
 
 
 def _declare(L: ctypes.CDLL) -> None:
-    L.ksr_version.restype = c_int
-    L.ksr_last_error.restype = c_char_p
     for name in EXPORTS:
         getattr(L, name).restype = c_int
+    L.ksr_last_error.restype = c_char_p
 
 
 # every symbol include/ksr.h declares (checked by tests/test_abi_symbols.py)
 EXPORTS = [
     "ksr_version", "ksr_last_error",
     "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",
+    "ksr_stem_fwd", "ksr_pointwise_fwd", "ksr_dwrelu_pw_fwd", "ksr_gate_pw_fwd",
+    "ksr_batch_tx_layer_fwd", "ksr_feed_kan_supported", "ksr_feed_kan_fwd",
 ]
 
 

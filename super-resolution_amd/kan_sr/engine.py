@@ -1,0 +1,140 @@
+"""Launch sequences for the ConvSepKAN hot path: which kernel runs when, on which buffers.
+
+All activations between kernels are NHWC fp32 ([B*H*W, C]).  `forward_infer` is the no-grad
+path; the training path (forward that keeps what the backward needs + the backward itself) lives
+in `train_forward` / `train_backward` and is wrapped by one torch.autograd.Function in module.py.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from ._lib import KsrError, check, host_floats, lib, ptr, stream
+from .ops import bilinear_up_into, make_knots
+
+LN_EPS = 1e-5
+TX_PARAM_NAMES = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
+                  "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
+                  "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
+
+
+def _ptr_array(tensors) -> ctypes.Array:
+    arr = (c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = None if t is None else ptr(t).value
+    return arr
+
+
+class Geometry:
+    def __init__(self, x: torch.Tensor, upscale: int, grid_size: int, spline_order: int, grid_range):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise KsrError(f"expected input [B,3,H,W], got {tuple(x.shape)}")
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise KsrError("ConvSepKan (HIP path) needs a float32 GPU tensor")
+        self.B, _, self.H, self.W = x.shape
+        self.N = self.B * self.H * self.W
+        self.r = upscale
+        self.n_coef = grid_size + spline_order
+        self.k = spline_order
+        self.knots = make_knots(grid_size, spline_order, grid_range)
+        self.knots_c = host_floats(self.knots)
+        if self.B > 128:
+            raise KsrError("local batch > 128 is not supported by the batch-axis attention kernel")
+        if not lib().ksr_feed_kan_supported(c_int(self.r), c_int(self.n_coef), c_int(self.k)):
+            raise KsrError(f"no fused feed+KAN kernel for upscale={self.r}, grid_size+spline_order="
+                           f"{self.n_coef}, spline_order={self.k}")
+
+
+def _dims(g: Geometry):
+    return c_int(g.B), c_int(g.H), c_int(g.W)
+
+
+def new_seed() -> int:
+    """Dropout stream id drawn from torch's CPU generator (follows torch.manual_seed, no GPU sync)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Geometry,
+                    saves: Optional[dict] = None, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """Y plane of x -> final-LayerNormed 64-channel features [N,64] (input of `feed`).
+    With `saves` (a dict) every tensor the backward needs is kept there."""
+    L = lib()
+    dev = x.device
+    N = g.N
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    keep = saves is not None
+    t2 = new(N, 128)
+    v = new(N) if keep else None
+    check(L.ksr_stem_fwd(ptr(x), c_int64(3 * g.H * g.W), ptr(p[pre + "ffn1.pointwise1.weight"]),
+                         ptr(p[pre + "ffn1.pointwise1.bias"]), ptr(p[pre + "ffn1.depthwise.weight"]),
+                         ptr(p[pre + "ffn1.depthwise.bias"]), ptr(p[pre + "ffn1.pointwise2.weight"]),
+                         ptr(p[pre + "ffn1.pointwise2.bias"]), ptr(p[pre + "ffn2.fn_1.0.weight"]),
+                         ptr(p[pre + "ffn2.fn_1.0.bias"]), ptr(t2), ptr(v), *_dims(g), stream()), "ksr_stem_fwd")
+    x3 = new(N, 64)
+    g2 = new(N, 64) if keep else None
+    check(L.ksr_gate_pw_fwd(ptr(t2), ptr(p[pre + "ffn2.gate.weight"]), ptr(p[pre + "ffn2.gate.bias"]),
+                            ptr(p[pre + "ffn2.fn_2.weight"]), ptr(p[pre + "ffn2.fn_2.bias"]), ptr(x3), ptr(g2),
+                            *_dims(g), stream()), "ksr_gate_pw_fwd")
+    t3 = new(N, 64)
+    check(L.ksr_pointwise_fwd(ptr(x3), ptr(p[pre + "ffn3.pointwise1.weight"]), ptr(p[pre + "ffn3.pointwise1.bias"]),
+                              ptr(t3), c_int(64), c_int(0), *_dims(g), stream()), "ksr_pointwise_fwd")
+    x4 = new(N, 64)
+    a4 = new(N, 64) if keep else None
+    check(L.ksr_dwrelu_pw_fwd(ptr(t3), ptr(p[pre + "ffn3.depthwise.weight"]), ptr(p[pre + "ffn3.depthwise.bias"]),
+                              ptr(p[pre + "ffn3.pointwise2.weight"]), ptr(p[pre + "ffn3.pointwise2.bias"]),
+                              ptr(x4), ptr(a4), *_dims(g), stream()), "ksr_dwrelu_pw_fwd")
+    t5 = new(N, 128)
+    check(L.ksr_pointwise_fwd(ptr(x4), ptr(p[pre + "ffn4.fn_1.0.weight"]), ptr(p[pre + "ffn4.fn_1.0.bias"]),
+                              ptr(t5), c_int(128), c_int(1), *_dims(g), stream()), "ksr_pointwise_fwd")
+    x6 = new(N, 64)
+    g6 = new(N, 64) if keep else None
+    check(L.ksr_gate_pw_fwd(ptr(t5), ptr(p[pre + "ffn4.gate.weight"]), ptr(p[pre + "ffn4.gate.bias"]),
+                            ptr(p[pre + "ffn4.fn_2.weight"]), ptr(p[pre + "ffn4.fn_2.bias"]), ptr(x6), ptr(g6),
+                            *_dims(g), stream()), "ksr_gate_pw_fwd")
+    if keep:
+        saves.update(v=v, t2=t2, g2=g2, x3=x3, t3=t3, a4=a4, x4=x4, t5=t5, g6=g6, x6=x6)
+    s = x6
+    for li in range(2):
+        q = f"{pre}encoder.layers.{li}."
+        plist = [p[q + n] for n in TX_PARAM_NAMES]
+        last = li == 1
+        plist += [p[pre + "encoder.norm.weight"], p[pre + "encoder.norm.bias"]] if last else [None, None]
+        out = new(N, 64)
+        sv = None
+        if keep:
+            sv = dict(qkv=new(N, 192), ctx=new(N, 64), xhat1=new(N, 64), rstd1=new(N), s1=new(N, 64),
+                      hmid=new(N, 32), xhat2=new(N, 64), rstd2=new(N),
+                      xhatf=new(N, 64) if last else None, rstdf=new(N) if last else None)
+            sv["in"] = s
+            saves[f"tx{li}"] = sv
+        sv_arr = _ptr_array([sv[k] for k in ("qkv", "ctx", "xhat1", "rstd1", "s1", "hmid", "xhat2", "rstd2",
+                                             "xhatf", "rstdf")]) if keep else None
+        check(L.ksr_batch_tx_layer_fwd(ptr(s), ptr(out), _ptr_array(plist), sv_arr, c_int(g.B),
+                                       c_int(g.H * g.W), c_float(LN_EPS), c_float(p_drop),
+                                       c_uint64((seed * 4 + li) & 0xFFFFFFFFFFFFFFFF), stream()),
+              "ksr_batch_tx_layer_fwd")
+        s = out
+    if keep:
+        saves["feat"] = s
+    return s
+
+
+def feed_kan_forward(feat: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Geometry,
+                     out: torch.Tensor, save_us: Optional[torch.Tensor] = None) -> None:
+    check(lib().ksr_feed_kan_fwd(ptr(feat), ptr(x), c_int64(3 * g.H * g.W), ptr(p[pre + "feed.weight"]),
+                                 ptr(p[pre + "feed.bias"]), ptr(out), c_int64(out.shape[1] * out.shape[2] * out.shape[3]),
+                                 ptr(save_us), *_dims(g), c_int(g.r), c_int(g.n_coef), g.knots_c,
+                                 c_int(len(g.knots)), c_int(g.k), stream()), "ksr_feed_kan_fwd")
+
+
+def forward_infer(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Geometry,
+                  p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """[B,3,H,W] -> [B,3,rH,rW]: Y through encoder + fused feed/KAN/shuffle, Cb/Cr bilinear."""
+    out = torch.empty(g.B, 3, g.H * g.r, g.W * g.r, device=x.device, dtype=torch.float32)
+    bilinear_up_into(x, out, g.r, 1, 2, 1)
+    feat = encoder_forward(x, p, pre, g, None, p_drop, seed)
+    feed_kan_forward(feat, x, p, pre, g, out)
+    return out

@@ -1,0 +1,136 @@
+"""Drop-in `ConvSepKan` nn.Module (constructor / forward signature and state_dict keys of
+conv_sep_kan/conv_sep_kan.py:8-42) whose forward and backward run on libksr's HIP kernels.
+
+The sub-modules below are PARAMETER CONTAINERS: they exist so that `state_dict()` has the reference's
+52 keys, so that `.modules()` yields nn.Conv2d / nn.Linear instances for the training pipeline's
+isinstance-based re-initialisation (src/ml/pipelines/default.py:41-55), and so that default
+initialisation consumes the RNG in the reference's order.  They have no forward of their own.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, List
+
+import torch
+import torch.nn as nn
+
+from . import engine
+from ._lib import KsrError
+
+MID = 64
+
+
+class _Container(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise KsrError("parameter container: the computation runs in ConvSepKan.forward (HIP kernels)")
+
+
+class FFN(_Container):                      # conv_sep_kan/unet_blocks.py:212-234
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        hidden = in_features
+        self.pointwise1 = nn.Conv2d(in_features, hidden, kernel_size=1)
+        self.depthwise = nn.Conv2d(hidden, hidden, kernel_size=3, padding=1, groups=hidden)
+        self.pointwise2 = nn.Conv2d(hidden, out_features, kernel_size=1)
+
+
+class GatedFFN(_Container):                 # conv_sep_kan/unet_blocks.py:244-265
+    def __init__(self, channels):
+        super().__init__()
+        self.fn_1 = nn.Sequential(nn.Conv2d(channels, 2 * channels, kernel_size=1), nn.ReLU())
+        self.fn_2 = nn.Conv2d(channels, channels, kernel_size=1)
+        self.gate = nn.Conv2d(channels, channels, kernel_size=3, padding=1, groups=channels)
+
+
+class TransformerEncoderLayer(_Container):  # conv_sep_kan/gazetr.py:35-51
+    def __init__(self, channels, nhead, dim_feedforward, dropout):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(channels, nhead, dropout=dropout, batch_first=True)
+        self.linear1 = nn.Linear(channels, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, channels)
+        self.norm1 = nn.LayerNorm(channels)
+        self.norm2 = nn.LayerNorm(channels)
+        self.p_drop = dropout
+
+
+class TransformerEncoder(_Container):       # conv_sep_kan/gazetr.py:16-22
+    def __init__(self, layer, num_layers, norm):
+        super().__init__()
+        self.layers = nn.ModuleList([copy.deepcopy(layer) for _ in range(num_layers)])
+        self.norm = norm
+
+
+class GazeTR(_Container):                   # conv_sep_kan/gazetr.py:69-98
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.ffn1 = FFN(in_channels, MID)
+        self.ffn2 = GatedFFN(MID)
+        self.ffn3 = FFN(MID, MID)
+        self.ffn4 = GatedFFN(MID)
+        layer = TransformerEncoderLayer(MID, 2, 32, 0.1)
+        self.encoder = TransformerEncoder(layer, 2, nn.LayerNorm(MID))
+        self.feed = nn.Conv2d(MID, out_channels, kernel_size=1)
+
+
+class ConvSepKanEncoder(_Container):        # conv_sep_kan/conv_sep_kan_encoder.py:12-17
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.encoder = GazeTR(in_channels, out_channels)
+
+
+class ConvSepKanCell(_Container):           # conv_sep_kan/conv_sep_kan_cells.py:106-134 (no parameters)
+    def __init__(self, in_channels, out_channels, grid_size, spline_order, residual_std, grid_range):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.grid_size, self.spline_order, self.grid_range = grid_size, spline_order, list(grid_range)
+        self.size = out_channels * in_channels * (grid_size + spline_order + 2)
+
+
+class ConvSepKanLayer(_Container):          # conv_sep_kan/conv_sep_kan_layer.py:7-15
+    def __init__(self, in_channels, out_channels, grid_size, spline_order, residual_std, grid_range):
+        super().__init__()
+        self.kan_cell = ConvSepKanCell(in_channels, out_channels, grid_size, spline_order, residual_std, grid_range)
+        self.encoder = ConvSepKanEncoder(in_channels, self.kan_cell.size)
+
+
+class ConvSepKan(nn.Module):
+    """Same constructor arguments as the reference; `kernel_sizes` and `residual_std` are accepted and
+    unused there too.  forward(x[B,3,H,W]) -> [B,3,rH,rW] (Y', Cb, Cr)."""
+
+    def __init__(self, in_channels: list, out_channels: list, kernel_sizes: list, grid_size, spline_order,
+                 residual_std, grid_range, upscale):
+        super().__init__()
+        self.upscale = upscale
+        self.grid_size, self.spline_order, self.grid_range = grid_size, spline_order, list(grid_range)
+        self.layers = nn.ModuleList()
+        self.shuffle = nn.PixelShuffle(upscale)          # kept for module-tree parity; no parameters
+        for in_ch, out_ch in zip(in_channels, out_channels):
+            self.layers.append(ConvSepKanLayer(in_ch, out_ch, grid_size, spline_order, residual_std, grid_range))
+        if len(self.layers) == 0:
+            raise KsrError("ConvSepKan needs at least one layer")
+        # Every layer is fed the Y plane and only the last layer's output survives the reference's
+        # loop (conv_sep_kan.py:36-37): the earlier layers are dead weight and are not evaluated.
+        last = self.layers[-1].kan_cell
+        if last.in_channels != 1:
+            raise KsrError("the layers read x[:, :1]: in_channels must be 1")
+        if last.out_channels != upscale * upscale:
+            raise KsrError("concat([y, cb, cr]) needs out_channels[-1] == upscale**2")
+
+    def _params(self) -> Dict[str, torch.Tensor]:
+        li = len(self.layers) - 1
+        pre = f"layers.{li}."
+        return {pre + n: t for n, t in self.layers[li].named_parameters()}
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.contiguous()
+        g = engine.Geometry(x, self.upscale, self.grid_size, self.spline_order, self.grid_range)
+        p = self._params()
+        pre = f"layers.{len(self.layers) - 1}.encoder.encoder."
+        needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in p.values())
+        p_drop = self.layers[-1].encoder.encoder.encoder.layers[0].p_drop if self.training else 0.0
+        seed = engine.new_seed() if p_drop > 0 else 0
+        if not needs_grad:
+            with torch.no_grad():
+                return engine.forward_infer(x, p, pre, g, p_drop, seed)
+        from .autograd import conv_sep_kan_train
+        return conv_sep_kan_train(x, p, pre, g, p_drop, seed)

@@ -1,0 +1,136 @@
+"""GPU parity of the encoder kernels and the whole ConvSepKan forward against the CPU oracle and the
+reference-generated golden vectors.  fp32 tolerance: max|d| <= 1e-5 + 1e-4*|ref|."""
+import ctypes
+from ctypes import c_float, c_int, c_int64, c_uint64
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2, t
+from oracle import convsepkan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+FWD_ATOL, FWD_RTOL, GRAD_REL = 1e-5, 1e-4, 1e-4
+
+
+def assert_fwd(a, ref, atol=FWD_ATOL, rtol=FWD_RTOL):
+    a, ref = a.detach().cpu(), ref.detach().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    err = (a - ref).abs()
+    assert bool((err <= atol + rtol * ref.abs()).all()), f"max err {float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e})"
+
+
+def nhwc(x):   # [B,C,H,W] -> [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def nchw(x, B, H, W):
+    return x.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+def cuda_params(p):
+    return {k: v.detach().cuda().contiguous() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 9, 11), (1, 37, 70), (3, 4, 32)])
+def test_encoder_trunk_stages(B, H, W):
+    """stem / gate / pointwise / dwrelu kernels one by one against the oracle's conv blocks."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(5)
+    p = orc.random_params(16, 5, 3, seed=7)
+    pre = "layers.0.encoder.encoder."
+    x = torch.rand(B, 3, H, W)
+    pc = cuda_params(p)
+    xc = x.cuda()
+    g = engine.Geometry(xc, 4, 5, 3, [-1, 1])
+    saves = {}
+    feat = engine.encoder_forward(xc, pc, pre, g, saves)
+    # oracle stage by stage
+    y1 = orc.ffn(x[:, :1], p, pre + "ffn1.")
+    t2 = torch.relu(torch.nn.functional.conv2d(y1, p[pre + "ffn2.fn_1.0.weight"], p[pre + "ffn2.fn_1.0.bias"]))
+    assert_fwd(nchw(saves["t2"], B, H, W), t2)
+    x3 = torch.sigmoid(orc.gated_ffn(y1, p, pre + "ffn2."))
+    assert_fwd(nchw(saves["x3"], B, H, W), x3)
+    x4 = orc.ffn(x3, p, pre + "ffn3.")
+    assert_fwd(nchw(saves["x4"], B, H, W), x4)
+    x6 = torch.sigmoid(orc.gated_ffn(x4, p, pre + "ffn4."))
+    assert_fwd(nchw(saves["x6"], B, H, W), x6)
+    ref = orc.gazetr_features(x[:, :1], p, pre)
+    assert_fwd(nchw(feat, B, H, W), ref, atol=2e-5)
+
+
+@pytest.mark.parametrize("S", [1, 2, 3, 8, 32, 64, 100])
+def test_batch_tx_layer_vs_oracle(S):
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(S)
+    HW = 50 if S < 64 else 7
+    p = orc.random_params(16, 5, 3, seed=3, scale=2.0)
+    pre = "layers.0.encoder.encoder.encoder.layers.0."
+    s = torch.randn(HW, S, 64)
+    ref = orc.batch_tx_layer(s, p, pre)
+    pc = cuda_params(p)
+    sin = s.permute(1, 0, 2).contiguous().cuda()          # [S, HW, 64]
+    out = torch.empty_like(sin)
+    plist = [pc[pre + n] for n in engine.TX_PARAM_NAMES] + [None, None]
+    check(lib().ksr_batch_tx_layer_fwd(ptr(sin), ptr(out), engine._ptr_array(plist), None, c_int(S), c_int(HW),
+                                       c_float(1e-5), c_float(0.0), c_uint64(0), stream()), "tx")
+    assert_fwd(out.permute(1, 0, 2), ref, atol=2e-5)
+
+
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_gazetr_golden_features_through_feed(B):
+    """GazeTR golden (P=40, i.e. upscale 2): encoder + fused feed/KAN output equals the oracle's KAN
+    applied to the reference's own `gaze` tensor."""
+    from kan_sr import engine
+    g = load_golden("gazetr")
+    pre = "layers.0.encoder.encoder."
+    p = {pre + k[2:]: t(v) for k, v in g.items() if k.startswith("p.")}
+    x1 = t(g[f"B{B}.x"])
+    x = torch.cat([x1, torch.zeros(B, 2, 8, 8)], 1).contiguous()
+    geo = engine.Geometry(x.cuda(), 2, 5, 3, [-1, 1])
+    out = engine.forward_infer(x.cuda(), cuda_params(p), pre, geo)
+    ref = orc.pixel_shuffle(orc.kan_cell(x1, t(g[f"B{B}.y"]), 4, 5, 3, [-1, 1]), 2)
+    assert_fwd(out[:, :1], ref, atol=2e-5)
+
+
+@pytest.mark.parametrize("r,G,k", [(2, 5, 3), (4, 5, 3), (4, 16, 3)])
+def test_full_model_forward_golden(r, G, k):
+    from kan_sr.module import ConvSepKan
+    g = load_golden(f"model_r{r}_G{G}_k{k}")
+    m = ConvSepKan([1], [r * r], [3], G, k, 0.1, [-1, 1], r)
+    sd = {n[2:]: t(v) for n, v in g.items() if n.startswith("p.")}
+    assert set(sd) == set(m.state_dict().keys())
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        y = m(t(g["x"]).cuda())
+    assert_fwd(y, t(g["y"]), atol=2e-5)
+
+
+def test_cfg1_shape_golden():
+    from kan_sr.module import ConvSepKan
+    g = load_golden("cfg1_smoke")
+    m = ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2)
+    m.load_state_dict({n[2:]: t(v) for n, v in g.items() if n.startswith("p.")})
+    m = m.cuda().eval()
+    with torch.no_grad():
+        y = m(t(g["x"]).cuda()).cpu()
+    assert y.shape == (4, 3, 128, 128)
+    assert_fwd(y[:, :, :4, :4], t(g["y_corner"]), atol=2e-5)
+    assert_fwd(y[1, 0, 77], t(g["y_row"]), atol=2e-5)
+    assert abs(float(y.double().sum()) - float(g["y_sum"])) < 5e-2
+
+
+def test_default_init_matches_reference_rng_order():
+    """Constructing under the same torch seed reproduces the reference's initial conv / linear weights."""
+    from kan_sr.module import ConvSepKan
+    g = load_golden("model_r4_G5_k3")
+    torch.manual_seed(600 + 10 * 4 + 5)
+    m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4)
+    for n, v in m.state_dict().items():
+        if "norm" in n:
+            continue
+        assert torch.equal(v, t(g["p." + n])), n
