@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native ConvSepKAN hot path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload infer|train]
+
+One JSON line on stdout (rank 0).  Workloads (synthetic data, random-init weights, seeds fixed):
+  infer : x4 SR inference, fp32, eval, one 960x540 YCbCr frame -> 3840x2160 per step and GPU
+          (BASELINE config "x4 SR inference, 1xMI355X, fp32, 1080p->4K"); N>1 = N independent replicas.
+  train : x4 SR training step (forward + backward [+ gradient all-reduce when N>1]), 64 patches of
+          128x128 per GPU (weak scaling, the per-rank batch semantics of the reference's trainer).
+`value` = whole-job output megapixels per second with inputs resident in HBM.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "super-resolution_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (spec)
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_pixel(name: str, S: int, P: int) -> float:
+    """Algorithmic flops per LR pixel and launch of each forward kernel (2*Cin*Cout per 1x1 conv,
+    2*9 per depthwise output channel, 256*S per token for the two attention products)."""
+    return {
+        "ksr_stem_fwd": 2 * 64 * 128 + 2 * 9 + 2 + 2 * 64,
+        "ksr_gate_pw_fwd": 2 * 64 * 64 + 2 * 9 * 64 + 64,
+        "ksr_pointwise_fwd": 2 * 64 * 96,                       # one 64->64 and one 64->128 launch: mean
+        "ksr_dwrelu_pw_fwd": 2 * 64 * 64 + 2 * 9 * 64,
+        "ksr_batch_tx_layer_fwd": 2 * (64 * 192 + 64 * 64 + 64 * 32 + 32 * 64) + 256 * S,
+        "ksr_feed_kan_fwd": 2 * 64 * P + 400,
+        "ksr_bilinear_up": 0,
+    }.get(name, 0)
+
+
+def build_model(upscale=4, G=5, k=3, seed=0):
+    from kan_sr.module import ConvSepKan
+    from kan_sr.init import init_like_training_setup
+    torch.manual_seed(seed)
+    m = ConvSepKan([1], [upscale * upscale], [3], G, k, 0.1, [-1, 1], upscale)
+    init_like_training_setup(m, seed)
+    return m
+
+
+def cpu_baseline(workload: str, seconds_budget: float = 12.0):
+    """The CPU restatement (oracle) of the same path on the host cores, bounded sample."""
+    from oracle import convsepkan_oracle as orc
+    ncores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+    torch.set_num_threads(ncores)
+    torch.manual_seed(1234)
+    p = orc.init_like_training_setup(orc.random_params(16, 5, 3, seed=0), seed=0)
+    kw = dict(out_channels=[16], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=4)
+    if workload == "infer":
+        x = torch.rand(1, 3, 270, 480)
+        sample = "one 270x480 LR tile (1/4 of the 960x540 frame), eval, no_grad"
+
+        def step():
+            with torch.no_grad():
+                orc.conv_sep_kan_forward(x, p, **kw)
+    else:
+        x = torch.rand(4, 3, 128, 128)
+        p = {n: v.requires_grad_() for n, v in p.items()}
+        sample = "4 patches of 128x128 (1/16 of the per-GPU batch), eval-mode graph, fwd+bwd"
+
+        def step():
+            y = orc.conv_sep_kan_forward(x, p, **kw)
+            y[:, :1].mean().backward()
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    best = 1e30
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 20):
+        t1 = time.perf_counter()
+        step()
+        best = min(best, time.perf_counter() - t1)
+        n += 1
+    mp = x.shape[0] * x.shape[2] * 4 * x.shape[3] * 4 / 1e6
+    return {"value": round(mp / best, 4), "unit": "MP/s", "cores": ncores, "kind": "port",
+            "sample": f"{sample}; best of {n} runs, {best * 1e3:.0f} ms each"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "infer"), choices=["infer", "train"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group("nccl", device_id=dev)
+
+    from kan_sr import _lib, engine
+    _lib.lib()   # fail loudly if the HIP library is missing
+
+    model = build_model().to(dev)
+    torch.manual_seed(1234 + rank)
+    if args.workload == "infer":
+        B, H, W = 1, 540, 960
+        model.eval()
+        x = torch.rand(B, 3, H, W, device=dev)
+        wl = "x4 SR inference fp32, 960x540 -> 3840x2160 frame (BASELINE configs[1]); N>1 = replicas"
+
+        def step():
+            with torch.no_grad():
+                return model(x)
+    else:
+        from kan_sr.train import TrainStep
+        B, H, W = 64, 128, 128
+        model.train()
+        x = torch.rand(B, 3, H, W, device=dev)
+        tgt = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
+        ts = TrainStep(model, world_size=world, rank=rank)
+        wl = ("x4 SR training step fp32 (fwd + bwd + RCCL gradient all-reduce + Adam), 64 patches of 128x128 per GPU "
+              "(BASELINE configs[2], per-rank batch), dropout live")
+
+        def step():
+            return ts.step(x, tgt)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    out_mp = B * (4 * H) * (4 * W) / 1e6
+    value = world * out_mp * args.steps / dt
+
+    roofline = None
+    cpu = None
+    if rank == 0:
+        # ---- per-kernel live timing (events on the launch stream), separate short run ----
+        _lib.PROFILE = {}
+        for _ in range(max(3, min(args.steps, 10))):
+            step()
+        torch.cuda.synchronize()
+        prof = {k: [s.elapsed_time(e) for s, e in v] for k, v in _lib.PROFILE.items()}
+        _lib.PROFILE = None
+        nlaunch = max(3, min(args.steps, 10))
+        totals = {k: sum(v) / nlaunch for k, v in prof.items()}            # ms per step per entry point
+        dom = max(totals, key=totals.get)
+        avg_ms = sum(prof[dom]) / len(prof[dom])
+        P = 16 * (5 + 3 + 2)
+        fl = flops_per_pixel(dom, B, P) * B * H * W
+        if dom.endswith("_bwd") or dom.endswith("_wgrad"):
+            fl = None
+        if fl:
+            ach = fl / (avg_ms * 1e-3) / 1e12
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                        "avg_launch_ms": round(avg_ms, 4),
+                        "ms_per_step_by_entry_point": {k: round(v, 4) for k, v in sorted(totals.items())}}
+        else:
+            roofline = {"kernel": dom, "bound": "mfma", "achieved": None, "peak": PEAK_MFMA_F32_TFLOPS,
+                        "unit": "TFLOP/s", "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                        "ms_per_step_by_entry_point": {k: round(v, 4) for k, v in sorted(totals.items())}}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args.workload)
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({
+            "metric": "output megapixels/sec", "value": round(value, 3), "unit": "MP/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "config": {"workload": wl, "upscale": 4, "grid_size": 5, "spline_order": 3,
+                                            "per_gpu_batch": B, "lr_patch": [H, W]},
+            "roofline": roofline, "cpu_baseline": cpu}))
+
+
+if __name__ == "__main__":
+    main()

@@ -22,15 +22,45 @@ class KsrError(RuntimeError):
     pass
 
 
-def lib() -> ctypes.CDLL:
+# When set to a dict, every library call is bracketed by two events on torch's current stream (the
+# stream the kernels are launched on) and appended under the entry point's name: bench.py uses this
+# to time individual kernels live.  None (the default) adds no overhead beyond one attribute test.
+PROFILE = None
+
+
+class _Proxy:
+    """Attribute access returns the ctypes function, wrapped with event timing while PROFILE is set."""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        fn = getattr(self._cdll, name)
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_mean", "_reduce")):
+            return fn
+
+        def timed(*args):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = fn(*args)
+            e.record()
+            PROFILE.setdefault(name, []).append((s, e))
+            return rc
+
+        return timed
+
+
+def lib() -> "_Proxy":
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise KsrError(
                 f"{LIB_PATH} is missing: build it with `make -C super-resolution_amd/csrc` "
                 "(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
-        _lib = ctypes.CDLL(LIB_PATH)
-        _declare(_lib)
+        cdll = ctypes.CDLL(LIB_PATH)
+        _declare(cdll)
+        _lib = _Proxy(cdll)
     return _lib
 
 
