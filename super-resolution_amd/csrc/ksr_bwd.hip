@@ -1,0 +1,227 @@
+// Backward "data gradient" kernels of the separable-conv trunk and of the QKV projection:
+//     [prologue that assembles dZ per pixel]  ->  dX = dZ * W (transposed 1x1 conv, MFMA)  ->  epilogue
+// Same one-pixel-per-lane scheme as the forward (ksr_gemm.h).  The prologue may apply the
+// TRANSPOSED depthwise 3x3 to a gradient tensor staged as an LDS halo tile (flipped taps), the
+// epilogue applies the derivative of whatever preceded the 1x1 conv in the forward pass.
+#include "ksr_conv_common.h"
+
+namespace {
+
+enum { BPRO_PLAIN = 0, BPRO_CONVT = 1, BPRO_CONVT_G = 2 };
+enum { BEPI_STORE = 0, BEPI_RELUMASK = 1, BEPI_SIGGRAD = 2, BEPI_GATE = 3, BEPI_RESID = 4, BEPI_RESID_SIGGRAD = 5,
+       BEPI_STEM = 6 };
+
+struct BwdArgs {
+    const float* dz; int dz_ld;                 // [N, dz_ld] gradient of the 1x1 conv output (PLAIN: KIN read;
+                                                //  CONVT_G: channels 0..63 read)
+    float* dz_store; int dz_store_ld, dz_store_c0;   // CONVT*: the conv-transposed part is also stored here
+    const float* halo_src;                      // [N,64] gradient to conv-transpose
+    const float* dw_w;                          // [64][9] depthwise weights
+    const float* mask_src; int mask_ld, mask_c0;     // CONVT_G: result *= (mask_src > 0)
+    const float* wt;                            // [KIN][64] weights of the forward 1x1 conv (C_out = KIN)
+    const float* e1; int e1_ld, e1_c0;
+    const float* e2; int e2_ld, e2_c0;
+    const float* resid;                         // [N,64]
+    float* out1; int out1_ld, out1_c0;
+    float* out2;                                // [N,64]
+    const float* v; const float* p2w; float* dpre;   // STEM epilogue
+    int B, H, W;
+};
+
+template <int KIN, int BPRO>
+struct __attribute__((aligned(16))) BwdSmem {
+    float frag[2 * (KIN / 2) * 64];
+    float dww[BPRO == BPRO_PLAIN ? 4 : 9 * 64];
+    float p2w[64];
+    float halo[BPRO == BPRO_PLAIN ? 4 : HALO_FLOATS];
+};
+
+template <int KIN, int BPRO, int BEPI>
+__global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
+    constexpr int KH = KIN / 2;
+    __shared__ BwdSmem<KIN, BPRO> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<KH, 2, true>(sm.frag, nullptr, a.wt, 64, nullptr, MapHL{32}, MapHL{KH}, tid, 256);
+    if (BPRO != BPRO_PLAIN) ksr_stage_dw<true>(sm.dww, a.dw_w, tid);
+    if (BEPI == BEPI_STEM && tid < 64) sm.p2w[tid] = a.p2w[tid];
+    __syncthreads();
+
+    const int HW = a.H * a.W;
+    const long N = (long)a.B * HW;
+    constexpr bool spatial = (BPRO != BPRO_PLAIN);
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
+    const long ntiles = spatial ? (long)a.B * tiles_y * tiles_x : (N + 127) / 128;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        bool live;
+        long n;
+        if (spatial) {
+            const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+            const int b = (int)(tile / ((long)tiles_x * tiles_y));
+            const int y0 = ty * 4, x0 = tx * 32;
+            const int y = y0 + wv, x = x0 + tok;
+            live = (y < a.H) && (x < a.W);
+            n = live ? (long)b * HW + (long)y * a.W + x : 0;
+            __syncthreads();
+            ksr_stage_halo(sm.halo, a.halo_src, 64, 0, b, y0, x0, a.H, a.W, tid);
+            __syncthreads();
+        } else {
+            n = tile * 128 + wv * 32 + tok;
+            live = n < N;
+            if (!live) n = 0;
+        }
+
+        float dz[KH];
+        if (BPRO == BPRO_PLAIN) {
+#pragma unroll
+            for (int grp = 0; grp < KIN / 64; ++grp) ksr_load32(a.dz + n * a.dz_ld + 64 * grp + 32 * h, dz + 32 * grp);
+        } else {
+            float g[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) g[i] = 0.f;
+            ksr_dwconv_lane(sm.halo, sm.dww, wv, tok, h, g);
+            if (BPRO == BPRO_CONVT_G) {
+                float mk[32];
+                ksr_load32(a.mask_src + n * a.mask_ld + a.mask_c0 + 32 * h, mk);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) g[i] = mk[i] > 0.f ? g[i] : 0.f;
+                ksr_load32(a.dz + n * a.dz_ld + 32 * h, dz);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) dz[32 + i] = g[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) dz[i] = g[i];
+            }
+            if (live) ksr_store32(a.dz_store + n * a.dz_store_ld + a.dz_store_c0 + 32 * h, g);
+        }
+
+        f32x16 acc[2];
+        ksr_wave_gemm<KH, 2>(sm.frag, nullptr, dz, acc, lane);
+        float dA[32];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { dA[i] = acc[0][i]; dA[16 + i] = acc[1][i]; }
+
+        if (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD) {
+            float r[32];
+            ksr_load32(a.resid + n * 64 + 32 * h, r);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) dA[i] += r[i];
+        }
+        if (BEPI == BEPI_RELUMASK) {
+            float e[32];
+            ksr_load32(a.e1 + n * a.e1_ld + a.e1_c0 + 32 * h, e);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) dA[i] = e[i] > 0.f ? dA[i] : 0.f;
+        }
+        if (BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD) {
+            float e[32];
+            ksr_load32(a.e1 + n * a.e1_ld + a.e1_c0 + 32 * h, e);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) dA[i] = dA[i] * e[i] * (1.f - e[i]);
+        }
+        if (BEPI == BEPI_GATE) {
+            float gte[32], val[32], o2[32];
+            ksr_load32(a.e1 + n * a.e1_ld + a.e1_c0 + 32 * h, gte);
+            ksr_load32(a.e2 + n * a.e2_ld + a.e2_c0 + 32 * h, val);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                o2[i] = dA[i] * val[i];
+                dA[i] = val[i] > 0.f ? dA[i] * gte[i] : 0.f;
+            }
+            if (live) ksr_store32(a.out2 + n * 64 + 32 * h, o2);
+        }
+        if (BEPI == BEPI_STEM) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) s += dA[i] * sm.p2w[32 * h + i];
+            s = ksr_pair_sum(s);
+            if (live && h == 0) a.dpre[n] = a.v[n] > 0.f ? s : 0.f;
+        }
+        if (live) ksr_store32(a.out1 + n * a.out1_ld + a.out1_c0 + 32 * h, dA);
+    }
+}
+
+template <int KIN, int BPRO, int BEPI>
+int launch_dgrad(const BwdArgs& a, hipStream_t s) {
+    const long N = (long)a.B * a.H * a.W;
+    const bool spatial = BPRO != BPRO_PLAIN;
+    const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
+    const long cap = spatial ? 512 : 768;
+    hipLaunchKernelGGL((dgrad_kernel<KIN, BPRO, BEPI>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, s, a);
+    KSR_LAUNCH_CHECK("dgrad");
+    return KSR_OK;
+}
+
+int dims_ok(int B, int H, int W, const char* who) {
+    KSR_CHECK_ARG(B > 0 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "%s: bad dimensions", who);
+    return KSR_OK;
+}
+
+}  // namespace
+
+// GatedFFN tail backward (fn_2 + value*gate product), used for ffn2 and ffn4.
+extern "C" int ksr_gate_pw_bwd(const float* dz, const float* fn2_w, const float* gate_saved, const float* t_saved,
+                               float* dt_value, float* dgate, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dz && fn2_w && gate_saved && t_saved && dt_value && dgate, "gate_pw_bwd: null pointer");
+    if (int rc = dims_ok(B, H, W, "gate_pw_bwd")) return rc;
+    BwdArgs a{};
+    a.dz = dz; a.dz_ld = 64; a.wt = fn2_w; a.e1 = gate_saved; a.e1_ld = 64; a.e2 = t_saved; a.e2_ld = 128;
+    a.out1 = dt_value; a.out1_ld = 128; a.out1_c0 = 0; a.out2 = dgate; a.B = B; a.H = H; a.W = W;
+    return launch_dgrad<64, BPRO_PLAIN, BEPI_GATE>(a, stream);
+}
+
+// fn_1 (64 -> 128) backward: completes dt[:, 64:128] = convT(dgate) * (t[:, 64:] > 0) and computes
+// dx = dt * W.  stem = 1: the input of fn_1 is the first FFN (1 -> 64): also emits dpre [N].
+extern "C" int ksr_fn1_bwd(float* dt, const float* dgate, const float* gate_w, const float* t_saved,
+                           const float* fn1_w, float* dx, int stem, const float* v_saved, const float* pw2_w,
+                           float* dpre, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dt && dgate && gate_w && t_saved && fn1_w && dx, "fn1_bwd: null pointer");
+    if (int rc = dims_ok(B, H, W, "fn1_bwd")) return rc;
+    BwdArgs a{};
+    a.dz = dt; a.dz_ld = 128; a.dz_store = dt; a.dz_store_ld = 128; a.dz_store_c0 = 64;
+    a.halo_src = dgate; a.dw_w = gate_w; a.mask_src = t_saved; a.mask_ld = 128; a.mask_c0 = 64;
+    a.wt = fn1_w; a.out1 = dx; a.out1_ld = 64; a.B = B; a.H = H; a.W = W;
+    if (stem) {
+        KSR_CHECK_ARG(v_saved && pw2_w && dpre, "fn1_bwd(stem): null pointer");
+        a.v = v_saved; a.p2w = pw2_w; a.dpre = dpre;
+        return launch_dgrad<128, BPRO_CONVT_G, BEPI_STEM>(a, stream);
+    }
+    return launch_dgrad<128, BPRO_CONVT_G, BEPI_STORE>(a, stream);
+}
+
+// FFN pointwise2 backward: ds = (dy * W) * (operand > 0), operand = relu(dw(.)) saved by the forward.
+extern "C" int ksr_pw2_bwd(const float* dy, const float* pw2_w, const float* operand_saved, float* ds, int B, int H,
+                           int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dy && pw2_w && operand_saved && ds, "pw2_bwd: null pointer");
+    if (int rc = dims_ok(B, H, W, "pw2_bwd")) return rc;
+    BwdArgs a{};
+    a.dz = dy; a.dz_ld = 64; a.wt = pw2_w; a.e1 = operand_saved; a.e1_ld = 64; a.out1 = ds; a.out1_ld = 64;
+    a.B = B; a.H = H; a.W = W;
+    return launch_dgrad<64, BPRO_PLAIN, BEPI_RELUMASK>(a, stream);
+}
+
+// FFN pointwise1 backward: dt = convT(ds) (stored), dx = dt * W, then the sigmoid that fed the FFN:
+// dz_prev = dx * y * (1 - y).
+extern "C" int ksr_pw1_bwd(const float* ds, const float* dw_w, const float* pw1_w, const float* y_saved, float* dt,
+                           float* dz_prev, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(ds && dw_w && pw1_w && y_saved && dt && dz_prev, "pw1_bwd: null pointer");
+    if (int rc = dims_ok(B, H, W, "pw1_bwd")) return rc;
+    BwdArgs a{};
+    a.halo_src = ds; a.dw_w = dw_w; a.dz_store = dt; a.dz_store_ld = 64; a.dz_store_c0 = 0; a.wt = pw1_w;
+    a.e1 = y_saved; a.e1_ld = 64; a.out1 = dz_prev; a.out1_ld = 64; a.B = B; a.H = H; a.W = W;
+    return launch_dgrad<64, BPRO_CONVT, BEPI_SIGGRAD>(a, stream);
+}
+
+// QKV projection backward + residual: ds = resid + dqkv * W_in, optionally followed by the sigmoid
+// derivative of the tensor that entered the first transformer layer (y_saved != NULL).
+extern "C" int ksr_in_proj_bwd(const float* dqkv, const float* in_w, const float* resid, const float* y_saved,
+                               float* ds, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dqkv && in_w && resid && ds, "in_proj_bwd: null pointer");
+    if (int rc = dims_ok(B, H, W, "in_proj_bwd")) return rc;
+    BwdArgs a{};
+    a.dz = dqkv; a.dz_ld = 192; a.wt = in_w; a.resid = resid; a.e1 = y_saved; a.e1_ld = 64;
+    a.out1 = ds; a.out1_ld = 64; a.B = B; a.H = H; a.W = W;
+    if (y_saved) return launch_dgrad<192, BPRO_PLAIN, BEPI_RESID_SIGGRAD>(a, stream);
+    return launch_dgrad<192, BPRO_PLAIN, BEPI_RESID>(a, stream);
+}

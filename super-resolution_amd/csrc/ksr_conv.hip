@@ -9,7 +9,7 @@
 //   PRO_GATE   : operand = in[n, 0:64] * (dw3x3(in[:, 64:128]) + b) - GatedFFN value * gated half
 // The depthwise 3x3 (zero padding 1) reads a 6 x 34 pixel halo tile of its 64 input channels staged in
 // LDS with coalesced 16-byte loads; the workgroup's 4 waves each take one 32-pixel row of a 4 x 32 tile.
-#include "ksr_gemm.h"
+#include "ksr_conv_common.h"
 
 namespace {
 
@@ -33,7 +33,6 @@ struct ConvArgs {
     int B, H, W;
 };
 
-constexpr int HALO_W = 34, HALO_H = 6, HALO_LD = 68;  // 64 channels + 4 floats pad per pixel
 
 template <int PRO, int NB>
 struct __attribute__((aligned(16))) ConvSmem {
@@ -62,7 +61,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
 
     ksr_stage_weights<32, NB, false>(sm.frag, sm.biasfrag, a.wt, 64, a.bias, MapHL{NOUT / 2}, MapHL{32}, tid, 256);
     if (PRO == PRO_DWRELU || PRO == PRO_GATE) {
-        for (int i = tid; i < 9 * 64; i += 256) sm.dww[i] = a.dw_w[(i & 63) * 9 + (i >> 6)];  // [tap][c]
+        ksr_stage_dw<false>(sm.dww, a.dw_w, tid);
         if (tid < 64) sm.dwb[tid] = a.dw_b[tid];
     }
     if (PRO == PRO_STEM) {
@@ -91,15 +90,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             // ---- stage the halo tile (rows y0-1..y0+4, cols x0-1..x0+32, 64 channels) ----
             const int c0 = (PRO == PRO_GATE) ? 64 : 0;
             __syncthreads();   // previous tile's readers are done
-            for (int c = tid; c < HALO_H * HALO_W * 16; c += 256) {
-                const int q = c & 15, pix = c >> 4;
-                const int hx = pix % HALO_W, hy = pix / HALO_W;
-                const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
-                    v = *reinterpret_cast<const float4*>(a.in + ((long)b * HW + (long)gy * a.W + gx) * a.in_ld + c0 + 4 * q);
-                *reinterpret_cast<float4*>(&sm.halo[pix * HALO_LD + 4 * q]) = v;
-            }
+            ksr_stage_halo(sm.halo, a.in, a.in_ld, c0, b, y0, x0, a.H, a.W, tid);
             __syncthreads();
         } else {
             n = tile * 128 + wv * 32 + tok;
@@ -139,21 +130,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             float g[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = sm.dwb[32 * h + i];
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float* hp = &sm.halo[((wv + dy) * HALO_W + (tok + dx)) * HALO_LD + 32 * h];
-                    const float* wp = &sm.dww[(dy * 3 + dx) * 64 + 32 * h];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const f32x4 tv = *reinterpret_cast<const f32x4*>(hp + 4 * q);
-                        const f32x4 wq = *reinterpret_cast<const f32x4*>(wp + 4 * q);
-                        g[4 * q + 0] += wq[0] * tv[0]; g[4 * q + 1] += wq[1] * tv[1];
-                        g[4 * q + 2] += wq[2] * tv[2]; g[4 * q + 3] += wq[3] * tv[3];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // one tap at a time: bounds live registers
-                }
+            ksr_dwconv_lane(sm.halo, sm.dww, wv, tok, h, g);
             if (PRO == PRO_DWRELU) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) op[i] = g[i] > 0.f ? g[i] : 0.f;

@@ -141,6 +141,101 @@ int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
     return KSR_OK;
 }
 
+template <int NB>
+struct __attribute__((aligned(16))) FeedBwdSmem {
+    float frag[2 * (NB * 16) * 64];
+    float knots[KSR_MAX_KNOTS];
+};
+
+// Backward: dparam[e] per lane (lane order), dfeat = dparam * W_feed, both stored; the feed weight
+// gradient is a separate reduction over pixels (ksr_wgrad with the KAN row map).
+template <int R, int KC, int KORD>
+__global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKnots kn) {
+    using C = FeedCfg<R, KC>;
+    constexpr int NB = C::NB, KH = NB * 16;
+    __shared__ FeedBwdSmem<NB> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<KH, 2, true>(sm.frag, nullptr, a.w, 64, nullptr, MapHL{32}, MapKan{C::O, KC}, tid, 256);
+    if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
+    __syncthreads();
+
+    const int HW = a.H * a.W;
+    const long N = (long)a.B * HW;
+    const long ntiles = (N + 127) / 128;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n0 = tile * 128 + wv * 32 + tok;
+        const bool live = n0 < N;
+        const long n = live ? n0 : 0;
+        const int b = (int)(n / HW), hw = (int)(n % HW);
+        const int y = hw / a.W, x = hw % a.W;
+
+        float go[C::OH];
+        {
+            const float* gp = a.gout + (long)b * a.out_bstride + ((long)(y * R + h * (R / 2))) * (a.W * R) + (long)x * R;
+#pragma unroll
+            for (int rr = 0; rr < R / 2; ++rr) {
+                if (R == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(gp + (long)rr * a.W * R);
+                    go[rr * R + 0] = v.x; go[rr * R + 1] = v.y; go[rr * R + 2] = v.z; go[rr * R + 3] = v.w;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(gp + (long)rr * a.W * R);
+                    go[rr * R + 0] = v.x; go[rr * R + 1] = v.y;
+                }
+            }
+        }
+        float us[C::OH * 2];
+        {
+            const float4* up = reinterpret_cast<const float4*>(a.save_us + (n * C::O + h * C::OH) * 2);
+#pragma unroll
+            for (int q = 0; q < C::OH / 2; ++q) {
+                const float4 v = up[q];
+                us[4 * q + 0] = v.x; us[4 * q + 1] = v.y; us[4 * q + 2] = v.z; us[4 * q + 3] = v.w;
+            }
+        }
+        const float xv = a.x_img[(long)b * a.img_bstride + hw];
+        float Nv[KSR_MAX_ORDER + 1], bv[KC];
+        const int m = basis_any<KORD>(xv, sm.knots, kn.M, Nv);
+        dense_basis<KC>(m, Nv, KORD, bv);
+        const float sl = ksr_silu(xv);
+
+        float dp[KH];
+#pragma unroll
+        for (int e = 0; e < KH; ++e) {
+            if (e < C::NH) {
+                const int ol = e / C::PER, gi = e % C::PER;
+                const float uw = us[2 * ol], S = us[2 * ol + 1];
+                dp[e] = gi < KC ? go[ol] * uw * bv[gi < KC ? gi : 0] : (gi == KC ? go[ol] * S : go[ol] * sl);
+            } else {
+                dp[e] = 0.f;
+            }
+        }
+        if (live) {
+            float4* gp4 = reinterpret_cast<float4*>(a.gparam + (n * 2 + h) * KH);
+#pragma unroll
+            for (int q = 0; q < KH / 4; ++q) gp4[q] = make_float4(dp[4 * q], dp[4 * q + 1], dp[4 * q + 2], dp[4 * q + 3]);
+        }
+        f32x16 acc[2];
+        ksr_wave_gemm<KH, 2>(sm.frag, nullptr, dp, acc, lane);
+        if (live) {
+            float df[32];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { df[i] = acc[0][i]; df[16 + i] = acc[1][i]; }
+            ksr_store32(a.gfeat + n * 64 + 32 * h, df);
+        }
+    }
+}
+
+template <int R, int KC, int KORD>
+int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
+    const long N = (long)a.B * a.H * a.W;
+    const long ntiles = (N + 127) / 128;
+    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
+    hipLaunchKernelGGL((feed_kan_bwd_kernel<R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
+    KSR_LAUNCH_CHECK("feed_kan_bwd");
+    return KSR_OK;
+}
+
 }  // namespace
 
 extern "C" int ksr_feed_kan_supported(int upscale, int n_coef, int spline_order) {
@@ -167,4 +262,30 @@ extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t i
     if (upscale == 2) return launch_feed_fwd<2, 8, 3>(a, kn, stream);
     if (n_coef == 8) return launch_feed_fwd<4, 8, 3>(a, kn, stream);
     return launch_feed_fwd<4, 19, 3>(a, kn, stream);
+}
+
+// Per-half padded length of the lane-ordered parameter gradient: gparam is [N, 2, this].
+extern "C" int ksr_feed_kan_lane_len(int upscale, int n_coef) {
+    const int nh = (upscale * upscale / 2) * (n_coef + 2);
+    return (nh + 15) / 16 * 16;
+}
+
+extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, const float* x_img,
+                                int64_t img_batch_stride, const float* feed_w, const float* save_us, float* gfeat,
+                                float* gparam, int B, int H, int W, int upscale, int n_coef, const float* knots,
+                                int n_knots, int spline_order, hipStream_t stream) {
+    KSR_CHECK_ARG(gout && x_img && feed_w && save_us && gfeat && gparam && knots, "feed_kan_bwd: null pointer");
+    KSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "feed_kan_bwd: non-positive dimension");
+    KSR_CHECK_ARG(n_knots == n_coef + spline_order + 1 && n_knots <= KSR_MAX_KNOTS, "feed_kan_bwd: bad knot count %d", n_knots);
+    KSR_UNSUPPORTED(!ksr_feed_kan_supported(upscale, n_coef, spline_order), "feed_kan_bwd: configuration has no fused kernel");
+    KSR_CHECK_ARG((reinterpret_cast<uintptr_t>(gout) & 15) == 0 && gout_batch_stride % 4 == 0, "feed_kan_bwd: gout must be 16-byte aligned");
+    FeedArgs a{};
+    a.gout = gout; a.out_bstride = gout_batch_stride; a.x_img = x_img; a.img_bstride = img_batch_stride;
+    a.w = feed_w; a.save_us = const_cast<float*>(save_us); a.gfeat = gfeat; a.gparam = gparam; a.B = B; a.H = H; a.W = W;
+    KsrKnots kn;
+    for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
+    kn.M = n_knots; kn.k = spline_order;
+    if (upscale == 2) return launch_feed_bwd<2, 8, 3>(a, kn, stream);
+    if (n_coef == 8) return launch_feed_bwd<4, 8, 3>(a, kn, stream);
+    return launch_feed_bwd<4, 19, 3>(a, kn, stream);
 }

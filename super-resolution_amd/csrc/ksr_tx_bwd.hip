@@ -1,0 +1,318 @@
+// Backward of the batch-axis transformer layer (see ksr_tx.hip for the forward and the lane layout).
+//
+//   tx_bwd_token_kernel : everything that is per token - [final LayerNorm] <- LayerNorm2 <- MLP <-
+//                         LayerNorm1 <- out-proj; writes the gradient tensors the parameter-gradient
+//                         reductions (ksr_wgrad / ksr_colreduce) consume, and d(ctx).
+//   tx_bwd_attn_kernel  : softmax-attention backward over the S images of a pixel: d(q|k|v).
+// The QKV projection's data gradient (+ residual) is ksr_in_proj_bwd (ksr_bwd.hip).
+#include "ksr_gemm.h"
+
+namespace {
+
+__device__ __forceinline__ float ksr_uniform(unsigned long long seed, unsigned stream, unsigned long long idx) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (idx * 8ULL + stream + 1ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+struct TxBwdTokArgs {
+    const float* dy;                          // [N,64] gradient of the layer output
+    const float *xhatf, *rstdf, *nf_w;        // final LayerNorm (optional: nf_w == null -> absent)
+    const float *xhat2, *rstd2, *n2_w;
+    const float* hmid;                        // [N,32] (after ReLU and dropout)
+    const float *xhat1, *rstd1, *n1_w;
+    const float *l2_w, *l1_w, *out_w;         // [64,32], [32,64], [64,64]
+    float *ds2, *dm, *dpre, *ds1, *du1, *da, *dctx;   // outputs (ds2 only with the final LayerNorm)
+    long N;
+    float p_drop;
+    unsigned long long seed;
+};
+
+struct __attribute__((aligned(16))) TxBwdTokSmem {
+    float f_l2t[1 * 32 * 64];      // 64 -> 32
+    float f_l1t[2 * 16 * 64];      // 32 -> 64
+    float f_outt[2 * 32 * 64];     // 64 -> 64
+    float ln[3][64];
+};
+
+__device__ __forceinline__ void ln_bwd(const float (&dy)[32], const float* __restrict__ gain, int h,
+                                       const float (&xhat)[32], float rstd, float (&dx)[32]) {
+    float dxh[32], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        dxh[i] = dy[i] * gain[32 * h + i];
+        s1 += dxh[i];
+        s2 += dxh[i] * xhat[i];
+    }
+    const float m1 = ksr_pair_sum(s1) * (1.f / 64.f), m2 = ksr_pair_sum(s2) * (1.f / 64.f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) dx[i] = rstd * (dxh[i] - m1 - xhat[i] * m2);
+}
+
+__global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
+    __shared__ TxBwdTokSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<32, 1, true>(sm.f_l2t, nullptr, a.l2_w, 32, nullptr, MapSplit{16}, MapHL{32}, tid, 256);
+    ksr_stage_weights<16, 2, true>(sm.f_l1t, nullptr, a.l1_w, 64, nullptr, MapHL{32}, MapSplit{16}, tid, 256);
+    ksr_stage_weights<32, 2, true>(sm.f_outt, nullptr, a.out_w, 64, nullptr, MapHL{32}, MapHL{32}, tid, 256);
+    if (tid < 64) {
+        sm.ln[0][tid] = a.nf_w ? a.nf_w[tid] : 1.f;
+        sm.ln[1][tid] = a.n2_w[tid];
+        sm.ln[2][tid] = a.n1_w[tid];
+    }
+    __syncthreads();
+    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+    const bool drop = a.p_drop > 0.f;
+    const long ntiles = (a.N + 127) / 128;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n0 = tile * 128 + wv * 32 + tok;
+        const bool live = n0 < a.N;
+        const long n = live ? n0 : 0;
+
+        float g[32], xh[32];
+        ksr_load32(a.dy + n * 64 + 32 * h, g);
+        if (a.nf_w) {
+            float t[32];
+            ksr_load32(a.xhatf + n * 64 + 32 * h, xh);
+            ln_bwd(g, sm.ln[0], h, xh, a.rstdf[n], t);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) g[i] = t[i];
+            if (live) ksr_store32(a.ds2 + n * 64 + 32 * h, g);
+        }
+        // LayerNorm 2
+        float du2[32];
+        ksr_load32(a.xhat2 + n * 64 + 32 * h, xh);
+        ln_bwd(g, sm.ln[1], h, xh, a.rstd2[n], du2);
+        // MLP
+        float dm[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            dm[i] = drop ? (ksr_uniform(a.seed, 3u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du2[i] * inv_keep : 0.f)
+                         : du2[i];
+        if (live) ksr_store32(a.dm + n * 64 + 32 * h, dm);
+        float dpre[16];
+        {
+            f32x16 acc[1];
+            ksr_wave_gemm<32, 1>(sm.f_l2t, nullptr, dm, acc, lane);
+            float hm[16];
+            ksr_load16(a.hmid + n * 32 + 16 * h, hm);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dpre[i] = hm[i] > 0.f ? (drop ? acc[0][i] * inv_keep : acc[0][i]) : 0.f;
+            if (live) ksr_store16(a.dpre + n * 32 + 16 * h, dpre);
+        }
+        float ds1[32];
+        {
+            f32x16 acc[2];
+            ksr_wave_gemm<16, 2>(sm.f_l1t, nullptr, dpre, acc, lane);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ds1[i] = du2[i] + acc[0][i]; ds1[16 + i] = du2[16 + i] + acc[1][i]; }
+            if (live) ksr_store32(a.ds1 + n * 64 + 32 * h, ds1);
+        }
+        // LayerNorm 1
+        float du1[32];
+        ksr_load32(a.xhat1 + n * 64 + 32 * h, xh);
+        ln_bwd(ds1, sm.ln[2], h, xh, a.rstd1[n], du1);
+        if (live) ksr_store32(a.du1 + n * 64 + 32 * h, du1);
+        float da[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            da[i] = drop ? (ksr_uniform(a.seed, 1u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du1[i] * inv_keep : 0.f)
+                         : du1[i];
+        if (live && drop) ksr_store32(a.da + n * 64 + 32 * h, da);
+        {
+            f32x16 acc[2];
+            ksr_wave_gemm<32, 2>(sm.f_outt, nullptr, da, acc, lane);
+            float dc[32];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dc[i] = acc[0][i]; dc[16 + i] = acc[1][i]; }
+            if (live) ksr_store32(a.dctx + n * 64 + 32 * h, dc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct TxBwdAttnArgs {
+    const float* qkv;    // [N,192] saved by the forward (q not scaled)
+    const float* ctx;    // [N,64]
+    const float* dctx;   // [N,64]
+    float* dqkv;         // [N,192]
+    int S, HW;
+    float p_drop;
+    unsigned long long seed;
+};
+
+constexpr int XLD = 140;     // floats per slot in the exchange buffer (2 x 68 + 4 pad)
+
+__global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
+    __shared__ __attribute__((aligned(16))) float xb[128 * XLD];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    const int S = a.S, HW = a.HW;
+    const int PPW = 128 / S;
+    const int ntiles = (HW + PPW - 1) / PPW;
+    const int slot = wv * 32 + tok;
+    const int b = slot / PPW, pl = slot - b * PPW;
+    const float scale = 0.17677669529663687f;
+    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+    const bool drop = a.p_drop > 0.f;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int p = tile * PPW + pl;
+        const bool live = (b < S) && (p < HW);
+        const long n = live ? ((long)b * HW + p) : 0;
+        float* mine = &xb[slot * XLD + 68 * h];
+
+        // ---- phase A: this lane is a QUERY.  exchange buffer holds k | v per (slot, head) ----
+        float q[32], dO[32];
+        float m = -INFINITY, l = 0.f, D = 0.f;
+        {
+            float kv[32];
+            ksr_load32(a.qkv + n * 192 + 64 + 32 * h, kv);
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(mine + 4 * c) = f32x4{kv[4 * c], kv[4 * c + 1], kv[4 * c + 2], kv[4 * c + 3]};
+            ksr_load32(a.qkv + n * 192 + 128 + 32 * h, kv);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(mine + 32 + 4 * c) = f32x4{kv[4 * c], kv[4 * c + 1], kv[4 * c + 2], kv[4 * c + 3]};
+            ksr_load32(a.qkv + n * 192 + 32 * h, q);
+            ksr_load32(a.dctx + n * 64 + 32 * h, dO);
+            float o[32];
+            ksr_load32(a.ctx + n * 64 + 32 * h, o);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { q[i] *= scale; D += dO[i] * o[i]; }
+        }
+        __syncthreads();
+        for (int j = 0; j < S; ++j) {
+            const float* kp = &xb[(j * PPW + pl) * XLD + 68 * h];
+            float sc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 kk = *reinterpret_cast<const f32x4*>(kp + 4 * c);
+                sc += q[4 * c] * kk[0] + q[4 * c + 1] * kk[1] + q[4 * c + 2] * kk[2] + q[4 * c + 3] * kk[3];
+            }
+            const float mn = fmaxf(m, sc);
+            l = l * expf(m - mn) + expf(sc - mn);
+            m = mn;
+        }
+        const float inv_l = 1.f / l;
+        float dq[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) dq[i] = 0.f;
+        for (int j = 0; j < S; ++j) {
+            const float* kp = &xb[(j * PPW + pl) * XLD + 68 * h];
+            float sc = 0.f, dp = 0.f;
+            f32x4 kk[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                kk[c] = *reinterpret_cast<const f32x4*>(kp + 4 * c);
+                const f32x4 vv = *reinterpret_cast<const f32x4*>(kp + 32 + 4 * c);
+                sc += q[4 * c] * kk[c][0] + q[4 * c + 1] * kk[c][1] + q[4 * c + 2] * kk[c][2] + q[4 * c + 3] * kk[c][3];
+                dp += dO[4 * c] * vv[0] + dO[4 * c + 1] * vv[1] + dO[4 * c + 2] * vv[2] + dO[4 * c + 3] * vv[3];
+            }
+            const float pj = expf(sc - m) * inv_l;
+            if (drop) {
+                const unsigned long long e = (((unsigned long long)n * 2 + h) << 8) + (unsigned)j;
+                dp = ksr_uniform(a.seed, 0u, e) < keep ? dp * inv_keep : 0.f;
+            }
+            const float dS = pj * (dp - D) * scale;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                dq[4 * c + 0] += dS * kk[c][0]; dq[4 * c + 1] += dS * kk[c][1];
+                dq[4 * c + 2] += dS * kk[c][2]; dq[4 * c + 3] += dS * kk[c][3];
+            }
+        }
+        if (live) ksr_store32(a.dqkv + n * 192 + 32 * h, dq);
+
+        // ---- phase B: this lane is a KEY.  exchange buffer holds q*scale | dO | m, 1/l, D ----
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            *reinterpret_cast<f32x4*>(mine + 4 * c) = f32x4{q[4 * c], q[4 * c + 1], q[4 * c + 2], q[4 * c + 3]};
+            *reinterpret_cast<f32x4*>(mine + 32 + 4 * c) = f32x4{dO[4 * c], dO[4 * c + 1], dO[4 * c + 2], dO[4 * c + 3]};
+        }
+        *reinterpret_cast<f32x4*>(mine + 64) = f32x4{m, inv_l, D, 0.f};
+        float kj[32], vj[32], dk[32], dv[32];
+        ksr_load32(a.qkv + n * 192 + 64 + 32 * h, kj);
+        ksr_load32(a.qkv + n * 192 + 128 + 32 * h, vj);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
+        __syncthreads();
+        for (int i = 0; i < S; ++i) {
+            const float* qp = &xb[(i * PPW + pl) * XLD + 68 * h];
+            float sc = 0.f, dp = 0.f;
+            f32x4 qq[8], dd[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                qq[c] = *reinterpret_cast<const f32x4*>(qp + 4 * c);
+                dd[c] = *reinterpret_cast<const f32x4*>(qp + 32 + 4 * c);
+                sc += qq[c][0] * kj[4 * c] + qq[c][1] * kj[4 * c + 1] + qq[c][2] * kj[4 * c + 2] + qq[c][3] * kj[4 * c + 3];
+                dp += dd[c][0] * vj[4 * c] + dd[c][1] * vj[4 * c + 1] + dd[c][2] * vj[4 * c + 2] + dd[c][3] * vj[4 * c + 3];
+            }
+            const f32x4 st = *reinterpret_cast<const f32x4*>(qp + 64);
+            const float pij = expf(sc - st[0]) * st[1];
+            float pt = pij;
+            if (drop) {
+                const long ni = (long)i * HW + p;          // global token index of query i
+                const unsigned long long e = (((unsigned long long)ni * 2 + h) << 8) + (unsigned)b;
+                const bool kept = ksr_uniform(a.seed, 0u, e) < keep;
+                pt = kept ? pij * inv_keep : 0.f;
+                dp = kept ? dp * inv_keep : 0.f;
+            }
+            const float dS = pij * (dp - st[2]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dk[4 * c + e] += dS * qq[c][e];
+                    dv[4 * c + e] += pt * dd[c][e];
+                }
+            }
+        }
+        if (live) {
+            ksr_store32(a.dqkv + n * 192 + 64 + 32 * h, dk);
+            ksr_store32(a.dqkv + n * 192 + 128 + 32 * h, dv);
+        }
+    }
+}
+
+}  // namespace
+
+// params[6]: norm_final.weight (or NULL), norm2.weight, norm1.weight, linear2.weight, linear1.weight,
+// out_proj.weight.  saved[7]: xhat_final, rstd_final, xhat2, rstd2, hmid, xhat1, rstd1.
+// outs[7]: ds2 (only with the final norm), dm, dpre [N,32], ds1, du1, da (only when p_drop > 0), dctx.
+extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const* params, const float* const* saved,
+                                            float* const* outs, int64_t N, float p_drop, uint64_t seed,
+                                            hipStream_t stream) {
+    KSR_CHECK_ARG(dy && params && saved && outs && N > 0, "batch_tx_layer_bwd_token: bad argument");
+    TxBwdTokArgs a{};
+    a.dy = dy;
+    a.nf_w = params[0]; a.n2_w = params[1]; a.n1_w = params[2]; a.l2_w = params[3]; a.l1_w = params[4]; a.out_w = params[5];
+    a.xhatf = saved[0]; a.rstdf = saved[1]; a.xhat2 = saved[2]; a.rstd2 = saved[3]; a.hmid = saved[4];
+    a.xhat1 = saved[5]; a.rstd1 = saved[6];
+    a.ds2 = outs[0]; a.dm = outs[1]; a.dpre = outs[2]; a.ds1 = outs[3]; a.du1 = outs[4]; a.da = outs[5]; a.dctx = outs[6];
+    for (int i = 1; i < 6; ++i) KSR_CHECK_ARG(params[i] != nullptr, "batch_tx_layer_bwd_token: params[%d] is null", i);
+    for (int i = 2; i < 7; ++i) KSR_CHECK_ARG(saved[i] != nullptr, "batch_tx_layer_bwd_token: saved[%d] is null", i);
+    KSR_CHECK_ARG(a.dm && a.dpre && a.ds1 && a.du1 && a.dctx, "batch_tx_layer_bwd_token: null output");
+    KSR_CHECK_ARG(!a.nf_w || (a.xhatf && a.rstdf && a.ds2), "batch_tx_layer_bwd_token: final norm needs xhat/rstd/ds2");
+    KSR_CHECK_ARG(!(p_drop > 0.f) || a.da, "batch_tx_layer_bwd_token: dropout needs the da output");
+    a.N = (long)N; a.p_drop = p_drop; a.seed = seed;
+    const long ntiles = (N + 127) / 128;
+    hipLaunchKernelGGL(tx_bwd_token_kernel, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token");
+    return KSR_OK;
+}
+
+extern "C" int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, const float* dctx, float* dqkv, int S,
+                                           int HW, float p_drop, uint64_t seed, hipStream_t stream) {
+    KSR_CHECK_ARG(qkv && ctx && dctx && dqkv && S > 0 && HW > 0, "batch_tx_layer_bwd_attn: bad argument");
+    KSR_UNSUPPORTED(S > 128, "batch_tx_layer_bwd_attn: local batch %d > 128 not supported", S);
+    TxBwdAttnArgs a{qkv, ctx, dctx, dqkv, S, HW, p_drop, seed};
+    const int PPW = 128 / S;
+    const int ntiles = (HW + PPW - 1) / PPW;
+    hipLaunchKernelGGL(tx_bwd_attn_kernel, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("batch_tx_layer_bwd_attn");
+    return KSR_OK;
+}

@@ -1,0 +1,350 @@
+// Parameter-gradient kernels: reductions over all N pixels.
+//
+//   wgrad      dW[j][k] = sum_n dZ[n][j] * A[n][k]  (+ db[j] = sum_n dZ[n][j])  on MFMA, pixels on the
+//              k axis of v_mfma_f32_32x32x2_f32 (2 pixels per instruction)
+//   colreduce  out[0][c] = sum_n a[n][c]*b[n][c], out[1][c] = sum_n a[n][c]       (LayerNorm gain/shift)
+//   dwgrad     depthwise 3x3 weight/bias gradient (stencil)
+//   stemgrad   the 12 scalars of the 1 -> 1 -> 1 front of the first FFN
+// Every kernel writes one partial result per workgroup into a slab; ksr_reduce sums the slabs in a
+// fixed order, so results are bitwise reproducible (no float atomics).
+#include "ksr_conv_common.h"
+
+namespace {
+
+constexpr int WG_MAXP = 6;     // output blocks per wave
+
+struct WgArgs {
+    const float* dz; int dz_ld, dz_c0, J;
+    const float* a1; int a1_ld, a1_c0, K;
+    const float* a2; int a2_ld, a2_c0;
+    float* slab;
+    long N;
+};
+
+__global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int col = lane & 31, kk = lane >> 5;
+    const int NJB = a.J / 32, NKB = a.K / 32;
+    const int kb = wv % NKB, jb0 = wv / NKB, jbs = 4 / NKB;
+    int np = 0;
+    for (int jb = jb0; jb < NJB; jb += jbs) ++np;
+
+    f32x16 acc[WG_MAXP];
+    float bsum[WG_MAXP];
+#pragma unroll
+    for (int p = 0; p < WG_MAXP; ++p) {
+        bsum[p] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[p][q] = 0.f;
+    }
+    const long per = (((a.N + gridDim.x - 1) / gridDim.x) + 15) / 16 * 16;
+    const long n0 = (long)blockIdx.x * per;
+    const long n1 = (n0 + per < a.N) ? n0 + per : a.N;
+
+    for (long t = n0; t < n1; t += 16) {
+        float bop[8], aop[WG_MAXP][8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long tokn = t + 2 * u + kk;
+            const bool ok = tokn < n1;
+            const long tn = ok ? tokn : n0;
+            float bv = a.a1[tn * a.a1_ld + a.a1_c0 + 32 * kb + col];
+            if (a.a2) bv *= a.a2[tn * a.a2_ld + a.a2_c0 + 32 * kb + col];
+            bop[u] = ok ? bv : 0.f;
+#pragma unroll
+            for (int p = 0; p < WG_MAXP; ++p) {
+                if (p < np) {
+                    const float av = a.dz[tn * a.dz_ld + a.dz_c0 + 32 * (jb0 + p * jbs) + col];
+                    aop[p][u] = ok ? av : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < WG_MAXP; ++p) {
+            if (p < np) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[p][u], bop[u], acc[p], 0, 0, 0);
+                    bsum[p] += aop[p][u];
+                }
+            }
+        }
+    }
+    float* slab = a.slab + (long)blockIdx.x * ((long)a.J * a.K + a.J);
+#pragma unroll
+    for (int p = 0; p < WG_MAXP; ++p) {
+        if (p < np) {
+            const int jb = jb0 + p * jbs;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * kk;
+                slab[(long)(32 * jb + row) * a.K + 32 * kb + col] = acc[p][q];
+            }
+            if (kb == 0) {
+                const float bs = ksr_pair_sum(bsum[p]);
+                if (kk == 0) slab[(long)a.J * a.K + 32 * jb + col] = bs;
+            }
+        }
+    }
+}
+
+// out[j*sj + k*sk] = sum_g slab[g][j*K + k];  bias[j] = sum_g slab[g][J*K + j].  With kan_O > 0 the rows
+// are in lane order (half, e) of the fused feed+KAN kernel and are scattered to the reference's
+// channel numbering (rows that are padding are dropped).
+struct RedArgs {
+    const float* slab; int G; int J, K; long stride;
+    float* out; int sj, sk;
+    float* bias;
+    int kan_O, kan_Kc, kan_nbh;   // nbh = per-half padded length (NB*16)
+};
+
+__global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = a.J * a.K + (a.bias ? a.J : 0);
+    if (idx >= total) return;
+    float s = 0.f;
+    for (int g = 0; g < a.G; ++g) s += a.slab[(long)g * a.stride + idx];
+    int j, k;
+    const bool is_bias = idx >= a.J * a.K;
+    if (is_bias) { j = idx - a.J * a.K; k = 0; }
+    else { j = idx / a.K; k = idx - j * a.K; }
+    if (a.kan_O > 0) {
+        const int h = j / a.kan_nbh, e = j - h * a.kan_nbh;
+        j = MapKan{a.kan_O, a.kan_Kc}(h, e);
+        if (j < 0) return;
+    }
+    if (is_bias) a.bias[j] = s;
+    else a.out[(long)j * a.sj + (long)k * a.sk] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct ColArgs {
+    const float* a; int a_ld, a_c0;                  // a [N, a_ld], 64 channels from a_c0
+    const float* b; int b_scalar;                    // b [N,64] or [N]
+    float* slab;                                     // [grid][2][64]
+    long N;
+};
+
+__global__ void __launch_bounds__(256) colreduce_kernel(ColArgs a) {
+    __shared__ float red[2][4][64];
+    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const long per = (a.N + gridDim.x - 1) / gridDim.x;
+    const long n0 = (long)blockIdx.x * per;
+    const long n1 = (n0 + per < a.N) ? n0 + per : a.N;
+    float sab = 0.f, sa = 0.f;
+    for (long n = n0 + rg; n < n1; n += 4) {
+        const float av = a.a[n * a.a_ld + a.a_c0 + c];
+        const float bv = a.b_scalar ? a.b[n] : a.b[n * 64 + c];
+        sab += av * bv;
+        sa += av;
+    }
+    red[0][rg][c] = sab;
+    red[1][rg][c] = sa;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int w = threadIdx.x >> 6;
+        a.slab[(long)blockIdx.x * 128 + w * 64 + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+struct DwgArgs {
+    const float* in; int in_ld, in_c0;     // conv input (NHWC)
+    const float* ds;                       // [N,64] gradient of the conv output
+    float* slab;                           // [grid][10][64]: 9 taps + bias
+    int B, H, W;
+};
+
+__global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
+    __shared__ __attribute__((aligned(16))) float halo[HALO_FLOATS];
+    __shared__ float red[10][4][64];
+    const int tid = threadIdx.x, c = tid & 63, row = tid >> 6;
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
+    const long ntiles = (long)a.B * tiles_y * tiles_x;
+    const long HW = (long)a.H * a.W;
+    float acc[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc[i] = 0.f;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const int b = (int)(tile / ((long)tiles_x * tiles_y));
+        const int y0 = ty * 4, x0 = tx * 32;
+        __syncthreads();
+        ksr_stage_halo(halo, a.in, a.in_ld, a.in_c0, b, y0, x0, a.H, a.W, tid);
+        __syncthreads();
+        const int y = y0 + row;
+        if (y < a.H) {
+            const int xmax = (a.W - x0) < 32 ? (a.W - x0) : 32;
+            for (int col = 0; col < xmax; ++col) {
+                const float d = a.ds[((long)b * HW + (long)y * a.W + x0 + col) * 64 + c];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx)
+                        acc[dy * 3 + dx] += d * halo[((row + dy) * HALO_W + (col + dx)) * HALO_LD + c];
+                acc[9] += d;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) red[i][row][c] = acc[i];
+    __syncthreads();
+    for (int i = tid; i < 640; i += 256) {
+        const int t = i >> 6, cc = i & 63;
+        a.slab[(long)blockIdx.x * 640 + i] = red[t][0][cc] + red[t][1][cc] + red[t][2][cc] + red[t][3][cc];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// First FFN front (pointwise1 1->1, depthwise 3x3 on one channel): u = w1*Y + b1 inside the image,
+// pre = bd + sum_tap wd[tap]*u(.+tap), v = relu(pre).  Given dpre [N]:
+//   slab[g][0..8] = sum dpre * u(.+tap); [9] = sum dpre; [10] = sum du*Y; [11] = sum du,
+//   du = sum_tap wd[tap] * dpre(.-tap).
+struct StemgArgs {
+    const float* x_img; long img_bstride;
+    const float* dpre;
+    const float* p1w; const float* p1b; const float* dww;
+    float* slab;    // [grid][12]
+    int B, H, W;
+};
+
+__global__ void __launch_bounds__(256) stemgrad_kernel(StemgArgs a) {
+    __shared__ float red[12][4];
+    const long HW = (long)a.H * a.W;
+    const long N = (long)a.B * HW;
+    const float w1 = a.p1w[0], b1 = a.p1b[0];
+    float acc[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) acc[i] = 0.f;
+    for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(n / HW);
+        const int hw = (int)(n % HW);
+        const int y = hw / a.W, x = hw % a.W;
+        const float* Y = a.x_img + (long)b * a.img_bstride;
+        const float* dp = a.dpre + (long)b * HW;
+        const float d = dp[hw];
+        float du = 0.f;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int tap = (dy + 1) * 3 + (dx + 1);
+                const int yy = y + dy, xx = x + dx;
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) acc[tap] += d * (w1 * Y[(long)yy * a.W + xx] + b1);
+                const int ys = y - dy, xs = x - dx;
+                if (ys >= 0 && ys < a.H && xs >= 0 && xs < a.W) du += a.dww[tap] * dp[(long)ys * a.W + xs];
+            }
+        acc[9] += d;
+        acc[10] += du * Y[hw];
+        acc[11] += du;
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        float v = acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[i][wv] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) a.slab[(long)blockIdx.x * 12 + threadIdx.x] =
+        red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+}
+
+// out[j][k] = r[j]*u[k] + c[j]*w[k]
+__global__ void __launch_bounds__(256) outer2_kernel(float* out, const float* r, const float* u, const float* c,
+                                                     const float* w, int J, int K) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= J * K) return;
+    const int j = idx / K, k = idx - j * K;
+    out[idx] = r[j] * u[k] + c[j] * w[k];
+}
+
+int launch_reduce(const float* slab, int G, int J, int K, long stride, float* out, int sj, int sk, float* bias,
+                  int kan_O, int kan_Kc, int kan_nbh, hipStream_t s) {
+    RedArgs r{slab, G, J, K, stride, out, sj, sk, bias, kan_O, kan_Kc, kan_nbh};
+    const int total = J * K + (bias ? J : 0);
+    hipLaunchKernelGGL(reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, r);
+    KSR_LAUNCH_CHECK("reduce");
+    return KSR_OK;
+}
+
+}  // namespace
+
+extern "C" int ksr_wgrad_slab_floats(int J, int K) { return 256 * (J * K + J); }
+
+// dW [J][K] (row-major, or scattered through the KAN channel map when kan_upscale > 0) and db [J].
+// slab: workspace of ksr_wgrad_slab_floats(J, K) floats.
+extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const float* a1, int a1_ld, int a1_c0, int K,
+                         const float* a2, int a2_ld, int a2_c0, int64_t N, float* slab, float* dW, float* db,
+                         int kan_upscale, int kan_n_coef, hipStream_t stream) {
+    KSR_CHECK_ARG(dz && a1 && slab && dW, "wgrad: null pointer");
+    KSR_CHECK_ARG(J > 0 && K > 0 && J % 32 == 0 && (K == 32 || K == 64), "wgrad: J must be a multiple of 32 and K 32 or 64");
+    KSR_CHECK_ARG(N > 0, "wgrad: N must be positive");
+    const int NKB = K / 32, per_wave = (J / 32 + (4 / NKB) - 1) / (4 / NKB);
+    KSR_UNSUPPORTED(per_wave > WG_MAXP, "wgrad: J=%d too large", J);
+    WgArgs a{dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, a2, a2_ld, a2_c0, slab, (long)N};
+    long g = (N + 511) / 512;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("wgrad");
+    int kan_O = 0, kan_nbh = 0;
+    if (kan_upscale > 0) {
+        kan_O = kan_upscale * kan_upscale;
+        kan_nbh = J / 2;
+    }
+    return launch_reduce(slab, (int)g, J, K, (long)J * K + J, dW, K, 1, db, kan_O, kan_n_coef, kan_nbh, stream);
+}
+
+// out[0][c] = sum_n a[n][c]*b, out[1][c] = sum_n a[n][c] for 64 channels c; rows out_row_stride apart.
+// slab: 256*128 floats.
+extern "C" int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b, int b_is_per_pixel_scalar, int64_t N,
+                             float* slab, float* out, int out_row_stride, hipStream_t stream) {
+    KSR_CHECK_ARG(a && b && slab && out && N > 0 && a_ld >= 64 && out_row_stride >= 64, "colreduce: bad argument");
+    ColArgs c{a, a_ld, a_c0, b, b_is_per_pixel_scalar, slab, (long)N};
+    long g = (N + 255) / 256;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, c);
+    KSR_LAUNCH_CHECK("colreduce");
+    return launch_reduce(slab, (int)g, 2, 64, 128, out, out_row_stride, 1, nullptr, 0, 0, 0, stream);
+}
+
+// Depthwise 3x3 (64 channels) parameter gradients: dW [64][1][3][3], db [64]. slab: 256*640 floats.
+extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, float* slab, float* dW,
+                                float* db, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(in && ds && slab && dW && db && B > 0 && H > 0 && W > 0, "dwconv_wgrad: bad argument");
+    DwgArgs d{in, in_ld, in_c0, ds, slab, B, H, W};
+    long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
+    const long g = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)g), dim3(256), 0, stream, d);
+    KSR_LAUNCH_CHECK("dwconv_wgrad");
+    // slab rows: tap t (J = 9) x channel (K = 64) then the bias row handled as a 10th row via two calls
+    if (int rc = launch_reduce(slab, (int)g, 9, 64, 640, dW, 1, 9, nullptr, 0, 0, 0, stream)) return rc;
+    return launch_reduce(slab + 576, (int)g, 1, 64, 640, db, 64, 1, nullptr, 0, 0, 0, stream);
+}
+
+// Gradients of the first FFN's scalar front.  out [12]: depthwise taps (9), depthwise bias, pointwise1
+// weight, pointwise1 bias.  slab: 256*12 floats.
+extern "C" int ksr_stem_scalar_wgrad(const float* x_img, int64_t img_batch_stride, const float* dpre,
+                                     const float* pw1_w, const float* pw1_b, const float* dw_w, float* slab,
+                                     float* out12, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(x_img && dpre && pw1_w && pw1_b && dw_w && slab && out12 && B > 0 && H > 0 && W > 0,
+                  "stem_scalar_wgrad: bad argument");
+    StemgArgs s{x_img, (long)img_batch_stride, dpre, pw1_w, pw1_b, dw_w, slab, B, H, W};
+    const long N = (long)B * H * W;
+    long g = (N + 255) / 256;
+    if (g > 256) g = 256;
+    hipLaunchKernelGGL(stemgrad_kernel, dim3((unsigned)g), dim3(256), 0, stream, s);
+    KSR_LAUNCH_CHECK("stem_scalar_wgrad");
+    return launch_reduce(slab, (int)g, 1, 12, 12, out12, 12, 1, nullptr, 0, 0, 0, stream);
+}
+
+// dW[j][k] = r[j]*u[k] + c[j]*w[k]: weight gradient of a 1x1 conv whose input is an affine function
+// u[k]*s + w[k] of one scalar s per pixel (r = sum_n dz*s, c = sum_n dz).
+extern "C" int ksr_outer2(float* out, const float* r, const float* u, const float* c, const float* w, int J, int K,
+                          hipStream_t stream) {
+    KSR_CHECK_ARG(out && r && u && c && w && J > 0 && K > 0, "outer2: bad argument");
+    hipLaunchKernelGGL(outer2_kernel, dim3((J * K + 255) / 256), dim3(256), 0, stream, out, r, u, c, w, J, K);
+    KSR_LAUNCH_CHECK("outer2");
+    return KSR_OK;
+}

@@ -36,7 +36,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_mean", "_reduce")):
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_mean", "colreduce", "_token", "_attn")):
             return fn
 
         def timed(*args):
@@ -79,6 +79,9 @@ EXPORTS = [
     "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",
     "ksr_stem_fwd", "ksr_pointwise_fwd", "ksr_dwrelu_pw_fwd", "ksr_gate_pw_fwd",
     "ksr_batch_tx_layer_fwd", "ksr_feed_kan_supported", "ksr_feed_kan_fwd",
+    "ksr_feed_kan_lane_len", "ksr_feed_kan_bwd", "ksr_batch_tx_layer_bwd_token", "ksr_batch_tx_layer_bwd_attn",
+    "ksr_in_proj_bwd", "ksr_gate_pw_bwd", "ksr_fn1_bwd", "ksr_pw2_bwd", "ksr_pw1_bwd",
+    "ksr_wgrad_slab_floats", "ksr_wgrad", "ksr_colreduce", "ksr_dwconv_wgrad", "ksr_stem_scalar_wgrad", "ksr_outer2",
 ]
 
 

@@ -1,0 +1,257 @@
+"""Training path: one torch.autograd.Function whose forward and backward are sequences of libksr
+kernels.  PyTorch only carries the tape node and owns the buffers."""
+from __future__ import annotations
+
+from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
+from typing import Dict, List
+
+import torch
+
+from . import engine
+from ._lib import KsrError, check, lib, ptr, stream
+from .engine import Geometry, TX_PARAM_NAMES, _dims, _ptr_array
+from .ops import bilinear_up_into
+
+# order in which the encoder's parameters enter (and their gradients leave) the autograd node
+PARAM_ORDER = (
+    ["ffn1.pointwise1.weight", "ffn1.pointwise1.bias", "ffn1.depthwise.weight", "ffn1.depthwise.bias",
+     "ffn1.pointwise2.weight", "ffn1.pointwise2.bias"]
+    + [f"{g}.{n}" for g in ("ffn2",) for n in ("fn_1.0.weight", "fn_1.0.bias", "fn_2.weight", "fn_2.bias",
+                                              "gate.weight", "gate.bias")]
+    + ["ffn3.pointwise1.weight", "ffn3.pointwise1.bias", "ffn3.depthwise.weight", "ffn3.depthwise.bias",
+       "ffn3.pointwise2.weight", "ffn3.pointwise2.bias"]
+    + [f"ffn4.{n}" for n in ("fn_1.0.weight", "fn_1.0.bias", "fn_2.weight", "fn_2.bias", "gate.weight", "gate.bias")]
+    + [f"encoder.layers.{l}.{n}" for l in range(2) for n in TX_PARAM_NAMES]
+    + ["encoder.norm.weight", "encoder.norm.bias", "feed.weight", "feed.bias"]
+)
+
+
+class _Ws:
+    """Scratch allocator for one backward pass."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self._slab = None
+
+    def new(self, *shape):
+        return torch.empty(*shape, device=self.dev, dtype=torch.float32)
+
+    def slab(self, nfloats):
+        if self._slab is None or self._slab.numel() < nfloats:
+            self._slab = torch.empty(max(nfloats, 256 * (192 * 64 + 192)), device=self.dev, dtype=torch.float32)
+        return self._slab
+
+
+def _wgrad(ws: _Ws, dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, N, dW, db, a2=None, a2_ld=0, a2_c0=0, kan=(0, 0)):
+    L = lib()
+    slab = ws.slab(int(L.ksr_wgrad_slab_floats(c_int(J), c_int(K))))
+    check(L.ksr_wgrad(ptr(dz), c_int(dz_ld), c_int(dz_c0), c_int(J), ptr(a1), c_int(a1_ld), c_int(a1_c0), c_int(K),
+                      ptr(a2), c_int(a2_ld), c_int(a2_c0), c_int64(N), ptr(slab), ptr(dW), ptr(db),
+                      c_int(kan[0]), c_int(kan[1]), stream()), "ksr_wgrad")
+
+
+def _colreduce(ws: _Ws, a, a_ld, a_c0, b, b_scalar, N, out=None, out_c0=0):
+    """out[0, out_c0 + c] = sum_n a[n, a_c0 + c] * b[n(, c)];  out[1, out_c0 + c] = sum_n a[n, a_c0 + c]."""
+    if out is None:
+        out = ws.new(2, 64)
+    slab = ws.slab(256 * 128)
+    check(lib().ksr_colreduce(ptr(a), c_int(a_ld), c_int(a_c0), ptr(b), c_int(int(b_scalar)), c_int64(N), ptr(slab),
+                              c_void_p(out.data_ptr() + 4 * out_c0), c_int(out.shape[1]), stream()), "ksr_colreduce")
+    return out
+
+
+def _dwconv_wgrad(ws: _Ws, inp, in_ld, in_c0, ds, g: Geometry):
+    dW = ws.new(64, 1, 3, 3)
+    db = ws.new(64)
+    slab = ws.slab(256 * 640)
+    check(lib().ksr_dwconv_wgrad(ptr(inp), c_int(in_ld), c_int(in_c0), ptr(ds), ptr(slab), ptr(dW), ptr(db),
+                                 *_dims(g), stream()), "ksr_dwconv_wgrad")
+    return dW, db
+
+
+def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, seed, grads, y_in_sigmoid):
+    """Backward of transformer layer li.  dy: gradient of its output [N,64].  Returns the gradient of
+    its input (times sigmoid' of that input when y_in_sigmoid is given)."""
+    L = lib()
+    N = g.N
+    q = f"{pre}encoder.layers.{li}."
+    last = li == 1
+    nf_w = p[pre + "encoder.norm.weight"] if last else None
+    params = [nf_w, p[q + "norm2.weight"], p[q + "norm1.weight"], p[q + "linear2.weight"], p[q + "linear1.weight"],
+              p[q + "self_attn.out_proj.weight"]]
+    saved = [sv["xhatf"], sv["rstdf"], sv["xhat2"], sv["rstd2"], sv["hmid"], sv["xhat1"], sv["rstd1"]]
+    ds2 = ws.new(N, 64) if last else None
+    dm, dpre, ds1, du1, dctx = ws.new(N, 64), ws.new(N, 32), ws.new(N, 64), ws.new(N, 64), ws.new(N, 64)
+    da = ws.new(N, 64) if p_drop > 0 else None
+    lseed = (seed * 4 + li) & 0xFFFFFFFFFFFFFFFF
+    check(L.ksr_batch_tx_layer_bwd_token(ptr(dy), _ptr_array(params), _ptr_array(saved),
+                                         _ptr_array([ds2, dm, dpre, ds1, du1, da, dctx]), c_int64(N),
+                                         c_float(p_drop), c_uint64(lseed), stream()), "ksr_batch_tx_layer_bwd_token")
+    if da is None:
+        da = du1
+    # LayerNorm gains / shifts
+    if last:
+        r = _colreduce(ws, dy, 64, 0, sv["xhatf"], False, N)
+        grads[pre + "encoder.norm.weight"], grads[pre + "encoder.norm.bias"] = r[0], r[1]
+        r = _colreduce(ws, ds2, 64, 0, sv["xhat2"], False, N)
+    else:
+        r = _colreduce(ws, dy, 64, 0, sv["xhat2"], False, N)
+    grads[q + "norm2.weight"], grads[q + "norm2.bias"] = r[0], r[1]
+    r = _colreduce(ws, ds1, 64, 0, sv["xhat1"], False, N)
+    grads[q + "norm1.weight"], grads[q + "norm1.bias"] = r[0], r[1]
+    # linear2 / linear1 / out_proj weights
+    gw, gb = ws.new(64, 32), ws.new(64)
+    _wgrad(ws, dm, 64, 0, 64, sv["hmid"], 32, 0, 32, N, gw, gb)
+    grads[q + "linear2.weight"], grads[q + "linear2.bias"] = gw, gb
+    gw, gb = ws.new(32, 64), ws.new(32)
+    _wgrad(ws, dpre, 32, 0, 32, sv["s1"], 64, 0, 64, N, gw, gb)
+    grads[q + "linear1.weight"], grads[q + "linear1.bias"] = gw, gb
+    gw, gb = ws.new(64, 64), ws.new(64)
+    _wgrad(ws, da, 64, 0, 64, sv["ctx"], 64, 0, 64, N, gw, gb)
+    grads[q + "self_attn.out_proj.weight"], grads[q + "self_attn.out_proj.bias"] = gw, gb
+    # attention
+    dqkv = ws.new(N, 192)
+    check(L.ksr_batch_tx_layer_bwd_attn(ptr(sv["qkv"]), ptr(sv["ctx"]), ptr(dctx), ptr(dqkv), c_int(g.B),
+                                        c_int(g.H * g.W), c_float(p_drop), c_uint64(lseed), stream()),
+          "ksr_batch_tx_layer_bwd_attn")
+    gw, gb = ws.new(192, 64), ws.new(192)
+    _wgrad(ws, dqkv, 192, 0, 192, sv["in"], 64, 0, 64, N, gw, gb)
+    grads[q + "self_attn.in_proj_weight"], grads[q + "self_attn.in_proj_bias"] = gw, gb
+    dsin = ws.new(N, 64)
+    check(L.ksr_in_proj_bwd(ptr(dqkv), ptr(p[q + "self_attn.in_proj_weight"]), ptr(du1), ptr(y_in_sigmoid), ptr(dsin),
+                            *_dims(g), stream()), "ksr_in_proj_bwd")
+    return dsin
+
+
+def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, grads, x_in, stem_saves=None, x_img=None):
+    """GatedFFN backward.  dz: gradient of fn_2's output (sigmoid' already applied) [N,64]; t = relu(fn_1(x_in))
+    [N,128].  Returns the gradient of the block input x_in [N,64]."""
+    L = lib()
+    N = g.N
+    q = pre + name + "."
+    dt = ws.new(N, 128)
+    dgate = ws.new(N, 64)
+    check(L.ksr_gate_pw_bwd(ptr(dz), ptr(p[q + "fn_2.weight"]), ptr(gate_saved), ptr(t), ptr(dt), ptr(dgate),
+                            *_dims(g), stream()), "ksr_gate_pw_bwd")
+    gw, gb = ws.new(64, 64, 1, 1), ws.new(64)
+    _wgrad(ws, dz, 64, 0, 64, t, 128, 0, 64, N, gw, gb, a2=gate_saved, a2_ld=64, a2_c0=0)
+    grads[q + "fn_2.weight"], grads[q + "fn_2.bias"] = gw, gb
+    grads[q + "gate.weight"], grads[q + "gate.bias"] = _dwconv_wgrad(ws, t, 128, 64, dgate, g)
+    dx = ws.new(N, 64)
+    if stem_saves is None:
+        check(L.ksr_fn1_bwd(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(t), ptr(p[q + "fn_1.0.weight"]), ptr(dx),
+                            c_int(0), ptr(None), ptr(None), ptr(None), *_dims(g), stream()), "ksr_fn1_bwd")
+        gw, gb = ws.new(128, 64, 1, 1), ws.new(128)
+        _wgrad(ws, dt, 128, 0, 128, x_in, 64, 0, 64, N, gw, gb)
+        grads[q + "fn_1.0.weight"], grads[q + "fn_1.0.bias"] = gw, gb
+        return dx
+    # the block input is the first FFN: x1[n, k] = pw2_w[k] * v[n] + pw2_b[k]
+    v = stem_saves
+    f = pre + "ffn1."
+    dpre = ws.new(N)
+    check(L.ksr_fn1_bwd(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(t), ptr(p[q + "fn_1.0.weight"]), ptr(dx),
+                        c_int(1), ptr(v), ptr(p[f + "pointwise2.weight"]), ptr(dpre), *_dims(g), stream()), "ksr_fn1_bwd")
+    rc = ws.new(2, 128)
+    _colreduce(ws, dt, 128, 0, v, True, N, rc, 0)
+    _colreduce(ws, dt, 128, 64, v, True, N, rc, 64)
+    r, c = rc[0], rc[1]
+    gw = ws.new(128, 64, 1, 1)
+    check(L.ksr_outer2(ptr(gw), ptr(r), ptr(p[f + "pointwise2.weight"]), ptr(c), ptr(p[f + "pointwise2.bias"]),
+                       c_int(128), c_int(64), stream()), "ksr_outer2")
+    grads[q + "fn_1.0.weight"], grads[q + "fn_1.0.bias"] = gw, c
+    r2 = _colreduce(ws, dx, 64, 0, v, True, N)
+    grads[f + "pointwise2.weight"], grads[f + "pointwise2.bias"] = r2[0].reshape(64, 1, 1, 1), r2[1]
+    out12 = ws.new(12)
+    slab = ws.slab(256 * 12)
+    check(L.ksr_stem_scalar_wgrad(ptr(x_img), c_int64(3 * g.H * g.W), ptr(dpre), ptr(p[f + "pointwise1.weight"]),
+                                  ptr(p[f + "pointwise1.bias"]), ptr(p[f + "depthwise.weight"]), ptr(slab), ptr(out12),
+                                  *_dims(g), stream()), "ksr_stem_scalar_wgrad")
+    grads[f + "depthwise.weight"] = out12[0:9].reshape(1, 1, 3, 3)
+    grads[f + "depthwise.bias"] = out12[9:10]
+    grads[f + "pointwise1.weight"] = out12[10:11].reshape(1, 1, 1, 1)
+    grads[f + "pointwise1.bias"] = out12[11:12]
+    return None
+
+
+def backward_all(gout: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Geometry, sv: dict,
+                 save_us: torch.Tensor, p_drop: float, seed: int) -> Dict[str, torch.Tensor]:
+    L = lib()
+    N = g.N
+    ws = _Ws(x.device)
+    grads: Dict[str, torch.Tensor] = {}
+    # ---- feed + KAN ----
+    lane_len = int(L.ksr_feed_kan_lane_len(c_int(g.r), c_int(g.n_coef)))
+    gfeat = ws.new(N, 64)
+    gparam = ws.new(N, 2 * lane_len)
+    check(L.ksr_feed_kan_bwd(ptr(gout), c_int64(gout.shape[1] * gout.shape[2] * gout.shape[3]), ptr(x),
+                             c_int64(3 * g.H * g.W), ptr(p[pre + "feed.weight"]), ptr(save_us), ptr(gfeat), ptr(gparam),
+                             *_dims(g), c_int(g.r), c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k),
+                             stream()), "ksr_feed_kan_bwd")
+    P = g.r * g.r * (g.n_coef + 2)
+    gw, gb = ws.new(P, 64, 1, 1), ws.new(P)
+    _wgrad(ws, gparam, 2 * lane_len, 0, 2 * lane_len, sv["feat"], 64, 0, 64, N, gw, gb, kan=(g.r, g.n_coef))
+    grads[pre + "feed.weight"], grads[pre + "feed.bias"] = gw, gb
+    # ---- transformer layers ----
+    d = _tx_layer_backward(ws, gfeat, 1, p, pre, g, sv["tx1"], p_drop, seed, grads, None)
+    dz6 = _tx_layer_backward(ws, d, 0, p, pre, g, sv["tx0"], p_drop, seed, grads, sv["x6"])
+    # ---- ffn4 (gated) ----
+    dx4 = _gated_backward(ws, dz6, "ffn4", p, pre, g, sv["t5"], sv["g6"], grads, sv["x4"])
+    # ---- ffn3 ----
+    q = pre + "ffn3."
+    ds4 = ws.new(N, 64)
+    check(L.ksr_pw2_bwd(ptr(dx4), ptr(p[q + "pointwise2.weight"]), ptr(sv["a4"]), ptr(ds4), *_dims(g), stream()),
+          "ksr_pw2_bwd")
+    gw, gb = ws.new(64, 64, 1, 1), ws.new(64)
+    _wgrad(ws, dx4, 64, 0, 64, sv["a4"], 64, 0, 64, N, gw, gb)
+    grads[q + "pointwise2.weight"], grads[q + "pointwise2.bias"] = gw, gb
+    grads[q + "depthwise.weight"], grads[q + "depthwise.bias"] = _dwconv_wgrad(ws, sv["t3"], 64, 0, ds4, g)
+    dt3, dz2 = ws.new(N, 64), ws.new(N, 64)
+    check(L.ksr_pw1_bwd(ptr(ds4), ptr(p[q + "depthwise.weight"]), ptr(p[q + "pointwise1.weight"]), ptr(sv["x3"]),
+                        ptr(dt3), ptr(dz2), *_dims(g), stream()), "ksr_pw1_bwd")
+    gw, gb = ws.new(64, 64, 1, 1), ws.new(64)
+    _wgrad(ws, dt3, 64, 0, 64, sv["x3"], 64, 0, 64, N, gw, gb)
+    grads[q + "pointwise1.weight"], grads[q + "pointwise1.bias"] = gw, gb
+    # ---- ffn2 (gated) + ffn1 ----
+    _gated_backward(ws, dz2, "ffn2", p, pre, g, sv["t2"], sv["g2"], grads, None, stem_saves=sv["v"], x_img=x)
+    return grads
+
+
+class _ConvSepKanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pre, g, p_drop, seed, names, *params):
+        p = dict(zip(names, params))
+        out = torch.empty(g.B, 3, g.H * g.r, g.W * g.r, device=x.device, dtype=torch.float32)
+        bilinear_up_into(x, out, g.r, 1, 2, 1)
+        sv: dict = {}
+        feat = engine.encoder_forward(x, p, pre, g, sv, p_drop, seed)
+        save_us = torch.empty(g.N, g.r * g.r, 2, device=x.device, dtype=torch.float32)
+        engine.feed_kan_forward(feat, x, p, pre, g, out, save_us)
+        ctx.sv, ctx.save_us, ctx.x, ctx.p = sv, save_us, x, p
+        ctx.cfg = (pre, g, p_drop, seed, names)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        pre, g, p_drop, seed, names = ctx.cfg
+        if ctx.needs_input_grad[0]:
+            raise KsrError("gradient with respect to the input image is not implemented (the training step "
+                           "of the reference never needs it)")
+        gout = gout.contiguous()
+        grads = backward_all(gout, ctx.x, ctx.p, pre, g, ctx.sv, ctx.save_us, p_drop, seed)
+        ctx.sv = ctx.save_us = None
+        out = []
+        for n, t in zip(names, ctx.p.values()):
+            gr = grads.get(n)
+            out.append(None if gr is None else gr.reshape(t.shape))
+        return (None, None, None, None, None, None, *out)
+
+
+def conv_sep_kan_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_drop: float, seed: int):
+    names = [pre + n for n in PARAM_ORDER]
+    li_prefix = pre[: -len("encoder.encoder.")]
+    # p is keyed "layers.L.encoder.encoder.<name>"
+    params = [p[n] for n in names]
+    for t in params:
+        if not t.is_contiguous():
+            raise KsrError("parameters must be contiguous")
+    return _ConvSepKanFn.apply(x, pre, g, p_drop, seed, names, *params)

@@ -134,3 +134,90 @@ def test_default_init_matches_reference_rng_order():
         if "norm" in n:
             continue
         assert torch.equal(v, t(g["p." + n])), n
+
+
+def _load_model_golden(r, G, k):
+    from kan_sr.module import ConvSepKan
+    g = load_golden(f"model_r{r}_G{G}_k{k}")
+    m = ConvSepKan([1], [r * r], [3], G, k, 0.1, [-1, 1], r)
+    m.load_state_dict({n[2:]: t(v) for n, v in g.items() if n.startswith("p.")})
+    return g, m.cuda().eval()
+
+
+@pytest.mark.parametrize("r,G,k", [(2, 5, 3), (4, 5, 3), (4, 16, 3)])
+def test_full_model_gradients_golden(r, G, k):
+    """All 52 parameter gradients of the eval-mode graph against the reference's autograd (fp32 goldens),
+    and against the reference's fp64 run: err(build, fp64) <= 2*err(ref fp32, fp64) + 1e-6."""
+    g, m = _load_model_golden(r, G, k)
+    y = m(t(g["x"]).cuda())
+    assert_fwd(y, t(g["y"]), atol=2e-5)
+    y.backward(t(g["gy"]).cuda())
+    worst = 0.0
+    for n, prm in m.named_parameters():
+        ref, ref64 = t(g["g." + n]), t(g["g64." + n])
+        got = prm.grad.cpu()
+        rel = rel_l2(got, ref)
+        worst = max(worst, rel)
+        assert rel <= GRAD_REL, f"{n}: rel-L2 {rel:.3e}"
+        e_me = float((got.double() - ref64).norm())
+        e_ref = float((ref.double() - ref64).norm())
+        assert e_me <= 2 * e_ref + 1e-6 * float(ref64.norm()) + 1e-9, f"{n}: {e_me:.3e} vs ref {e_ref:.3e}"
+
+
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_gazetr_golden_gradients(B):
+    """GazeTR golden (P=40): parameter gradients for cotangent gy on the `gaze` tensor, obtained here by
+    pushing gy through the oracle's KAN cell ... not needed: compare via the full chain instead."""
+    from kan_sr.module import ConvSepKan
+    g = load_golden("gazetr")
+    pre = "layers.0.encoder.encoder."
+    m = ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2)
+    m.load_state_dict({pre + k[2:]: t(v) for k, v in g.items() if k.startswith("p.")})
+    x1 = t(g[f"B{B}.x"])
+    x = torch.cat([x1, torch.zeros(B, 2, 8, 8)], 1).contiguous()
+    # oracle chain on CPU with the same parameters (the oracle is pinned on this golden separately)
+    p = {n: v.detach().clone().requires_grad_() for n, v in m.state_dict().items()}
+    yr = orc.conv_sep_kan_forward(x, p, out_channels=[4], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=2)
+    gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(B))
+    (yr * gy).sum().backward()
+    m = m.cuda().eval()
+    y = m(x.cuda())
+    assert_fwd(y, yr, atol=2e-5)
+    y.backward(gy.cuda())
+    for n, prm in m.named_parameters():
+        rel = rel_l2(prm.grad.cpu(), p[n].grad)
+        assert rel <= GRAD_REL, f"{n}: rel-L2 {rel:.3e}"
+
+
+def test_gradients_odd_sizes_vs_oracle():
+    """Ragged tiles: H, W not multiples of the 4x32 tile, batch not a power of two."""
+    from kan_sr.module import ConvSepKan
+    torch.manual_seed(11)
+    B, H, W, r = 3, 13, 45, 4
+    p0 = orc.random_params(16, 5, 3, seed=21)
+    m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], r)
+    m.load_state_dict(p0)
+    x = torch.rand(B, 3, H, W)
+    p = {n: v.clone().requires_grad_() for n, v in p0.items()}
+    yr = orc.conv_sep_kan_forward(x, p, out_channels=[16], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=r)
+    gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(5))
+    (yr * gy).sum().backward()
+    m = m.cuda().eval()
+    y = m(x.cuda())
+    assert_fwd(y, yr, atol=2e-5)
+    y.backward(gy.cuda())
+    for n, prm in m.named_parameters():
+        rel = rel_l2(prm.grad.cpu(), p[n].grad)
+        assert rel <= GRAD_REL, f"{n}: rel-L2 {rel:.3e}"
+
+
+def test_backward_is_bitwise_reproducible():
+    g, m = _load_model_golden(4, 5, 3)
+    x, gy = t(g["x"]).cuda(), t(g["gy"]).cuda()
+    runs = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        m(x).backward(gy)
+        runs.append({n: prm.grad.clone() for n, prm in m.named_parameters()})
+    for n in runs[0]:
+        assert torch.equal(runs[0][n], runs[1][n]), n
