@@ -112,6 +112,117 @@ int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t img_batch_st
                      int W, int upscale, int n_coef, const float* knots, int n_knots, int spline_order,
                      ksr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Backward.  The reference has no hand-written backward: these replace what autograd derives from the
+ * forward lines cited above.  "saved" tensors are the optional outputs of the forward entry points.
+ */
+
+/* Backward of ksr_feed_kan_fwd.  gout: gradient of the Y plane of the output (pixel-shuffled layout,
+ * gout_batch_stride elements between images).  Writes gfeat [N,64] and gparam [N, 2, L] = gradient of
+ * the feed output in the kernel's lane order, L = ksr_feed_kan_lane_len(); feed.weight/bias gradients
+ * follow from ksr_wgrad(gparam, feat, ..., kan_upscale, kan_n_coef). */
+int ksr_feed_kan_lane_len(int upscale, int n_coef);
+int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, const float* x_img, int64_t img_batch_stride,
+                     const float* feed_w, const float* save_us, float* gfeat, float* gparam, int B, int H, int W,
+                     int upscale, int n_coef, const float* knots, int n_knots, int spline_order,
+                     ksr_stream_t stream);
+
+/* Backward of ksr_batch_tx_layer_fwd, per-token part: [final norm] <- norm2 <- linear2/ReLU/linear1 <-
+ * norm1 <- out_proj.  params[6]: final norm.weight (or NULL), norm2.weight, norm1.weight, linear2.weight,
+ * linear1.weight, out_proj.weight.  saved[7]: xhat_final, rstd_final, xhat2, rstd2, hmid, xhat1, rstd1.
+ * outs[7]: ds2 [N,64] (gradient of norm2's output; only with the final norm), dm [N,64] (of linear2's
+ * output), dpre [N,32] (of linear1's output), ds1 [N,64] (of norm1's output), du1 [N,64] (of norm1's
+ * input), da [N,64] (of out_proj's output; only when p_drop > 0, else it equals du1), dctx [N,64]. */
+int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const* params, const float* const* saved,
+                                 float* const* outs, int64_t N, float p_drop, uint64_t seed, ksr_stream_t stream);
+
+/* Attention backward over the S images of each pixel: qkv [N,192], ctx [N,64] (saved), dctx -> dqkv [N,192]. */
+int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, const float* dctx, float* dqkv, int S, int HW,
+                                float p_drop, uint64_t seed, ksr_stream_t stream);
+
+/* ds = resid + dqkv * in_proj_weight; with y_saved != NULL also times y(1-y) (the sigmoid that produced
+ * the first transformer layer's input, gazetr.py:107). */
+int ksr_in_proj_bwd(const float* dqkv, const float* in_w, const float* resid, const float* y_saved, float* ds, int B,
+                    int H, int W, ksr_stream_t stream);
+
+/* GatedFFN tail backward (backward of ksr_gate_pw_fwd without its sigmoid, which the producer of dz has
+ * already applied): dA = dz * fn_2.weight; dt_value = dA * gate * (t[:, :64] > 0) written to channels 0..63
+ * of dt [N,128]; dgate [N,64] = dA * t[:, :64]. */
+int ksr_gate_pw_bwd(const float* dz, const float* fn2_w, const float* gate_saved, const float* t_saved,
+                    float* dt_value, float* dgate, int B, int H, int W, ksr_stream_t stream);
+
+/* fn_1 (1x1 conv 64 -> 128 + ReLU) backward.  Completes dt[:, 64:128] = convT3x3(dgate) * (t[:, 64:] > 0),
+ * then dx [N,64] = dt * fn_1.weight.  stem = 1: the conv's input was ffn1 (ksr_stem_fwd); additionally
+ * dpre [N] = (sum_c dx[c] * pointwise2.weight[c]) * (v > 0), the gradient at ffn1's depthwise output. */
+int ksr_fn1_bwd(float* dt, const float* dgate, const float* gate_w, const float* t_saved, const float* fn1_w,
+                float* dx, int stem, const float* v_saved, const float* pw2_w, float* dpre, int B, int H, int W,
+                ksr_stream_t stream);
+
+/* FFN.pointwise2 backward: ds [N,64] = (dy * pointwise2.weight) * (operand_saved > 0). */
+int ksr_pw2_bwd(const float* dy, const float* pw2_w, const float* operand_saved, float* ds, int B, int H, int W,
+                ksr_stream_t stream);
+
+/* FFN.depthwise + pointwise1 backward: dt [N,64] = convT3x3(ds); dx = dt * pointwise1.weight;
+ * dz_prev [N,64] = dx * y(1-y), y_saved = the sigmoid output that fed the FFN (gazetr.py:104). */
+int ksr_pw1_bwd(const float* ds, const float* dw_w, const float* pw1_w, const float* y_saved, float* dt,
+                float* dz_prev, int B, int H, int W, ksr_stream_t stream);
+
+/* Weight gradient of a 1x1 conv / linear layer: dW[j][k] = sum_n dz[n, dz_c0+j] * a1[n, a1_c0+k]
+ * (* a2[n, a2_c0+k] when a2 != NULL), db[j] = sum_n dz[n, dz_c0+j].  J % 32 == 0, K in {32, 64}.
+ * slab: ksr_wgrad_slab_floats(J, K) floats of workspace.  kan_upscale > 0: dz is ksr_feed_kan_bwd's
+ * gparam and rows are scattered to the reference's channel order of feed.weight / feed.bias.
+ * Deterministic (fixed-order slab reduction, no atomics). */
+int ksr_wgrad_slab_floats(int J, int K);
+int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const float* a1, int a1_ld, int a1_c0, int K,
+              const float* a2, int a2_ld, int a2_c0, int64_t N, float* slab, float* dW, float* db,
+              int kan_upscale, int kan_n_coef, ksr_stream_t stream);
+
+/* out[0][c] = sum_n a[n, a_c0+c] * b, out[1][c] = sum_n a[n, a_c0+c], c < 64; b is [N,64] or, with
+ * b_is_per_pixel_scalar, [N].  LayerNorm gain/shift gradients and ffn1.pointwise2.  slab: 256*128 floats. */
+int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b, int b_is_per_pixel_scalar, int64_t N,
+                  float* slab, float* out, int out_row_stride, ksr_stream_t stream);
+
+/* Depthwise 3x3 parameter gradients (64 channels): in = the conv's input (NHWC, in_ld channels per pixel,
+ * 64 channels from in_c0), ds [N,64] = gradient of its output.  dW [64,1,3,3], db [64]. slab: 256*640 floats. */
+int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, float* slab, float* dW, float* db,
+                     int B, int H, int W, ksr_stream_t stream);
+
+/* ffn1's scalar front (pointwise1 1->1, depthwise 3x3 on one channel): out12 = gradients of
+ * pointwise1.weight, pointwise1.bias, depthwise.weight (9), depthwise.bias.  slab: 256*12 floats. */
+int ksr_stem_scalar_wgrad(const float* x_img, int64_t img_batch_stride, const float* dpre, const float* pw1_w,
+                          const float* pw1_b, const float* dw_w, float* slab, float* out12, int B, int H, int W,
+                          ksr_stream_t stream);
+
+/* out[j][k] = r[j]*u[k] + c[j]*w[k] (weight gradient of ffn2.fn_1, whose input is u*v+w with one scalar v
+ * per pixel); c_copy (optional) receives c, the bias gradient. */
+int ksr_outer2(float* out, const float* r, const float* u, const float* c, const float* w, int J, int K,
+               float* c_copy, ksr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training step support (DefaultPipeline.training_step / configure_optimizers,
+ * src/ml/pipelines/default.py:59-84, and the implicit DDP gradient all-reduce, src/cli/train.py:58-62).
+ */
+
+/* loss = mean |pred[:,0] - tgt[:,0]| (nn.L1Loss on the Y plane, default.py:79) and its gradient
+ * grad[b, :] = sign(pred - tgt) * grad_scale / numel.  slab256: 256 floats; loss_out: 1 float (device). */
+int ksr_l1_y_loss(const float* pred, int64_t pred_batch_stride, const float* tgt, int64_t tgt_batch_stride,
+                  float* grad, int64_t grad_batch_stride, int B, int64_t plane_elems, float grad_scale,
+                  float* slab256, float* loss_out, ksr_stream_t stream);
+
+/* torch.optim.Adam step (default.py:61) over flat buffers; grads are multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce).  step counts from 1. */
+int ksr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                  float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                  ksr_stream_t stream);
+
+/* Gradient exchange: one RCCL communicator per process (one process per GPU).  Rank 0 creates the
+ * 128-byte id, every rank calls ksr_comm_init with it; ksr_allreduce_sum is an in-place fp32 sum. */
+int ksr_comm_unique_id(void* out128);
+int ksr_comm_init(int rank, int nranks, const void* unique_id128);
+int ksr_allreduce_sum(float* buf, int64_t n, ksr_stream_t stream);
+int ksr_comm_nranks(void);
+int ksr_comm_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
 // ---------------------------------------------------------------------------------------------
 // First FFN front (pointwise1 1->1, depthwise 3x3 on one channel): u = w1*Y + b1 inside the image,
 // pre = bd + sum_tap wd[tap]*u(.+tap), v = relu(pre).  Given dpre [N]:
-//   slab[g][0..8] = sum dpre * u(.+tap); [9] = sum dpre; [10] = sum du*Y; [11] = sum du,
+//   slab[g][0] = sum du*Y; [1] = sum du; [2..10] = sum dpre * u(.+tap); [11] = sum dpre,
 //   du = sum_tap wd[tap] * dpre(.-tap).
 struct StemgArgs {
     const float* x_img; long img_bstride;
@@ -230,13 +230,13 @@ __global__ void __launch_bounds__(256) stemgrad_kernel(StemgArgs a) {
             for (int dx = -1; dx <= 1; ++dx) {
                 const int tap = (dy + 1) * 3 + (dx + 1);
                 const int yy = y + dy, xx = x + dx;
-                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) acc[tap] += d * (w1 * Y[(long)yy * a.W + xx] + b1);
+                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) acc[2 + tap] += d * (w1 * Y[(long)yy * a.W + xx] + b1);
                 const int ys = y - dy, xs = x - dx;
                 if (ys >= 0 && ys < a.H && xs >= 0 && xs < a.W) du += a.dww[tap] * dp[(long)ys * a.W + xs];
             }
-        acc[9] += d;
-        acc[10] += du * Y[hw];
-        acc[11] += du;
+        acc[11] += d;
+        acc[0] += du * Y[hw];
+        acc[1] += du;
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -253,11 +253,12 @@ __global__ void __launch_bounds__(256) stemgrad_kernel(StemgArgs a) {
 
 // out[j][k] = r[j]*u[k] + c[j]*w[k]
 __global__ void __launch_bounds__(256) outer2_kernel(float* out, const float* r, const float* u, const float* c,
-                                                     const float* w, int J, int K) {
+                                                     const float* w, int J, int K, float* c_copy) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= J * K) return;
     const int j = idx / K, k = idx - j * K;
     out[idx] = r[j] * u[k] + c[j] * w[k];
+    if (c_copy && k == 0) c_copy[j] = c[j];
 }
 
 int launch_reduce(const float* slab, int G, int J, int K, long stride, float* out, int sj, int sk, float* bias,
@@ -323,8 +324,8 @@ extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const flo
     return launch_reduce(slab + 576, (int)g, 1, 64, 640, db, 64, 1, nullptr, 0, 0, 0, stream);
 }
 
-// Gradients of the first FFN's scalar front.  out [12]: depthwise taps (9), depthwise bias, pointwise1
-// weight, pointwise1 bias.  slab: 256*12 floats.
+// Gradients of the first FFN's scalar front.  out [12]: pointwise1 weight, pointwise1 bias, depthwise
+// taps (9), depthwise bias (the order of the module's parameters).  slab: 256*12 floats.
 extern "C" int ksr_stem_scalar_wgrad(const float* x_img, int64_t img_batch_stride, const float* dpre,
                                      const float* pw1_w, const float* pw1_b, const float* dw_w, float* slab,
                                      float* out12, int B, int H, int W, hipStream_t stream) {
@@ -341,10 +342,11 @@ extern "C" int ksr_stem_scalar_wgrad(const float* x_img, int64_t img_batch_strid
 
 // dW[j][k] = r[j]*u[k] + c[j]*w[k]: weight gradient of a 1x1 conv whose input is an affine function
 // u[k]*s + w[k] of one scalar s per pixel (r = sum_n dz*s, c = sum_n dz).
+// c_copy (optional) receives c: it is the bias gradient of the same conv.
 extern "C" int ksr_outer2(float* out, const float* r, const float* u, const float* c, const float* w, int J, int K,
-                          hipStream_t stream) {
+                          float* c_copy, hipStream_t stream) {
     KSR_CHECK_ARG(out && r && u && c && w && J > 0 && K > 0, "outer2: bad argument");
-    hipLaunchKernelGGL(outer2_kernel, dim3((J * K + 255) / 256), dim3(256), 0, stream, out, r, u, c, w, J, K);
+    hipLaunchKernelGGL(outer2_kernel, dim3((J * K + 255) / 256), dim3(256), 0, stream, out, r, u, c, w, J, K, c_copy);
     KSR_LAUNCH_CHECK("outer2");
     return KSR_OK;
 }

@@ -36,7 +36,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_mean", "colreduce", "_token", "_attn")):
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2")):
             return fn
 
         def timed(*args):
@@ -82,6 +82,8 @@ EXPORTS = [
     "ksr_feed_kan_lane_len", "ksr_feed_kan_bwd", "ksr_batch_tx_layer_bwd_token", "ksr_batch_tx_layer_bwd_attn",
     "ksr_in_proj_bwd", "ksr_gate_pw_bwd", "ksr_fn1_bwd", "ksr_pw2_bwd", "ksr_pw1_bwd",
     "ksr_wgrad_slab_floats", "ksr_wgrad", "ksr_colreduce", "ksr_dwconv_wgrad", "ksr_stem_scalar_wgrad", "ksr_outer2",
+    "ksr_l1_y_loss", "ksr_adam_step", "ksr_comm_unique_id", "ksr_comm_init", "ksr_allreduce_sum", "ksr_comm_nranks",
+    "ksr_comm_destroy",
 ]
 
 

@@ -27,14 +27,31 @@ PARAM_ORDER = (
 
 
 class _Ws:
-    """Scratch allocator for one backward pass."""
+    """Scratch allocator for one backward pass.  With an `arena` (name -> view into a flat gradient
+    buffer) every parameter gradient is written in place by the kernels."""
 
-    def __init__(self, dev):
+    def __init__(self, dev, arena=None):
         self.dev = dev
         self._slab = None
+        self.arena = arena
 
     def new(self, *shape):
         return torch.empty(*shape, device=self.dev, dtype=torch.float32)
+
+    def grad(self, name, *shape):
+        if self.arena is None:
+            return self.new(*shape)
+        t = self.arena[name]
+        assert t.numel() == torch.Size(shape).numel(), name
+        return t
+
+    def grad_pair(self, name_w, name_b, n):
+        """[2, n] tensor whose rows are the gradients of two adjacent parameters (weight, bias)."""
+        if self.arena is None:
+            return self.new(2, n)
+        w, b = self.arena[name_w], self.arena[name_b]
+        assert w.numel() == n and b.numel() == n and b.data_ptr() == w.data_ptr() + 4 * n, (name_w, name_b)
+        return torch.as_strided(w, (2, n), (n, 1))
 
     def slab(self, nfloats):
         if self._slab is None or self._slab.numel() < nfloats:
@@ -50,19 +67,17 @@ def _wgrad(ws: _Ws, dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, N, dW, db, a2=None
                       c_int(kan[0]), c_int(kan[1]), stream()), "ksr_wgrad")
 
 
-def _colreduce(ws: _Ws, a, a_ld, a_c0, b, b_scalar, N, out=None, out_c0=0):
+def _colreduce(ws: _Ws, a, a_ld, a_c0, b, b_scalar, N, out, out_c0=0):
     """out[0, out_c0 + c] = sum_n a[n, a_c0 + c] * b[n(, c)];  out[1, out_c0 + c] = sum_n a[n, a_c0 + c]."""
-    if out is None:
-        out = ws.new(2, 64)
     slab = ws.slab(256 * 128)
     check(lib().ksr_colreduce(ptr(a), c_int(a_ld), c_int(a_c0), ptr(b), c_int(int(b_scalar)), c_int64(N), ptr(slab),
                               c_void_p(out.data_ptr() + 4 * out_c0), c_int(out.shape[1]), stream()), "ksr_colreduce")
     return out
 
 
-def _dwconv_wgrad(ws: _Ws, inp, in_ld, in_c0, ds, g: Geometry):
-    dW = ws.new(64, 1, 3, 3)
-    db = ws.new(64)
+def _dwconv_wgrad(ws: _Ws, inp, in_ld, in_c0, ds, g: Geometry, name_w, name_b):
+    dW = ws.grad(name_w, 64, 1, 3, 3)
+    db = ws.grad(name_b, 64)
     slab = ws.slab(256 * 640)
     check(lib().ksr_dwconv_wgrad(ptr(inp), c_int(in_ld), c_int(in_c0), ptr(ds), ptr(slab), ptr(dW), ptr(db),
                                  *_dims(g), stream()), "ksr_dwconv_wgrad")
@@ -91,22 +106,23 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
         da = du1
     # LayerNorm gains / shifts
     if last:
-        r = _colreduce(ws, dy, 64, 0, sv["xhatf"], False, N)
+        r = _colreduce(ws, dy, 64, 0, sv["xhatf"], False, N,
+                       ws.grad_pair(pre + "encoder.norm.weight", pre + "encoder.norm.bias", 64))
         grads[pre + "encoder.norm.weight"], grads[pre + "encoder.norm.bias"] = r[0], r[1]
-        r = _colreduce(ws, ds2, 64, 0, sv["xhat2"], False, N)
+        r = _colreduce(ws, ds2, 64, 0, sv["xhat2"], False, N, ws.grad_pair(q + "norm2.weight", q + "norm2.bias", 64))
     else:
-        r = _colreduce(ws, dy, 64, 0, sv["xhat2"], False, N)
+        r = _colreduce(ws, dy, 64, 0, sv["xhat2"], False, N, ws.grad_pair(q + "norm2.weight", q + "norm2.bias", 64))
     grads[q + "norm2.weight"], grads[q + "norm2.bias"] = r[0], r[1]
-    r = _colreduce(ws, ds1, 64, 0, sv["xhat1"], False, N)
+    r = _colreduce(ws, ds1, 64, 0, sv["xhat1"], False, N, ws.grad_pair(q + "norm1.weight", q + "norm1.bias", 64))
     grads[q + "norm1.weight"], grads[q + "norm1.bias"] = r[0], r[1]
     # linear2 / linear1 / out_proj weights
-    gw, gb = ws.new(64, 32), ws.new(64)
+    gw, gb = ws.grad(q + "linear2.weight", 64, 32), ws.grad(q + "linear2.bias", 64)
     _wgrad(ws, dm, 64, 0, 64, sv["hmid"], 32, 0, 32, N, gw, gb)
     grads[q + "linear2.weight"], grads[q + "linear2.bias"] = gw, gb
-    gw, gb = ws.new(32, 64), ws.new(32)
+    gw, gb = ws.grad(q + "linear1.weight", 32, 64), ws.grad(q + "linear1.bias", 32)
     _wgrad(ws, dpre, 32, 0, 32, sv["s1"], 64, 0, 64, N, gw, gb)
     grads[q + "linear1.weight"], grads[q + "linear1.bias"] = gw, gb
-    gw, gb = ws.new(64, 64), ws.new(64)
+    gw, gb = ws.grad(q + "self_attn.out_proj.weight", 64, 64), ws.grad(q + "self_attn.out_proj.bias", 64)
     _wgrad(ws, da, 64, 0, 64, sv["ctx"], 64, 0, 64, N, gw, gb)
     grads[q + "self_attn.out_proj.weight"], grads[q + "self_attn.out_proj.bias"] = gw, gb
     # attention
@@ -114,7 +130,7 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     check(L.ksr_batch_tx_layer_bwd_attn(ptr(sv["qkv"]), ptr(sv["ctx"]), ptr(dctx), ptr(dqkv), c_int(g.B),
                                         c_int(g.H * g.W), c_float(p_drop), c_uint64(lseed), stream()),
           "ksr_batch_tx_layer_bwd_attn")
-    gw, gb = ws.new(192, 64), ws.new(192)
+    gw, gb = ws.grad(q + "self_attn.in_proj_weight", 192, 64), ws.grad(q + "self_attn.in_proj_bias", 192)
     _wgrad(ws, dqkv, 192, 0, 192, sv["in"], 64, 0, 64, N, gw, gb)
     grads[q + "self_attn.in_proj_weight"], grads[q + "self_attn.in_proj_bias"] = gw, gb
     dsin = ws.new(N, 64)
@@ -133,15 +149,16 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
     dgate = ws.new(N, 64)
     check(L.ksr_gate_pw_bwd(ptr(dz), ptr(p[q + "fn_2.weight"]), ptr(gate_saved), ptr(t), ptr(dt), ptr(dgate),
                             *_dims(g), stream()), "ksr_gate_pw_bwd")
-    gw, gb = ws.new(64, 64, 1, 1), ws.new(64)
+    gw, gb = ws.grad(q + "fn_2.weight", 64, 64, 1, 1), ws.grad(q + "fn_2.bias", 64)
     _wgrad(ws, dz, 64, 0, 64, t, 128, 0, 64, N, gw, gb, a2=gate_saved, a2_ld=64, a2_c0=0)
     grads[q + "fn_2.weight"], grads[q + "fn_2.bias"] = gw, gb
-    grads[q + "gate.weight"], grads[q + "gate.bias"] = _dwconv_wgrad(ws, t, 128, 64, dgate, g)
+    grads[q + "gate.weight"], grads[q + "gate.bias"] = _dwconv_wgrad(ws, t, 128, 64, dgate, g, q + "gate.weight",
+                                                                   q + "gate.bias")
     dx = ws.new(N, 64)
     if stem_saves is None:
         check(L.ksr_fn1_bwd(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(t), ptr(p[q + "fn_1.0.weight"]), ptr(dx),
                             c_int(0), ptr(None), ptr(None), ptr(None), *_dims(g), stream()), "ksr_fn1_bwd")
-        gw, gb = ws.new(128, 64, 1, 1), ws.new(128)
+        gw, gb = ws.grad(q + "fn_1.0.weight", 128, 64, 1, 1), ws.grad(q + "fn_1.0.bias", 128)
         _wgrad(ws, dt, 128, 0, 128, x_in, 64, 0, 64, N, gw, gb)
         grads[q + "fn_1.0.weight"], grads[q + "fn_1.0.bias"] = gw, gb
         return dx
@@ -154,46 +171,62 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
     rc = ws.new(2, 128)
     _colreduce(ws, dt, 128, 0, v, True, N, rc, 0)
     _colreduce(ws, dt, 128, 64, v, True, N, rc, 64)
-    r, c = rc[0], rc[1]
-    gw = ws.new(128, 64, 1, 1)
-    check(L.ksr_outer2(ptr(gw), ptr(r), ptr(p[f + "pointwise2.weight"]), ptr(c), ptr(p[f + "pointwise2.bias"]),
-                       c_int(128), c_int(64), stream()), "ksr_outer2")
-    grads[q + "fn_1.0.weight"], grads[q + "fn_1.0.bias"] = gw, c
-    r2 = _colreduce(ws, dx, 64, 0, v, True, N)
+    gw, gb = ws.grad(q + "fn_1.0.weight", 128, 64, 1, 1), ws.grad(q + "fn_1.0.bias", 128)
+    check(L.ksr_outer2(ptr(gw), c_void_p(rc.data_ptr()), ptr(p[f + "pointwise2.weight"]),
+                       c_void_p(rc.data_ptr() + 4 * 128), ptr(p[f + "pointwise2.bias"]),
+                       c_int(128), c_int(64), ptr(gb), stream()), "ksr_outer2")
+    grads[q + "fn_1.0.weight"], grads[q + "fn_1.0.bias"] = gw, gb
+    r2 = _colreduce(ws, dx, 64, 0, v, True, N, ws.grad_pair(f + "pointwise2.weight", f + "pointwise2.bias", 64))
     grads[f + "pointwise2.weight"], grads[f + "pointwise2.bias"] = r2[0].reshape(64, 1, 1, 1), r2[1]
-    out12 = ws.new(12)
+    if ws.arena is None:
+        out12 = ws.new(12)
+    else:   # the four tensors are adjacent in the flat buffer, in this order
+        names12 = [f + "pointwise1.weight", f + "pointwise1.bias", f + "depthwise.weight", f + "depthwise.bias"]
+        base = ws.arena[names12[0]]
+        off = 0
+        for nm in names12:
+            assert ws.arena[nm].data_ptr() == base.data_ptr() + 4 * off, nm
+            off += ws.arena[nm].numel()
+        out12 = torch.as_strided(base, (12,), (1,))
     slab = ws.slab(256 * 12)
     check(L.ksr_stem_scalar_wgrad(ptr(x_img), c_int64(3 * g.H * g.W), ptr(dpre), ptr(p[f + "pointwise1.weight"]),
                                   ptr(p[f + "pointwise1.bias"]), ptr(p[f + "depthwise.weight"]), ptr(slab), ptr(out12),
                                   *_dims(g), stream()), "ksr_stem_scalar_wgrad")
-    grads[f + "depthwise.weight"] = out12[0:9].reshape(1, 1, 3, 3)
-    grads[f + "depthwise.bias"] = out12[9:10]
-    grads[f + "pointwise1.weight"] = out12[10:11].reshape(1, 1, 1, 1)
-    grads[f + "pointwise1.bias"] = out12[11:12]
+    grads[f + "pointwise1.weight"] = out12[0:1].reshape(1, 1, 1, 1)
+    grads[f + "pointwise1.bias"] = out12[1:2]
+    grads[f + "depthwise.weight"] = out12[2:11].reshape(1, 1, 3, 3)
+    grads[f + "depthwise.bias"] = out12[11:12]
     return None
 
 
-def backward_all(gout: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Geometry, sv: dict,
-                 save_us: torch.Tensor, p_drop: float, seed: int) -> Dict[str, torch.Tensor]:
+def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str,
+                 g: Geometry, sv: dict, save_us: torch.Tensor, p_drop: float, seed: int, arena=None,
+                 on_tail_done=None) -> Dict[str, torch.Tensor]:
+    """gout: gradient of the Y plane of the output (images gout_batch_stride elements apart).
+    arena: optional name -> view map; gradients are then written in place.  on_tail_done() is called
+    once the gradients of feed + both transformer layers + the final norm have been enqueued (the
+    first all-reduce bucket), while the conv-trunk backward is still to come."""
     L = lib()
     N = g.N
-    ws = _Ws(x.device)
+    ws = _Ws(x.device, arena)
     grads: Dict[str, torch.Tensor] = {}
     # ---- feed + KAN ----
     lane_len = int(L.ksr_feed_kan_lane_len(c_int(g.r), c_int(g.n_coef)))
     gfeat = ws.new(N, 64)
     gparam = ws.new(N, 2 * lane_len)
-    check(L.ksr_feed_kan_bwd(ptr(gout), c_int64(gout.shape[1] * gout.shape[2] * gout.shape[3]), ptr(x),
+    check(L.ksr_feed_kan_bwd(ptr(gout), c_int64(gout_batch_stride), ptr(x),
                              c_int64(3 * g.H * g.W), ptr(p[pre + "feed.weight"]), ptr(save_us), ptr(gfeat), ptr(gparam),
                              *_dims(g), c_int(g.r), c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k),
                              stream()), "ksr_feed_kan_bwd")
     P = g.r * g.r * (g.n_coef + 2)
-    gw, gb = ws.new(P, 64, 1, 1), ws.new(P)
+    gw, gb = ws.grad(pre + "feed.weight", P, 64, 1, 1), ws.grad(pre + "feed.bias", P)
     _wgrad(ws, gparam, 2 * lane_len, 0, 2 * lane_len, sv["feat"], 64, 0, 64, N, gw, gb, kan=(g.r, g.n_coef))
     grads[pre + "feed.weight"], grads[pre + "feed.bias"] = gw, gb
     # ---- transformer layers ----
     d = _tx_layer_backward(ws, gfeat, 1, p, pre, g, sv["tx1"], p_drop, seed, grads, None)
     dz6 = _tx_layer_backward(ws, d, 0, p, pre, g, sv["tx0"], p_drop, seed, grads, sv["x6"])
+    if on_tail_done is not None:
+        on_tail_done()
     # ---- ffn4 (gated) ----
     dx4 = _gated_backward(ws, dz6, "ffn4", p, pre, g, sv["t5"], sv["g6"], grads, sv["x4"])
     # ---- ffn3 ----
@@ -201,14 +234,15 @@ def backward_all(gout: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor]
     ds4 = ws.new(N, 64)
     check(L.ksr_pw2_bwd(ptr(dx4), ptr(p[q + "pointwise2.weight"]), ptr(sv["a4"]), ptr(ds4), *_dims(g), stream()),
           "ksr_pw2_bwd")
-    gw, gb = ws.new(64, 64, 1, 1), ws.new(64)
+    gw, gb = ws.grad(q + "pointwise2.weight", 64, 64, 1, 1), ws.grad(q + "pointwise2.bias", 64)
     _wgrad(ws, dx4, 64, 0, 64, sv["a4"], 64, 0, 64, N, gw, gb)
     grads[q + "pointwise2.weight"], grads[q + "pointwise2.bias"] = gw, gb
-    grads[q + "depthwise.weight"], grads[q + "depthwise.bias"] = _dwconv_wgrad(ws, sv["t3"], 64, 0, ds4, g)
+    grads[q + "depthwise.weight"], grads[q + "depthwise.bias"] = _dwconv_wgrad(ws, sv["t3"], 64, 0, ds4, g,
+                                                                             q + "depthwise.weight", q + "depthwise.bias")
     dt3, dz2 = ws.new(N, 64), ws.new(N, 64)
     check(L.ksr_pw1_bwd(ptr(ds4), ptr(p[q + "depthwise.weight"]), ptr(p[q + "pointwise1.weight"]), ptr(sv["x3"]),
                         ptr(dt3), ptr(dz2), *_dims(g), stream()), "ksr_pw1_bwd")
-    gw, gb = ws.new(64, 64, 1, 1), ws.new(64)
+    gw, gb = ws.grad(q + "pointwise1.weight", 64, 64, 1, 1), ws.grad(q + "pointwise1.bias", 64)
     _wgrad(ws, dt3, 64, 0, 64, sv["x3"], 64, 0, 64, N, gw, gb)
     grads[q + "pointwise1.weight"], grads[q + "pointwise1.bias"] = gw, gb
     # ---- ffn2 (gated) + ffn1 ----
@@ -237,7 +271,8 @@ class _ConvSepKanFn(torch.autograd.Function):
             raise KsrError("gradient with respect to the input image is not implemented (the training step "
                            "of the reference never needs it)")
         gout = gout.contiguous()
-        grads = backward_all(gout, ctx.x, ctx.p, pre, g, ctx.sv, ctx.save_us, p_drop, seed)
+        grads = backward_all(gout, gout.shape[1] * gout.shape[2] * gout.shape[3], ctx.x, ctx.p, pre, g, ctx.sv,
+                             ctx.save_us, p_drop, seed)
         ctx.sv = ctx.save_us = None
         out = []
         for n, t in zip(names, ctx.p.values()):

@@ -1,0 +1,171 @@
+"""Data-parallel training step for ConvSepKan on MI355X.
+
+One process per GPU.  Parameters, gradients and Adam state of the live layer are single flat fp32
+buffers; the kernels write every gradient in place.  The flat order follows the order in which the
+backward FINISHES gradients (feed, transformer layers, final norm | conv trunk), so the first bucket
+can be all-reduced on a side stream (RCCL over xGMI) while the conv-trunk backward is still running.
+The loss of the step is L1 on the Y plane (the SSIM term of the reference's training_step,
+src/ml/pipelines/default.py:79-81, is not part of this step).
+
+The attention of the hyper-encoder mixes the images of the LOCAL batch (as under the reference's DDP),
+so no activation crosses GPUs: the only exchange is the gradient all-reduce.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_float, c_int, c_int64, c_void_p
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import engine
+from ._lib import KsrError, check, lib, ptr, stream
+from .autograd import PARAM_ORDER, backward_all
+from .engine import TX_PARAM_NAMES
+
+# gradient-completion order of the parameter groups (see module docstring)
+_TAIL = (["feed.weight", "feed.bias"]
+         + [f"encoder.layers.1.{n}" for n in TX_PARAM_NAMES] + ["encoder.norm.weight", "encoder.norm.bias"]
+         + [f"encoder.layers.0.{n}" for n in TX_PARAM_NAMES])
+_TRUNK = [n for n in PARAM_ORDER if n not in _TAIL]   # ffn1..ffn4 in module order (adjacency preserved)
+FLAT_ORDER = _TAIL + _TRUNK
+
+
+def flat_layout(shapes: Dict[str, torch.Size]):
+    """name -> (offset, numel) in FLAT_ORDER, plus the element count of the first bucket and the total."""
+    off, table = 0, {}
+    for n in FLAT_ORDER:
+        k = shapes[n].numel()
+        table[n] = (off, k)
+        off += k
+        if n == _TAIL[-1]:
+            tail_end = off
+    return table, tail_end, off
+
+
+def shard_batch(global_batch: int, world_size: int, rank: int):
+    """Contiguous shard [lo, hi) of a global batch for `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(global_batch, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class RcclComm:
+    """Gradient exchange through libksr's RCCL wrapper.  The 128-byte unique id travels over the
+    torch.distributed process group that the launcher (torchrun) already set up."""
+
+    def __init__(self, rank: int, world_size: int):
+        import torch.distributed as dist
+        L = lib()
+        buf = (ctypes.c_ubyte * 128)()
+        if rank == 0:
+            check(L.ksr_comm_unique_id(buf), "ksr_comm_unique_id")
+        idt = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device="cuda")
+        dist.broadcast(idt, src=0)
+        raw = bytes(idt.cpu().tolist())
+        check(L.ksr_comm_init(c_int(rank), c_int(world_size), ctypes.c_char_p(raw)), "ksr_comm_init")
+        self.world_size = world_size
+
+    def allreduce_sum(self, t: torch.Tensor, hip_stream: c_void_p) -> None:
+        check(lib().ksr_allreduce_sum(ptr(t), c_int64(t.numel()), hip_stream), "ksr_allreduce_sum")
+
+    def close(self):
+        lib().ksr_comm_destroy()
+
+
+class GlooComm:
+    """Same interface over a CPU torch.distributed group: used by the multi-process CPU tests that
+    rehearse the N > 1 host logic (sharding, flat layout, sum-then-scale).  Not used on GPUs."""
+
+    def __init__(self, world_size: int):
+        self.world_size = world_size
+
+    def allreduce_sum(self, t: torch.Tensor, hip_stream=None) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def close(self):
+        pass
+
+
+class TrainStep:
+    def __init__(self, model, world_size: int = 1, rank: int = 0, lr: float = 1e-3, betas=(0.9, 0.999),
+                 eps: float = 1e-8, weight_decay: float = 0.0, comm=None):
+        self.model = model
+        self.world_size, self.rank = world_size, rank
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        li = len(model.layers) - 1
+        self.pre = f"layers.{li}.encoder.encoder."
+        layer = model.layers[li].encoder.encoder
+        named = dict(layer.named_parameters())
+        dev = next(model.parameters()).device
+        table, self.tail_end, total = flat_layout({n: named[n].shape for n in FLAT_ORDER})
+        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.arena: Dict[str, torch.Tensor] = {}
+        for n in FLAT_ORDER:
+            off, k = table[n]
+            prm = named[n]
+            view = self.flat_p[off:off + k].view(prm.shape)
+            view.copy_(prm.data)
+            prm.data = view                       # the module's parameters now live in the flat buffer
+            self.p[self.pre + n] = prm.data
+            self.arena[self.pre + n] = self.flat_g[off:off + k].view(prm.shape)
+        self.steps = 0
+        self.comm = comm
+        if world_size > 1 and comm is None:
+            self.comm = RcclComm(rank, world_size)
+        self.side = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.slab = torch.empty(256, device=dev, dtype=torch.float32)
+        self.loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.last_seed = 0
+
+    def step(self, x: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+        """One optimisation step on this rank's shard.  Returns the (device) loss tensor of the shard."""
+        L = lib()
+        m = self.model
+        x = x.contiguous()
+        g = engine.Geometry(x, m.upscale, m.grid_size, m.spline_order, m.grid_range)
+        p_drop = m.layers[-1].encoder.encoder.encoder.layers[0].p_drop if m.training else 0.0
+        seed = engine.new_seed() if p_drop > 0 else 0
+        self.last_seed = seed
+        out = torch.empty(g.B, 3, g.H * g.r, g.W * g.r, device=x.device, dtype=torch.float32)
+        engine.bilinear_up_into(x, out, g.r, 1, 2, 1)
+        sv: dict = {}
+        feat = engine.encoder_forward(x, self.p, self.pre, g, sv, p_drop, seed)
+        save_us = torch.empty(g.N, g.r * g.r, 2, device=x.device, dtype=torch.float32)
+        engine.feed_kan_forward(feat, x, self.p, self.pre, g, out, save_us)
+        # loss + dL/dY'
+        plane = g.H * g.r * g.W * g.r
+        gy = torch.empty(g.B, plane, device=x.device, dtype=torch.float32)
+        check(L.ksr_l1_y_loss(ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
+                              c_int64(plane), c_int(g.B), c_int64(plane), c_float(1.0), ptr(self.slab), ptr(self.loss),
+                              stream()), "ksr_l1_y_loss")
+        main = torch.cuda.current_stream()
+
+        def tail_done():
+            if self.side is None:
+                return
+            self.side.wait_stream(main)
+            self.comm.allreduce_sum(self.flat_g[:self.tail_end], c_void_p(self.side.cuda_stream))
+
+        backward_all(gy, plane, x, self.p, self.pre, g, sv, save_us, p_drop, seed, arena=self.arena,
+                     on_tail_done=tail_done)
+        if self.side is not None:
+            self.side.wait_stream(main)
+            self.comm.allreduce_sum(self.flat_g[self.tail_end:], c_void_p(self.side.cuda_stream))
+            main.wait_stream(self.side)
+        self.steps += 1
+        check(L.ksr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                              c_int64(self.flat_p.numel()), c_float(self.lr), c_float(self.betas[0]),
+                              c_float(self.betas[1]), c_float(self.eps), c_float(self.wd), c_int(self.steps),
+                              c_float(1.0 / self.world_size), stream()), "ksr_adam_step")
+        self.out = out
+        return self.loss
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
