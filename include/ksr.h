@@ -178,7 +178,7 @@ int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const float* a1, int
               int kan_upscale, int kan_n_coef, ksr_stream_t stream);
 
 /* out[0][c] = sum_n a[n, a_c0+c] * b, out[1][c] = sum_n a[n, a_c0+c], c < 64; b is [N,64] or, with
- * b_is_per_pixel_scalar, [N].  LayerNorm gain/shift gradients and ffn1.pointwise2.  slab: 256*128 floats. */
+ * b_is_per_pixel_scalar, [N].  LayerNorm gain/shift gradients and ffn1.pointwise2.  slab: 1024*128 floats. */
 int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b, int b_is_per_pixel_scalar, int64_t N,
                   float* slab, float* out, int out_row_stride, ksr_stream_t stream);
 

@@ -93,11 +93,19 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) dz[i] = g[i];
             }
-            if (live) ksr_store32(a.dz_store + n * a.dz_store_ld + a.dz_store_c0 + 32 * h, g);
         }
 
+        // phase fences: keep the epilogue's loads from being hoisted above the GEMM (register pressure)
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[2];
         ksr_wave_gemm<KH, 2>(sm.frag, nullptr, dz, acc, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (BPRO != BPRO_PLAIN) {
+            // the conv-transposed gradient is also an output (stored here, after the GEMM: a conditional
+            // store right behind the stencil makes the compiler duplicate it and spill)
+            if (live) ksr_store32(a.dz_store + n * a.dz_store_ld + a.dz_store_c0 + 32 * h, dz + (BPRO == BPRO_CONVT_G ? 32 : 0));
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float dA[32];
 #pragma unroll
         for (int i = 0; i < 16; ++i) { dA[i] = acc[0][i]; dA[16 + i] = acc[1][i]; }

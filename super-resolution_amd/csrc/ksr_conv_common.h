@@ -50,6 +50,10 @@ __device__ __forceinline__ void ksr_dwconv_lane(const float* __restrict__ halo, 
                 g[4 * q + 0] += wq[0] * tv[0]; g[4 * q + 1] += wq[1] * tv[1];
                 g[4 * q + 2] += wq[2] * tv[2]; g[4 * q + 3] += wq[3] * tv[3];
             }
+            // Pin the partial sums here: without it the compiler may sink a tap's FMAs far below its LDS
+            // reads (seen when the stencil result is also stored to memory) and spill hundreds of VGPRs.
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(g[i]));
             __builtin_amdgcn_sched_barrier(0);   // one tap at a time: bounds live registers
         }
 }

@@ -12,6 +12,8 @@
 namespace {
 
 constexpr int WG_MAXP = 6;     // output blocks per wave
+constexpr int WG_T = 32;       // pixels per staged chunk
+constexpr int WG_GRID = 512;   // at most this many workgroups / partial slabs
 
 struct WgArgs {
     const float* dz; int dz_ld, dz_c0, J;
@@ -21,13 +23,23 @@ struct WgArgs {
     long N;
 };
 
+// Each workgroup walks its pixel range in chunks of 32 pixels.  A chunk's rows [dz | a1 | a2] are copied
+// global -> LDS by 16-byte LDS-DMA loads (lane-linear image = row-major [32][RL]), double buffered: the
+// loads of chunk c+1 are in flight while the MFMAs of chunk c run.  Operands are then read from LDS with
+// conflict-free ds_read_b32 (lane = column).  Wave w owns column block kb = w % (K/32) of A and the
+// dz blocks jb = w / (K/32) + i * (4 / (K/32)).
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int col = lane & 31, kk = lane >> 5;
     const int NJB = a.J / 32, NKB = a.K / 32;
     const int kb = wv % NKB, jb0 = wv / NKB, jbs = 4 / NKB;
     int np = 0;
     for (int jb = jb0; jb < NJB; jb += jbs) ++np;
+    const int RL = a.J + a.K + (a.a2 ? a.K : 0);       // floats per staged row
+    const int RL4 = RL / 4;
+    const unsigned inv = (unsigned)((0x100000000ULL + RL4 - 1) / RL4);
+    const int npass = (WG_T * RL4) / 256;               // RL4 is a multiple of 8: exact
 
     f32x16 acc[WG_MAXP];
     float bsum[WG_MAXP];
@@ -37,35 +49,50 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[p][q] = 0.f;
     }
-    const long per = (((a.N + gridDim.x - 1) / gridDim.x) + 15) / 16 * 16;
+    const long per = (((a.N + gridDim.x - 1) / gridDim.x) + WG_T - 1) / WG_T * WG_T;
     const long n0 = (long)blockIdx.x * per;
     const long n1 = (n0 + per < a.N) ? n0 + per : a.N;
+    const int nchunks = n1 > n0 ? (int)((n1 - n0 + WG_T - 1) / WG_T) : 0;
 
-    for (long t = n0; t < n1; t += 16) {
-        float bop[8], aop[WG_MAXP][8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const long tokn = t + 2 * u + kk;
-            const bool ok = tokn < n1;
-            const long tn = ok ? tokn : n0;
-            float bv = a.a1[tn * a.a1_ld + a.a1_c0 + 32 * kb + col];
-            if (a.a2) bv *= a.a2[tn * a.a2_ld + a.a2_c0 + 32 * kb + col];
-            bop[u] = ok ? bv : 0.f;
+    auto issue = [&](int c) {
+        float* dstbuf = wlds + (c & 1) * (WG_T * RL);
+        const long t0 = n0 + (long)c * WG_T;
+        for (int i = 0; i < npass; ++i) {
+            const unsigned f = (unsigned)(i * 256 + tid);
+            const unsigned trow = __umulhi(f, inv);
+            const int q = (int)(f - trow * RL4) * 4;
+            long tokn = t0 + trow;
+            if (tokn >= n1) tokn = n1 - 1;
+            const float* src;
+            if (q < a.J) src = a.dz + tokn * a.dz_ld + a.dz_c0 + q;
+            else if (q < a.J + a.K) src = a.a1 + tokn * a.a1_ld + a.a1_c0 + (q - a.J);
+            else src = a.a2 + tokn * a.a2_ld + a.a2_c0 + (q - a.J - a.K);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dstbuf + (i * 256 + wv * 64) * 4),
+                                             16, 0, 0);
+        }
+    };
+
+    if (nchunks > 0) issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                 // chunk c has landed (vmcnt(0) + barrier); buffer (c+1)&1 is free
+        if (c + 1 < nchunks) issue(c + 1);
+        const float* buf = wlds + (c & 1) * (WG_T * RL);
+        const long t0 = n0 + (long)c * WG_T;
+        const bool full = t0 + WG_T <= n1;
+#pragma unroll 4
+        for (int u = 0; u < WG_T / 2; ++u) {
+            const float* row = buf + (2 * u + kk) * RL;
+            float bv = row[a.J + 32 * kb + col];
+            if (a.a2) bv *= row[a.J + a.K + 32 * kb + col];
+            const bool ok = full || (t0 + 2 * u + kk < n1);
 #pragma unroll
             for (int p = 0; p < WG_MAXP; ++p) {
                 if (p < np) {
-                    const float av = a.dz[tn * a.dz_ld + a.dz_c0 + 32 * (jb0 + p * jbs) + col];
-                    aop[p][u] = ok ? av : 0.f;
-                }
-            }
-        }
-#pragma unroll
-        for (int p = 0; p < WG_MAXP; ++p) {
-            if (p < np) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(aop[p][u], bop[u], acc[p], 0, 0, 0);
-                    bsum[p] += aop[p][u];
+                    float av = row[32 * (jb0 + p * jbs) + col];
+                    av = ok ? av : 0.f;
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p], 0, 0, 0);
+                    bsum[p] += av;
                 }
             }
         }
@@ -99,11 +126,20 @@ struct RedArgs {
 };
 
 __global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // 16 outputs x 16 slab groups per workgroup; group partials are combined in a fixed order
+    __shared__ float part[16][17];
+    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int idx = blockIdx.x * 16 + o;
     const int total = a.J * a.K + (a.bias ? a.J : 0);
-    if (idx >= total) return;
     float s = 0.f;
-    for (int g = 0; g < a.G; ++g) s += a.slab[(long)g * a.stride + idx];
+    if (idx < total)
+        for (int g = grp; g < a.G; g += 16) s += a.slab[(long)g * a.stride + idx];
+    part[grp][o] = s;
+    __syncthreads();
+    if (grp != 0 || idx >= total) return;
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += part[r][o];
     int j, k;
     const bool is_bias = idx >= a.J * a.K;
     if (is_bias) { j = idx - a.J * a.K; k = 0; }
@@ -126,24 +162,39 @@ struct ColArgs {
 };
 
 __global__ void __launch_bounds__(256) colreduce_kernel(ColArgs a) {
-    __shared__ float red[2][4][64];
-    const int c = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    __shared__ float red[2][16][64];
+    const int c4 = (threadIdx.x & 15) * 4, rg = threadIdx.x >> 4;     // 16 row groups x 16 channel quads
     const long per = (a.N + gridDim.x - 1) / gridDim.x;
     const long n0 = (long)blockIdx.x * per;
     const long n1 = (n0 + per < a.N) ? n0 + per : a.N;
-    float sab = 0.f, sa = 0.f;
-    for (long n = n0 + rg; n < n1; n += 4) {
-        const float av = a.a[n * a.a_ld + a.a_c0 + c];
-        const float bv = a.b_scalar ? a.b[n] : a.b[n * 64 + c];
-        sab += av * bv;
-        sa += av;
+    float sab[4] = {0.f, 0.f, 0.f, 0.f}, sa[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long n = n0 + rg; n < n1; n += 64) {
+        float4 av[4], bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long nn = n + 16 * u;
+            const bool ok = nn < n1;
+            const long nc = ok ? nn : n;
+            av[u] = *reinterpret_cast<const float4*>(a.a + nc * a.a_ld + a.a_c0 + c4);
+            if (a.b_scalar) { const float s = a.b[nc]; bv[u] = make_float4(s, s, s, s); }
+            else bv[u] = *reinterpret_cast<const float4*>(a.b + nc * 64 + c4);
+            if (!ok) av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sab[0] += av[u].x * bv[u].x; sab[1] += av[u].y * bv[u].y; sab[2] += av[u].z * bv[u].z; sab[3] += av[u].w * bv[u].w;
+            sa[0] += av[u].x; sa[1] += av[u].y; sa[2] += av[u].z; sa[3] += av[u].w;
+        }
     }
-    red[0][rg][c] = sab;
-    red[1][rg][c] = sa;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][rg][c4 + e] = sab[e]; red[1][rg][c4 + e] = sa[e]; }
     __syncthreads();
     if (threadIdx.x < 128) {
-        const int w = threadIdx.x >> 6;
-        a.slab[(long)blockIdx.x * 128 + w * 64 + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
+        const int w = threadIdx.x >> 6, c = threadIdx.x & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += red[w][r][c];
+        a.slab[(long)blockIdx.x * 128 + w * 64 + c] = s;
     }
 }
 
@@ -265,14 +316,14 @@ int launch_reduce(const float* slab, int G, int J, int K, long stride, float* ou
                   int kan_O, int kan_Kc, int kan_nbh, hipStream_t s) {
     RedArgs r{slab, G, J, K, stride, out, sj, sk, bias, kan_O, kan_Kc, kan_nbh};
     const int total = J * K + (bias ? J : 0);
-    hipLaunchKernelGGL(reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, s, r);
     KSR_LAUNCH_CHECK("reduce");
     return KSR_OK;
 }
 
 }  // namespace
 
-extern "C" int ksr_wgrad_slab_floats(int J, int K) { return 256 * (J * K + J); }
+extern "C" int ksr_wgrad_slab_floats(int J, int K) { return WG_GRID * (J * K + J); }
 
 // dW [J][K] (row-major, or scattered through the KAN channel map when kan_upscale > 0) and db [J].
 // slab: workspace of ksr_wgrad_slab_floats(J, K) floats.
@@ -284,10 +335,22 @@ extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const flo
     KSR_CHECK_ARG(N > 0, "wgrad: N must be positive");
     const int NKB = K / 32, per_wave = (J / 32 + (4 / NKB) - 1) / (4 / NKB);
     KSR_UNSUPPORTED(per_wave > WG_MAXP, "wgrad: J=%d too large", J);
+    KSR_CHECK_ARG(dz_ld % 4 == 0 && dz_c0 % 4 == 0 && a1_ld % 4 == 0 && a1_c0 % 4 == 0 && a2_ld % 4 == 0 && a2_c0 % 4 == 0,
+                  "wgrad: leading dimensions and channel offsets must be multiples of 4");
     WgArgs a{dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, a2, a2_ld, a2_c0, slab, (long)N};
-    long g = (N + 511) / 512;
-    if (g > 256) g = 256;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)g), dim3(256), 0, stream, a);
+    const int RL = J + K + (a2 ? K : 0);
+    const size_t lds_bytes = (size_t)2 * WG_T * RL * sizeof(float);
+    KSR_UNSUPPORTED(lds_bytes > 160 * 1024, "wgrad: J=%d needs %zu bytes of LDS", J, lds_bytes);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { ksr_set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return KSR_ERR_HIP; }
+        attr_set = true;
+    }
+    long g = (N + 4 * WG_T - 1) / (4 * WG_T);
+    if (g > WG_GRID) g = WG_GRID;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
     KSR_LAUNCH_CHECK("wgrad");
     int kan_O = 0, kan_nbh = 0;
     if (kan_upscale > 0) {
@@ -298,13 +361,14 @@ extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const flo
 }
 
 // out[0][c] = sum_n a[n][c]*b, out[1][c] = sum_n a[n][c] for 64 channels c; rows out_row_stride apart.
-// slab: 256*128 floats.
+// slab: 1024*128 floats.
 extern "C" int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b, int b_is_per_pixel_scalar, int64_t N,
                              float* slab, float* out, int out_row_stride, hipStream_t stream) {
     KSR_CHECK_ARG(a && b && slab && out && N > 0 && a_ld >= 64 && out_row_stride >= 64, "colreduce: bad argument");
+    KSR_CHECK_ARG(a_ld % 4 == 0 && a_c0 % 4 == 0, "colreduce: a_ld and a_c0 must be multiples of 4");
     ColArgs c{a, a_ld, a_c0, b, b_is_per_pixel_scalar, slab, (long)N};
     long g = (N + 255) / 256;
-    if (g > 256) g = 256;
+    if (g > 1024) g = 1024;
     hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, c);
     KSR_LAUNCH_CHECK("colreduce");
     return launch_reduce(slab, (int)g, 2, 64, 128, out, out_row_stride, 1, nullptr, 0, 0, 0, stream);

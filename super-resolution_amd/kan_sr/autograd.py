@@ -55,7 +55,7 @@ class _Ws:
 
     def slab(self, nfloats):
         if self._slab is None or self._slab.numel() < nfloats:
-            self._slab = torch.empty(max(nfloats, 256 * (192 * 64 + 192)), device=self.dev, dtype=torch.float32)
+            self._slab = torch.empty(max(nfloats, 512 * (192 * 64 + 192)), device=self.dev, dtype=torch.float32)
         return self._slab
 
 
@@ -69,7 +69,7 @@ def _wgrad(ws: _Ws, dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, N, dW, db, a2=None
 
 def _colreduce(ws: _Ws, a, a_ld, a_c0, b, b_scalar, N, out, out_c0=0):
     """out[0, out_c0 + c] = sum_n a[n, a_c0 + c] * b[n(, c)];  out[1, out_c0 + c] = sum_n a[n, a_c0 + c]."""
-    slab = ws.slab(256 * 128)
+    slab = ws.slab(1024 * 128)
     check(lib().ksr_colreduce(ptr(a), c_int(a_ld), c_int(a_c0), ptr(b), c_int(int(b_scalar)), c_int64(N), ptr(slab),
                               c_void_p(out.data_ptr() + 4 * out_c0), c_int(out.shape[1]), stream()), "ksr_colreduce")
     return out
