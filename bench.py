@@ -4,10 +4,12 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload infer|train]
 
 One JSON line on stdout (rank 0).  Workloads (synthetic data, random-init weights, seeds fixed):
+  train : (default) x4 SR training step (forward + L1(Y) + backward + RCCL gradient all-reduce when N>1 +
+          Adam), 64 patches of 128x128 per GPU (weak scaling: the per-rank batch semantics of the
+          reference's trainer), dropout live.  At N=1 the line also carries "inference": the 1-GPU
+          960x540 -> 3840x2160 frame rate, the second half of BASELINE.json's metric.
   infer : x4 SR inference, fp32, eval, one 960x540 YCbCr frame -> 3840x2160 per step and GPU
           (BASELINE config "x4 SR inference, 1xMI355X, fp32, 1080p->4K"); N>1 = N independent replicas.
-  train : x4 SR training step (forward + backward [+ gradient all-reduce when N>1]), 64 patches of
-          128x128 per GPU (weak scaling, the per-rank batch semantics of the reference's trainer).
 `value` = whole-job output megapixels per second with inputs resident in HBM.
 """
 import argparse
@@ -26,18 +28,27 @@ PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (spec)
 PEAK_HBM_GBS = 8000.0
 
 
-def flops_per_pixel(name: str, S: int, P: int) -> float:
-    """Algorithmic flops per LR pixel and launch of each forward kernel (2*Cin*Cout per 1x1 conv,
-    2*9 per depthwise output channel, 256*S per token for the two attention products)."""
+def kernel_models(S: int, P: int):
+    """Per entry point: (bound, algorithmic flops per LR pixel per step, algorithmic HBM bytes per LR pixel per
+    step) summed over that entry point's launches in one step.  Flops: 2*Cin*Cout per 1x1 conv / linear,
+    2*9 per depthwise output, 256*S per token for the two attention products (x2.5 in the backward, which
+    recomputes the scores).  Bytes: tensors each launch must read + write once, fp32."""
+    lin = 2 * (64 * 192 + 64 * 64 + 64 * 32 + 32 * 64)
+    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64 + 64 * 64 + 192 * 64) + (64 * 64 + 128 * 64) + 2 * 64 * 64 + 64 * 64
+    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64) + (64 + 64) + (192 + 64)) + (64 * 3 + 128 + 64)
+                    + 2 * (64 + 64) + 64 * 3)
     return {
-        "ksr_stem_fwd": 2 * 64 * 128 + 2 * 9 + 2 + 2 * 64,
-        "ksr_gate_pw_fwd": 2 * 64 * 64 + 2 * 9 * 64 + 64,
-        "ksr_pointwise_fwd": 2 * 64 * 96,                       # one 64->64 and one 64->128 launch: mean
-        "ksr_dwrelu_pw_fwd": 2 * 64 * 64 + 2 * 9 * 64,
-        "ksr_batch_tx_layer_fwd": 2 * (64 * 192 + 64 * 64 + 64 * 32 + 32 * 64) + 256 * S,
-        "ksr_feed_kan_fwd": 2 * 64 * P + 400,
-        "ksr_bilinear_up": 0,
-    }.get(name, 0)
+        "ksr_stem_fwd": ("mfma", 2 * 64 * 128 + 150, 4 + 512),
+        "ksr_gate_pw_fwd": ("mfma", 2 * (2 * 64 * 64 + 2 * 9 * 64 + 64), 2 * (512 + 256)),
+        "ksr_pointwise_fwd": ("mfma", 2 * 64 * 64 + 2 * 64 * 128, (256 + 256) + (256 + 512)),
+        "ksr_dwrelu_pw_fwd": ("mfma", 2 * 64 * 64 + 2 * 9 * 64, 512),
+        "ksr_batch_tx_layer_fwd": ("mfma", 2 * (lin + 256 * S), 2 * 512),
+        "ksr_feed_kan_fwd": ("mfma", 2 * 64 * P + 400, 256 + 4 + 4 * 16),
+        "ksr_batch_tx_layer_bwd_attn": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192)),
+        "ksr_batch_tx_layer_bwd_token": ("mfma", 2 * 2 * (64 * 32 + 32 * 64 + 64 * 64), 2 * 4 * (64 * 4 + 32 + 64 * 5 + 32)),
+        "ksr_wgrad": ("hbm", 2 * wg_jk, wg_bytes),
+        "ksr_bilinear_up": ("hbm", 0, 8 + 8 * 16),
+    }
 
 
 def build_model(upscale=4, G=5, k=3, seed=0):
@@ -91,7 +102,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "infer"), choices=["infer", "train"])
+    ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -160,6 +171,7 @@ def main():
 
     roofline = None
     cpu = None
+    inference = None
     if rank == 0:
         # ---- per-kernel live timing (events on the launch stream), separate short run ----
         _lib.PROFILE = {}
@@ -173,21 +185,41 @@ def main():
         dom = max(totals, key=totals.get)
         avg_ms = sum(prof[dom]) / len(prof[dom])
         P = 16 * (5 + 3 + 2)
-        fl = flops_per_pixel(dom, B, P) * B * H * W
-        if dom.endswith("_bwd") or dom.endswith("_wgrad"):
-            fl = None
-        if fl:
-            ach = fl / (avg_ms * 1e-3) / 1e12
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
-                        "avg_launch_ms": round(avg_ms, 4),
-                        "ms_per_step_by_entry_point": {k: round(v, 4) for k, v in sorted(totals.items())}}
-        else:
-            roofline = {"kernel": dom, "bound": "mfma", "achieved": None, "peak": PEAK_MFMA_F32_TFLOPS,
-                        "unit": "TFLOP/s", "frac": None, "traffic": None, "avg_launch_ms": round(avg_ms, 4),
-                        "ms_per_step_by_entry_point": {k: round(v, 4) for k, v in sorted(totals.items())}}
+        kmodel = kernel_models(B, P).get(dom)
+        npx = B * H * W
+        roofline = {"kernel": dom, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
+                    "traffic": None}
+        if kmodel is not None:
+            bound, fl, by = kmodel
+            t = totals[dom] * 1e-3
+            if bound == "mfma":
+                ach = fl * npx / t / 1e12
+                roofline.update(bound="mfma", achieved=round(ach, 3), peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s",
+                                frac=round(ach / PEAK_MFMA_F32_TFLOPS, 4))
+            else:
+                ach = by * npx / t / 1e9
+                roofline.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                frac=round(ach / PEAK_HBM_GBS, 4))
+        roofline["avg_launch_ms"] = round(avg_ms, 4)
+        roofline["launches_per_step"] = len(prof[dom]) // nlaunch
+        roofline["ms_per_step_by_entry_point"] = {k: round(v, 4) for k, v in sorted(totals.items())}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload)
+        if world == 1 and args.workload == "train":
+            # second half of the headline metric: 1-GPU x4 inference of one 960x540 -> 3840x2160 frame
+            model.eval()
+            xi = torch.rand(1, 3, 540, 960, device=dev)
+            with torch.no_grad():
+                for _ in range(5):
+                    model(xi)
+                torch.cuda.synchronize()
+                ti = time.perf_counter()
+                for _ in range(20):
+                    model(xi)
+                torch.cuda.synchronize()
+            ti = (time.perf_counter() - ti) / 20
+            inference = {"value": round(3840 * 2160 / 1e6 / ti, 1), "unit": "MP/s", "ms_per_frame": round(ti * 1e3, 4),
+                         "workload": "x4 SR inference fp32 eval, 960x540 -> 3840x2160, 1 GPU (BASELINE configs[1])"}
 
     if dist is not None:
         dist.barrier()
@@ -199,7 +231,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic", "config": {"workload": wl, "upscale": 4, "grid_size": 5, "spline_order": 3,
                                             "per_gpu_batch": B, "lr_patch": [H, W]},
-            "roofline": roofline, "cpu_baseline": cpu}))
+            "roofline": roofline, "cpu_baseline": cpu, "inference": inference}))
 
 
 if __name__ == "__main__":

@@ -118,7 +118,7 @@ class TrainStep:
         self.comm = comm
         if world_size > 1 and comm is None:
             self.comm = RcclComm(rank, world_size)
-        self.side = torch.cuda.Stream(device=dev) if world_size > 1 else None
+        self.side = torch.cuda.Stream(device=dev) if self.comm is not None else None
         self.slab = torch.empty(256, device=dev, dtype=torch.float32)
         self.loss = torch.zeros(1, device=dev, dtype=torch.float32)
         self.last_seed = 0

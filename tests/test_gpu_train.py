@@ -129,3 +129,31 @@ def test_dropout_backward_uses_same_masks():
     fd = (lp - lm) / (2 * eps)
     an = float((gflat * d).sum())
     assert abs(fd - an) <= 0.08 * max(abs(an), abs(fd)) + 2e-4, (fd, an)
+
+
+def test_rccl_path_single_rank_matches_no_comm_path():
+    """The RCCL wrapper + two-bucket side-stream schedule with a 1-rank communicator must give exactly the
+    parameters of the communicator-free step (sum over one rank, scale 1)."""
+    import torch.distributed as dist
+    from kan_sr.train import RcclComm, TrainStep
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        torch.manual_seed(4)
+        x = torch.rand(2, 3, 8, 32).cuda()
+        tgt = torch.rand(2, 3, 32, 128).cuda()
+        ma, _ = _model(4, seed=5)
+        mb, _ = _model(4, seed=5)
+        ta = TrainStep(ma.cuda().eval())
+        comm = RcclComm(0, 1)
+        tb = TrainStep(mb.cuda().eval(), world_size=1, rank=0, comm=comm)
+        assert tb.side is not None
+        for _ in range(3):
+            la, lb = ta.step(x, tgt), tb.step(x, tgt)
+        torch.cuda.synchronize()
+        assert float(la) == float(lb)
+        assert torch.equal(ta.flat_p, tb.flat_p)
+        comm.close()
+    finally:
+        dist.destroy_process_group()
