@@ -73,7 +73,8 @@ int ksr_stem_fwd(const float* x_img, int64_t img_batch_stride, const float* pw1_
                  ksr_stream_t stream);
 
 /* 1x1 conv 64 -> n_out with activation act (0 none, 1 ReLU): FFN.pointwise1 (n_out 64, act 0;
- * unet_blocks.py:237) and GatedFFN.fn_1 (n_out 128, act 1; unet_blocks.py:268). in [N,64], out [N,n_out]. */
+ * unet_blocks.py:237), GatedFFN.fn_1 (n_out 128, act 1; unet_blocks.py:268) and the attention in_proj
+ * (n_out 192, act 0; nn.MultiheadAttention in gazetr.py:39). in [N,64], out [N,n_out]. */
 int ksr_pointwise_fwd(const float* in, const float* w, const float* bias, float* out, int n_out, int act,
                       int B, int H, int W, ksr_stream_t stream);
 
@@ -100,6 +101,16 @@ int ksr_gate_pw_fwd(const float* t_in, const float* gate_w, const float* gate_b,
  *   p_drop > 0 enables the four dropout sites (counter-based generator keyed by seed). S <= 128. */
 int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* const* params, float* const* saves, int S,
                            int HW, float eps, float p_drop, uint64_t seed, ksr_stream_t stream);
+
+/* The same layer as three kernels, used for large local batches: ksr_pointwise_fwd(n_out = 192) computes
+ * qkv [N,192] = in_proj(x); ksr_batch_attn_fwd runs the 2-head softmax attention over the S images of every
+ * pixel on the matrix cores (ctx [N,64]); ksr_batch_tx_layer_post_fwd does out_proj, norm1, the MLP, norm2
+ * (and the final norm).  params / saves as for ksr_batch_tx_layer_fwd (params[0..1], saves[0..1] unused). */
+int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, float p_drop, uint64_t seed,
+                       ksr_stream_t stream);
+int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, float* out, const float* const* params,
+                                float* const* saves, int64_t N, float eps, float p_drop, uint64_t seed,
+                                ksr_stream_t stream);
 
 /* feed (1x1 conv 64 -> P, gazetr.py:117) + ConvSepKanCell (conv_sep_kan_cells.py:136-156) + PixelShuffle
  * (conv_sep_kan.py:38) fused; the [N,P] coefficient tensor is never written.  in_dim = 1, out_dim =
@@ -139,6 +150,10 @@ int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const* params, co
 /* Attention backward over the S images of each pixel: qkv [N,192], ctx [N,64] (saved), dctx -> dqkv [N,192]. */
 int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, const float* dctx, float* dqkv, int S, int HW,
                                 float p_drop, uint64_t seed, ksr_stream_t stream);
+
+/* The same computation on the matrix cores (used for large S, the backward of ksr_batch_attn_fwd). */
+int ksr_batch_attn_bwd(const float* qkv, const float* ctx, const float* dctx, float* dqkv, int S, int HW,
+                       float p_drop, uint64_t seed, ksr_stream_t stream);
 
 /* ds = resid + dqkv * in_proj_weight; with y_saved != NULL also times y(1-y) (the sigmoid that produced
  * the first transformer layer's input, gazetr.py:107). */

@@ -100,6 +100,35 @@ __device__ __forceinline__ int ksr_bspline_local(float x, const float* __restric
     return m;
 }
 
+// Counter-based uniform in [0,1) for dropout: a 32-bit avalanche hash of (seed, stream, element index).
+// Stateless, so the backward regenerates exactly the masks of the forward.
+__device__ __forceinline__ float ksr_uniform(unsigned long long seed, unsigned stream, unsigned long long idx) {
+    const unsigned s32 = (unsigned)seed * 0x9E3779B1u ^ (unsigned)(seed >> 32) * 0x85EBCA77u ^ (stream * 0xC2B2AE3Du + 0x27D4EB2Fu);
+    unsigned x = (unsigned)idx * 0x9E3779B1u ^ (unsigned)(idx >> 32) * 0x85EBCA77u ^ s32;
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ unsigned ksr_hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+// Dropout on the attention probabilities: one 32-bit base per (query token, head), mixed with the key's
+// image index.  Forward and both backward roles (query side, key side) derive the same bit from it.
+__device__ __forceinline__ unsigned ksr_attn_drop_base(unsigned long long seed, unsigned long long token, int head) {
+    const unsigned long long idx = token * 2ULL + (unsigned)head;
+    const unsigned s32 = (unsigned)seed * 0x9E3779B1u ^ (unsigned)(seed >> 32) * 0x85EBCA77u ^ 0x27D4EB2Fu;
+    return ksr_hash32((unsigned)idx * 0x9E3779B1u ^ (unsigned)(idx >> 32) * 0x85EBCA77u ^ s32);
+}
+__device__ __forceinline__ bool ksr_attn_keep(unsigned base, int key_b, float keep) {
+    const unsigned x = ksr_hash32(base + (unsigned)key_b * 0x9E3779B1u);
+    return (float)(x >> 8) * (1.0f / 16777216.0f) < keep;
+}
+
 __device__ __forceinline__ float ksr_silu(float x) { return x / (1.f + expf(-x)); }
 __device__ __forceinline__ float ksr_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 

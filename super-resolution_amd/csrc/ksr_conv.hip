@@ -208,6 +208,7 @@ extern "C" int ksr_pointwise_fwd(const float* in, const float* w, const float* b
     a.in = in; a.in_ld = 64; a.wt = w; a.bias = bias; a.out = out; a.B = B; a.H = H; a.W = W;
     if (n_out == 64 && act == ACT_NONE) return launch_conv<PRO_PLAIN, 64, ACT_NONE>(a, stream);
     if (n_out == 128 && act == ACT_RELU) return launch_conv<PRO_PLAIN, 128, ACT_RELU>(a, stream);
+    if (n_out == 192 && act == ACT_NONE) return launch_conv<PRO_PLAIN, 192, ACT_NONE>(a, stream);
     ksr_set_error("pointwise_fwd: unsupported (n_out=%d, act=%d)", n_out, act);
     return KSR_ERR_UNSUPPORTED;
 }

@@ -15,6 +15,7 @@ namespace {
 
 struct TxArgs {
     const float* in;    // [S, HW, 64]
+    const float* ctx_in; // POST mode: attention output [N,64]
     float* out;         // [S, HW, 64]
     const float *in_w, *in_b;     // [192, 64], [192]
     const float *out_w, *out_b;   // [64, 64], [64]
@@ -34,24 +35,16 @@ struct TxArgs {
 
 constexpr int KV_LD = 132;        // floats per slot: [h0: k32 v32][h1: k32 v32] + 4 pad
 
+template <bool POST>
 struct __attribute__((aligned(16))) TxSmem {
-    float f_in[6 * 32 * 64];      // 64 -> 192
+    float f_in[POST ? 4 : 6 * 32 * 64];      // 64 -> 192
     float f_out[2 * 32 * 64];     // 64 -> 64
     float f_l1[1 * 32 * 64];      // 64 -> 32
     float f_l2[2 * 16 * 64];      // 32 -> 64
     float b_in[6 * 32], b_out[2 * 32], b_l1[32], b_l2[2 * 32];
     float ln[6][64];              // n1_w, n1_b, n2_w, n2_b, nf_w, nf_b
-    float kv[128 * KV_LD];
+    float kv[POST ? 4 : 128 * KV_LD];
 };
-
-// counter-based uniform in [0,1): hash of (seed, stream, element index)
-__device__ __forceinline__ float ksr_uniform(unsigned long long seed, unsigned stream, unsigned long long idx) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (idx * 8ULL + stream + 1ULL);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
 
 __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* __restrict__ g,
                                           const float* __restrict__ b, int h, float (&y)[32]) {
@@ -64,13 +57,16 @@ __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* 
     }
 }
 
-template <bool TRAIN>
-__global__ void __launch_bounds__(256, 1) tx_layer_fwd_kernel(TxArgs a) {
-    __shared__ TxSmem sm;
+// POST = true: the QKV projection and the attention ran in separate kernels (ksr_pointwise_fwd,
+// ksr_batch_attn_fwd); this kernel starts from ctx and needs neither the QKV weights nor the K/V
+// exchange buffer in LDS (4x the occupancy).
+template <bool TRAIN, bool POST>
+__global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs a) {
+    __shared__ TxSmem<POST> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
 
-    ksr_stage_weights<32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
+    if (!POST) ksr_stage_weights<32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
     ksr_stage_weights<32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, 256);
     ksr_stage_weights<32, 1, false>(sm.f_l1, sm.b_l1, a.l1_w, 64, a.l1_b, MapSplit{16}, MapHL{32}, tid, 256);
     ksr_stage_weights<16, 2, false>(sm.f_l2, sm.b_l2, a.l2_w, 32, a.l2_b, MapHL{32}, MapSplit{16}, tid, 256);
@@ -82,17 +78,19 @@ __global__ void __launch_bounds__(256, 1) tx_layer_fwd_kernel(TxArgs a) {
     __syncthreads();
 
     const int S = a.S, HW = a.HW;
-    const int PPW = 128 / S;                          // pixels per workgroup tile (S <= 128)
-    const int ntiles = (HW + PPW - 1) / PPW;
+    const int PPW = POST ? 128 : 128 / S;             // pixels per workgroup tile (S <= 128)
+    const int ntiles = POST ? (int)(((long)S * HW + 127) / 128) : (HW + PPW - 1) / PPW;
     const int slot = wv * 32 + tok;
     const int b = slot / PPW, pl = slot - b * PPW;
     const float scale = 0.17677669529663687f;         // 1/sqrt(32)
     const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        // POST: no cross-token step is left, tiles are 128 consecutive rows of [S*HW, 64]
         const int p = tile * PPW + pl;
-        const bool live = (b < S) && (p < HW);
-        const long n = live ? ((long)b * HW + p) : 0;
+        const long nrow = (long)tile * 128 + slot;
+        const bool live = POST ? (nrow < (long)S * HW) : ((b < S) && (p < HW));
+        const long n = live ? (POST ? nrow : ((long)b * HW + p)) : 0;
 
         float s0[32];
         if (live) ksr_load32(a.in + n * 64 + 32 * h, s0);
@@ -101,6 +99,10 @@ __global__ void __launch_bounds__(256, 1) tx_layer_fwd_kernel(TxArgs a) {
             for (int i = 0; i < 32; ++i) s0[i] = 0.f;
         }
 
+        float ctx[32];
+        if (POST) {
+            ksr_load32(a.ctx_in + n * 64 + 32 * h, ctx);
+        } else {
         // ---- QKV projection -------------------------------------------------------------
         float q[32];
         {
@@ -130,9 +132,9 @@ __global__ void __launch_bounds__(256, 1) tx_layer_fwd_kernel(TxArgs a) {
         __syncthreads();
 
         // ---- attention over the S images at this pixel, head h --------------------------
-        float ctx[32];
         {
             float m = -INFINITY, l = 0.f;
+            const unsigned dbase = ksr_attn_drop_base(a.seed, (unsigned long long)n, h);
 #pragma unroll
             for (int i = 0; i < 32; ++i) ctx[i] = 0.f;
             for (int j = 0; j < S; ++j) {
@@ -150,8 +152,7 @@ __global__ void __launch_bounds__(256, 1) tx_layer_fwd_kernel(TxArgs a) {
                 if (TRAIN && a.p_drop > 0.f) {
                     // dropout on the attention probabilities (after normalisation in the reference;
                     // the mask commutes with the 1/l scaling)
-                    const unsigned long long e = (((unsigned long long)n * 2 + h) << 8) + (unsigned)j;
-                    pj = ksr_uniform(a.seed, 0u, e) < keep ? pj * inv_keep : 0.f;
+                    pj = ksr_attn_keep(dbase, j, keep) ? pj * inv_keep : 0.f;
                 }
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -167,6 +168,7 @@ __global__ void __launch_bounds__(256, 1) tx_layer_fwd_kernel(TxArgs a) {
             if (TRAIN && a.sv_ctx && live) ksr_store32(a.sv_ctx + n * 64 + 32 * h, ctx);
         }
 
+        }
         // ---- out projection + residual + LayerNorm 1 -------------------------------------
         float s1[32];
         {
@@ -265,8 +267,36 @@ extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* 
     const int PPW = 128 / S;
     const int ntiles = (HW + PPW - 1) / PPW;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    if (saves || p_drop > 0.f) hipLaunchKernelGGL(tx_layer_fwd_kernel<true>, dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(tx_layer_fwd_kernel<false>, dim3(grid), dim3(256), 0, stream, a);
+    if (saves || p_drop > 0.f) hipLaunchKernelGGL((tx_layer_fwd_kernel<true, false>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((tx_layer_fwd_kernel<false, false>), dim3(grid), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("batch_tx_layer_fwd");
+    return KSR_OK;
+}
+
+// The same layer after its attention: in = layer input (residual), ctx = attention output
+// (ksr_batch_attn_fwd).  params as ksr_batch_tx_layer_fwd (entries 0, 1 unused); saves[0], saves[1] unused.
+extern "C" int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, float* out, const float* const* params,
+                                           float* const* saves, int64_t N, float eps, float p_drop, uint64_t seed,
+                                           hipStream_t stream) {
+    KSR_CHECK_ARG(in && ctx && out && params && N > 0, "batch_tx_layer_post_fwd: bad argument");
+    KSR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "batch_tx_layer_post_fwd: dropout p must be in [0,1)");
+    for (int i = 2; i < 12; ++i) KSR_CHECK_ARG(params[i] != nullptr, "batch_tx_layer_post_fwd: params[%d] is null", i);
+    TxArgs a{};
+    a.in = in; a.ctx_in = ctx; a.out = out;
+    a.out_w = params[2]; a.out_b = params[3];
+    a.l1_w = params[4]; a.l1_b = params[5]; a.l2_w = params[6]; a.l2_b = params[7];
+    a.n1_w = params[8]; a.n1_b = params[9]; a.n2_w = params[10]; a.n2_b = params[11];
+    a.nf_w = params[12]; a.nf_b = params[13];
+    KSR_CHECK_ARG((a.nf_w == nullptr) == (a.nf_b == nullptr), "batch_tx_layer_post_fwd: final norm needs weight and bias");
+    if (saves) {
+        a.sv_xhat1 = saves[2]; a.sv_rstd1 = saves[3]; a.sv_s1 = saves[4];
+        a.sv_hmid = saves[5]; a.sv_xhat2 = saves[6]; a.sv_rstd2 = saves[7]; a.sv_xhatf = saves[8]; a.sv_rstdf = saves[9];
+    }
+    a.S = 1; a.HW = (int)N; a.eps = eps; a.p_drop = p_drop; a.seed = seed;
+    const long ntiles = (N + 127) / 128;
+    const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
+    if (saves || p_drop > 0.f) hipLaunchKernelGGL((tx_layer_fwd_kernel<true, true>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((tx_layer_fwd_kernel<false, true>), dim3(grid), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("batch_tx_layer_post_fwd");
     return KSR_OK;
 }

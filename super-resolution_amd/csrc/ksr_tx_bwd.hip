@@ -9,14 +9,6 @@
 
 namespace {
 
-__device__ __forceinline__ float ksr_uniform(unsigned long long seed, unsigned stream, unsigned long long idx) {
-    unsigned long long z = seed + 0x9E3779B97F4A7C15ULL * (idx * 8ULL + stream + 1ULL);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
-}
-
 struct TxBwdTokArgs {
     const float* dy;                          // [N,64] gradient of the layer output
     const float *xhatf, *rstdf, *nf_w;        // final LayerNorm (optional: nf_w == null -> absent)
@@ -214,8 +206,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
             }
             const float pj = expf(sc - m) * inv_l;
             if (drop) {
-                const unsigned long long e = (((unsigned long long)n * 2 + h) << 8) + (unsigned)j;
-                dp = ksr_uniform(a.seed, 0u, e) < keep ? dp * inv_keep : 0.f;
+                dp = ksr_attn_keep(ksr_attn_drop_base(a.seed, (unsigned long long)n, h), j, keep) ? dp * inv_keep : 0.f;
             }
             const float dS = pj * (dp - D) * scale;
 #pragma unroll
@@ -256,8 +247,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
             float pt = pij;
             if (drop) {
                 const long ni = (long)i * HW + p;          // global token index of query i
-                const unsigned long long e = (((unsigned long long)ni * 2 + h) << 8) + (unsigned)b;
-                const bool kept = ksr_uniform(a.seed, 0u, e) < keep;
+                const bool kept = ksr_attn_keep(ksr_attn_drop_base(a.seed, (unsigned long long)ni, h), b, keep);
                 pt = kept ? pij * inv_keep : 0.f;
                 dp = kept ? dp * inv_keep : 0.f;
             }

@@ -78,8 +78,10 @@ EXPORTS = [
     "ksr_version", "ksr_last_error",
     "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",
     "ksr_stem_fwd", "ksr_pointwise_fwd", "ksr_dwrelu_pw_fwd", "ksr_gate_pw_fwd",
-    "ksr_batch_tx_layer_fwd", "ksr_feed_kan_supported", "ksr_feed_kan_fwd",
+    "ksr_batch_tx_layer_fwd", "ksr_batch_attn_fwd", "ksr_batch_tx_layer_post_fwd",
+    "ksr_feed_kan_supported", "ksr_feed_kan_fwd",
     "ksr_feed_kan_lane_len", "ksr_feed_kan_bwd", "ksr_batch_tx_layer_bwd_token", "ksr_batch_tx_layer_bwd_attn",
+    "ksr_batch_attn_bwd",
     "ksr_in_proj_bwd", "ksr_gate_pw_bwd", "ksr_fn1_bwd", "ksr_pw2_bwd", "ksr_pw1_bwd",
     "ksr_wgrad_slab_floats", "ksr_wgrad", "ksr_colreduce", "ksr_dwconv_wgrad", "ksr_stem_scalar_wgrad", "ksr_outer2",
     "ksr_l1_y_loss", "ksr_adam_step", "ksr_comm_unique_id", "ksr_comm_init", "ksr_allreduce_sum", "ksr_comm_nranks",

@@ -16,6 +16,9 @@ from ._lib import KsrError, check, host_floats, lib, ptr, stream
 from .ops import bilinear_up_into, make_knots
 
 LN_EPS = 1e-5
+# local batch above which the transformer layer runs as QKV GEMM + MFMA attention + post kernel instead of the
+# single fused kernel (whose VALU attention is cheaper for short sequences)
+SPLIT_ATTENTION_ABOVE = 16
 TX_PARAM_NAMES = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
                   "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
                   "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
@@ -110,12 +113,25 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
                       xhatf=new(N, 64) if last else None, rstdf=new(N) if last else None)
             sv["in"] = s
             saves[f"tx{li}"] = sv
-        sv_arr = _ptr_array([sv[k] for k in ("qkv", "ctx", "xhat1", "rstd1", "s1", "hmid", "xhat2", "rstd2",
-                                             "xhatf", "rstdf")]) if keep else None
-        check(L.ksr_batch_tx_layer_fwd(ptr(s), ptr(out), _ptr_array(plist), sv_arr, c_int(g.B),
-                                       c_int(g.H * g.W), c_float(LN_EPS), c_float(p_drop),
-                                       c_uint64((seed * 4 + li) & 0xFFFFFFFFFFFFFFFF), stream()),
-              "ksr_batch_tx_layer_fwd")
+        names = ("qkv", "ctx", "xhat1", "rstd1", "s1", "hmid", "xhat2", "rstd2", "xhatf", "rstdf")
+        lseed = c_uint64((seed * 4 + li) & 0xFFFFFFFFFFFFFFFF)
+        if g.B > SPLIT_ATTENTION_ABOVE:
+            # large local batch: QKV projection, MFMA attention and the rest of the layer as three kernels
+            qkv = sv["qkv"] if keep else new(N, 192)
+            ctx = sv["ctx"] if keep else new(N, 64)
+            check(L.ksr_pointwise_fwd(ptr(s), ptr(plist[0]), ptr(plist[1]), ptr(qkv), c_int(192), c_int(0),
+                                      *_dims(g), stream()), "ksr_pointwise_fwd")
+            check(L.ksr_batch_attn_fwd(ptr(qkv), ptr(ctx), c_int(g.B), c_int(g.H * g.W), c_float(p_drop), lseed,
+                                       stream()), "ksr_batch_attn_fwd")
+            sv_arr = _ptr_array([None, None] + [sv[k] for k in names[2:]]) if keep else None
+            check(L.ksr_batch_tx_layer_post_fwd(ptr(s), ptr(ctx), ptr(out), _ptr_array(plist), sv_arr, c_int64(N),
+                                                c_float(LN_EPS), c_float(p_drop), lseed, stream()),
+                  "ksr_batch_tx_layer_post_fwd")
+        else:
+            sv_arr = _ptr_array([sv[k] for k in names]) if keep else None
+            check(L.ksr_batch_tx_layer_fwd(ptr(s), ptr(out), _ptr_array(plist), sv_arr, c_int(g.B),
+                                           c_int(g.H * g.W), c_float(LN_EPS), c_float(p_drop), lseed, stream()),
+                  "ksr_batch_tx_layer_fwd")
         s = out
     if keep:
         saves["feat"] = s

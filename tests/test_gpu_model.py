@@ -221,3 +221,66 @@ def test_backward_is_bitwise_reproducible():
         runs.append({n: prm.grad.clone() for n, prm in m.named_parameters()})
     for n in runs[0]:
         assert torch.equal(runs[0][n], runs[1][n]), n
+
+
+@pytest.mark.parametrize("S", [17, 32, 33, 64, 100, 128])
+@pytest.mark.parametrize("HW", [5, 37])
+def test_mfma_attention_split_layer_vs_oracle(S, HW):
+    """Large local batch: QKV GEMM + MFMA attention + post kernel against the oracle layer."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(S * 100 + HW)
+    p = orc.random_params(16, 5, 3, seed=3, scale=2.0)
+    pre = "layers.0.encoder.encoder.encoder.layers.0."
+    s = torch.randn(HW, S, 64)
+    ref = orc.batch_tx_layer(s, p, pre)
+    pc = cuda_params(p)
+    sin = s.permute(1, 0, 2).contiguous().cuda()
+    N = S * HW
+    plist = [pc[pre + n] for n in engine.TX_PARAM_NAMES] + [None, None]
+    qkv = torch.empty(N, 192, device="cuda")
+    ctx = torch.empty(N, 64, device="cuda")
+    out = torch.empty_like(sin)
+    L = lib()
+    check(L.ksr_pointwise_fwd(ptr(sin), ptr(plist[0]), ptr(plist[1]), ptr(qkv), c_int(192), c_int(0), c_int(S), c_int(HW),
+                              c_int(1), stream()), "qkv")
+    check(L.ksr_batch_attn_fwd(ptr(qkv), ptr(ctx), c_int(S), c_int(HW), c_float(0.0), c_uint64(0), stream()), "attn")
+    check(L.ksr_batch_tx_layer_post_fwd(ptr(sin), ptr(ctx), ptr(out), engine._ptr_array(plist), None, c_int64(N),
+                                        c_float(1e-5), c_float(0.0), c_uint64(0), stream()), "post")
+    assert_fwd(out.permute(1, 0, 2), ref, atol=2e-5)
+    # the fused kernel gives the same answer
+    out2 = torch.empty_like(sin)
+    check(L.ksr_batch_tx_layer_fwd(ptr(sin), ptr(out2), engine._ptr_array(plist), None, c_int(S), c_int(HW),
+                                   c_float(1e-5), c_float(0.0), c_uint64(0), stream()), "tx")
+    assert_fwd(out2, out, atol=2e-5)
+
+
+@pytest.mark.parametrize("S,HW", [(3, 41), (8, 20), (20, 9), (32, 6), (64, 5), (100, 3)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.3])
+def test_mfma_attention_matches_valu_attention(S, HW, p_drop):
+    """Forward and backward MFMA attention kernels against the VALU kernels (same dropout masks), and the
+    VALU backward against autograd of the oracle's attention when dropout is off."""
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(S + HW)
+    N = S * HW
+    qkv = torch.randn(N, 192, device="cuda")
+    dctx = torch.randn(N, 64, device="cuda")
+    L = lib()
+    ctx = torch.empty(N, 64, device="cuda")
+    check(L.ksr_batch_attn_fwd(ptr(qkv), ptr(ctx), c_int(S), c_int(HW), c_float(p_drop), c_uint64(99), stream()), "fwd")
+    d1 = torch.empty(N, 192, device="cuda")
+    d2 = torch.empty(N, 192, device="cuda")
+    check(L.ksr_batch_attn_bwd(ptr(qkv), ptr(ctx), ptr(dctx), ptr(d1), c_int(S), c_int(HW), c_float(p_drop), c_uint64(99),
+                               stream()), "bwd mfma")
+    check(L.ksr_batch_tx_layer_bwd_attn(ptr(qkv), ptr(ctx), ptr(dctx), ptr(d2), c_int(S), c_int(HW), c_float(p_drop),
+                                        c_uint64(99), stream()), "bwd valu")
+    assert rel_l2(d1.cpu(), d2.cpu()) <= 2e-5
+    if p_drop == 0.0:
+        x = qkv.cpu().reshape(S, HW, 3, 2, 32).permute(2, 1, 3, 0, 4).clone().requires_grad_()   # [3, HW, head, S, 32]
+        q, k, v = x[0], x[1], x[2]
+        att = torch.softmax(q @ k.transpose(-1, -2) / 32 ** 0.5, -1)
+        o = (att @ v).permute(2, 0, 1, 3).reshape(N, 64)
+        assert_fwd(ctx, o.detach(), atol=2e-5)
+        o.backward(dctx.cpu())
+        ref = x.grad.permute(3, 1, 0, 2, 4).reshape(N, 192)
+        assert rel_l2(d1.cpu(), ref) <= 1e-5
