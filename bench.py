@@ -104,6 +104,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "fp32"), choices=["fp32", "bf16"],
+                    help="MFMA operand precision of the training workload (inference is always fp32)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -138,6 +140,7 @@ def main():
         from kan_sr.train import TrainStep
         B, H, W = 64, 128, 128
         model.train()
+        model.precision = args.precision
         x = torch.rand(B, 3, H, W, device=dev)
         tgt = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
         ts = TrainStep(model, world_size=world, rank=rank)
@@ -208,6 +211,7 @@ def main():
         if world == 1 and args.workload == "train":
             # second half of the headline metric: 1-GPU x4 inference of one 960x540 -> 3840x2160 frame
             model.eval()
+            model.precision = "fp32"
             xi = torch.rand(1, 3, 540, 960, device=dev)
             with torch.no_grad():
                 for _ in range(5):

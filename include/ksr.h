@@ -29,6 +29,14 @@ typedef struct ihipStream_t* ksr_stream_t; /* == hipStream_t */
 int ksr_version(void);
 const char* ksr_last_error(void);
 
+/* MFMA operand precision of every 1x1-conv / linear GEMM kernel below: 0 = exact fp32 (the mode in which
+ * parity with the reference's fp32 results is stated), 1 = bf16 operands with fp32 accumulation (the
+ * reference has no such mode; separately stated tolerance).  HBM storage, the spline basis, LayerNorm,
+ * softmax, the attention products and the weight-gradient reductions stay fp32 in both modes.
+ * Process-wide, read at launch time. */
+int ksr_set_precision(int prec);
+int ksr_get_precision(void);
+
 /* KAN cell with the per-pixel parameter tensor materialised.
  * Replaces ConvSepKanCell.forward (conv_sep_kan/conv_sep_kan_cells.py:136-156), KANLayer.__call__
  * (conv_sep_kan/kan_layer.py:153-162), compute_bspline (conv_sep_kan/bspline.py:4-28) and, when

@@ -14,3 +14,16 @@ void ksr_set_error(const char* fmt, ...) {
 extern "C" const char* ksr_last_error(void) { return g_err; }
 
 extern "C" int ksr_version(void) { return 100; }
+
+// MFMA operand precision of the GEMM kernels (0 = exact fp32, 1 = bf16 operands / fp32 accumulate).
+// Process-wide, read at launch time; the caller sets it before a forward/backward sequence.
+static int g_prec = 0;
+int ksr_prec() { return g_prec; }
+
+extern "C" int ksr_set_precision(int prec) {
+    KSR_CHECK_ARG(prec == 0 || prec == 1, "set_precision: 0 (fp32) or 1 (bf16 MFMA operands)");
+    g_prec = prec;
+    return KSR_OK;
+}
+
+extern "C" int ksr_get_precision(void) { return g_prec; }

@@ -36,13 +36,13 @@ struct __attribute__((aligned(16))) BwdSmem {
     float halo[BPRO == BPRO_PLAIN ? 4 : HALO_FLOATS];
 };
 
-template <int KIN, int BPRO, int BEPI>
+template <int PREC, int KIN, int BPRO, int BEPI>
 __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     constexpr int KH = KIN / 2;
     __shared__ BwdSmem<KIN, BPRO> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
-    ksr_stage_weights<KH, 2, true>(sm.frag, nullptr, a.wt, 64, nullptr, MapHL{32}, MapHL{KH}, tid, 256);
+    ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.wt, 64, nullptr, MapHL{32}, MapHL{KH}, tid, 256);
     if (BPRO != BPRO_PLAIN) ksr_stage_dw<true>(sm.dww, a.dw_w, tid);
     if (BEPI == BEPI_STEM && tid < 64) sm.p2w[tid] = a.p2w[tid];
     __syncthreads();
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         // phase fences: keep the epilogue's loads from being hoisted above the GEMM (register pressure)
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[2];
-        ksr_wave_gemm<KH, 2>(sm.frag, nullptr, dz, acc, lane);
+        ksr_wave_gemm<PREC, KH, 2>(sm.frag, nullptr, dz, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
         if (BPRO != BPRO_PLAIN) {
             // the conv-transposed gradient is also an output (stored here, after the GEMM: a conditional
@@ -150,15 +150,20 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     }
 }
 
-template <int KIN, int BPRO, int BEPI>
-int launch_dgrad(const BwdArgs& a, hipStream_t s) {
+template <int PREC, int KIN, int BPRO, int BEPI>
+int launch_dgrad_p(const BwdArgs& a, hipStream_t s) {
     const long N = (long)a.B * a.H * a.W;
     const bool spatial = BPRO != BPRO_PLAIN;
     const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
     const long cap = spatial ? 512 : 768;
-    hipLaunchKernelGGL((dgrad_kernel<KIN, BPRO, BEPI>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dgrad_kernel<PREC, KIN, BPRO, BEPI>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("dgrad");
     return KSR_OK;
+}
+
+template <int KIN, int BPRO, int BEPI>
+int launch_dgrad(const BwdArgs& a, hipStream_t s) {
+    return ksr_prec() == KSR_BF16 ? launch_dgrad_p<KSR_BF16, KIN, BPRO, BEPI>(a, s) : launch_dgrad_p<KSR_F32, KIN, BPRO, BEPI>(a, s);
 }
 
 int dims_ok(int B, int H, int W, const char* who) {

@@ -52,14 +52,14 @@ __device__ __forceinline__ float apply_act(float v) {
     return v;
 }
 
-template <int PRO, int NOUT, int ACT>
+template <int PREC, int PRO, int NOUT, int ACT>
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
     constexpr int NB = NOUT / 32;   // 16-register blocks per lane half (NOUT/2 outputs per half)
     __shared__ ConvSmem<PRO, NB> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
 
-    ksr_stage_weights<32, NB, false>(sm.frag, sm.biasfrag, a.wt, 64, a.bias, MapHL{NOUT / 2}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.wt, 64, a.bias, MapHL{NOUT / 2}, MapHL{32}, tid, 256);
     if (PRO == PRO_DWRELU || PRO == PRO_GATE) {
         ksr_stage_dw<false>(sm.dww, a.dw_w, tid);
         if (tid < 64) sm.dwb[tid] = a.dw_b[tid];
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
         }
 
         f32x16 acc[NB];
-        ksr_wave_gemm<32, NB>(sm.frag, sm.biasfrag, op, acc, lane);
+        ksr_wave_gemm<PREC, 32, NB>(sm.frag, sm.biasfrag, op, acc, lane);
 
         if (live) {
 #pragma unroll
@@ -166,16 +166,21 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
     }
 }
 
-template <int PRO, int NOUT, int ACT>
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+template <int PREC, int PRO, int NOUT, int ACT>
+int launch_conv_p(const ConvArgs& a, hipStream_t s) {
     const bool spatial = (PRO == PRO_DWRELU || PRO == PRO_GATE);
     const long N = (long)a.B * a.H * a.W;
     const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
     const long cap = spatial ? 512 : 1024;
     const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
-    hipLaunchKernelGGL((conv_fwd_kernel<PRO, NOUT, ACT>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<PREC, PRO, NOUT, ACT>), dim3(grid), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("conv_fwd");
     return KSR_OK;
+}
+
+template <int PRO, int NOUT, int ACT>
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    return ksr_prec() == KSR_BF16 ? launch_conv_p<KSR_BF16, PRO, NOUT, ACT>(a, s) : launch_conv_p<KSR_F32, PRO, NOUT, ACT>(a, s);
 }
 
 int check_dims(int B, int H, int W, const char* who) {

@@ -62,14 +62,14 @@ struct __attribute__((aligned(16))) FeedSmem {
     float knots[KSR_MAX_KNOTS];
 };
 
-template <int R, int KC, int KORD>
+template <int PREC, int R, int KC, int KORD>
 __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKnots kn) {
     using C = FeedCfg<R, KC>;
     constexpr int NB = C::NB;
     __shared__ FeedSmem<NB> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
-    ksr_stage_weights<32, NB, false>(sm.frag, sm.biasfrag, a.w, 64, a.bias, MapKan{C::O, KC}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.w, 64, a.bias, MapKan{C::O, KC}, MapHL{32}, tid, 256);
     if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
     __syncthreads();
 
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
             for (int i = 0; i < 32; ++i) f[i] = 0.f;
         }
         f32x16 acc[NB];
-        ksr_wave_gemm<32, NB>(sm.frag, sm.biasfrag, f, acc, lane);
+        ksr_wave_gemm<PREC, 32, NB>(sm.frag, sm.biasfrag, f, acc, lane);
 
         const float xv = live ? a.x_img[(long)b * a.img_bstride + hw] : 0.f;
         float Nv[KSR_MAX_ORDER + 1], bv[KC];
@@ -136,7 +136,8 @@ int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
     const long N = (long)a.B * a.H * a.W;
     const long ntiles = (N + 127) / 128;
     const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);
-    hipLaunchKernelGGL((feed_kan_fwd_kernel<R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
+    if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((feed_kan_fwd_kernel<KSR_BF16, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
+    else hipLaunchKernelGGL((feed_kan_fwd_kernel<KSR_F32, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
     KSR_LAUNCH_CHECK("feed_kan_fwd");
     return KSR_OK;
 }
@@ -149,14 +150,14 @@ struct __attribute__((aligned(16))) FeedBwdSmem {
 
 // Backward: dparam[e] per lane (lane order), dfeat = dparam * W_feed, both stored; the feed weight
 // gradient is a separate reduction over pixels (ksr_wgrad with the KAN row map).
-template <int R, int KC, int KORD>
+template <int PREC, int R, int KC, int KORD>
 __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKnots kn) {
     using C = FeedCfg<R, KC>;
     constexpr int NB = C::NB, KH = NB * 16;
     __shared__ FeedBwdSmem<NB> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
-    ksr_stage_weights<KH, 2, true>(sm.frag, nullptr, a.w, 64, nullptr, MapHL{32}, MapKan{C::O, KC}, tid, 256);
+    ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.w, 64, nullptr, MapHL{32}, MapKan{C::O, KC}, tid, 256);
     if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
     __syncthreads();
 
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
             for (int q = 0; q < KH / 4; ++q) gp4[q] = make_float4(dp[4 * q], dp[4 * q + 1], dp[4 * q + 2], dp[4 * q + 3]);
         }
         f32x16 acc[2];
-        ksr_wave_gemm<KH, 2>(sm.frag, nullptr, dp, acc, lane);
+        ksr_wave_gemm<PREC, KH, 2>(sm.frag, nullptr, dp, acc, lane);
         if (live) {
             float df[32];
 #pragma unroll
@@ -231,7 +232,8 @@ int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
     const long N = (long)a.B * a.H * a.W;
     const long ntiles = (N + 127) / 128;
     const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
-    hipLaunchKernelGGL((feed_kan_bwd_kernel<R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
+    if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((feed_kan_bwd_kernel<KSR_BF16, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
+    else hipLaunchKernelGGL((feed_kan_bwd_kernel<KSR_F32, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
     KSR_LAUNCH_CHECK("feed_kan_bwd");
     return KSR_OK;
 }

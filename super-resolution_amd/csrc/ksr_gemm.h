@@ -21,6 +21,12 @@
 
 #define KSR_WAVE 64
 
+// MFMA operand precision of ksr_wave_gemm: exact fp32 (v_mfma_f32_32x32x2_f32) or bf16 operands with fp32
+// accumulation (v_mfma_f32_32x32x16_bf16, 16x the rate).  Storage in HBM and all other arithmetic stay fp32.
+enum { KSR_F32 = 0, KSR_BF16 = 1 };
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+int ksr_prec();   // process-wide setting (ksr_set_precision)
+
 // D row of a 32x32 MFMA block held by (lane half h, register q): (q&3) + 8*(q>>2) + 4*h.
 // Inverse: for A-operand row rho, the result lands on half (rho>>2)&1, register (rho&3)+4*(rho>>3).
 __device__ __forceinline__ int ksr_row_half(int rho) { return (rho >> 2) & 1; }
@@ -58,25 +64,29 @@ __host__ __device__ constexpr int ksr_bias_floats(int NB) { return NB * 32; }
 // fragment order.  frag[((blk*(KH/4) + s/4)*64 + lane)*4 + s%4] = W(out(h(rho), 16*blk+q(rho)), in(hh, s))
 // for lane = rho + 32*hh.  biasfrag[(blk*2 + h)*16 + q] = bias[out(h, 16*blk+q)].
 // Called by all threads of the workgroup; caller synchronises afterwards.
-template <int KH, int NB, bool TRANS, class OutMap, class InMap>
+template <int PREC, int KH, int NB, bool TRANS, class OutMap, class InMap>
 __device__ __forceinline__ void ksr_stage_weights(float* __restrict__ frag, float* __restrict__ biasfrag,
                                                   const float* __restrict__ W, int ldw,
                                                   const float* __restrict__ bias, OutMap om, InMap im,
                                                   int tid, int nthreads) {
-    static_assert(KH % 4 == 0, "KH must be a multiple of 4");
+    static_assert(KH % 8 == 0, "KH must be a multiple of 8");
     const int total = NB * KH * 64;
+    __bf16* frag16 = reinterpret_cast<__bf16*>(frag);
     for (int idx = tid; idx < total; idx += nthreads) {
-        const int s_lo = idx & 3;
-        const int lane = (idx >> 2) & 63;
-        const int rest = idx >> 8;             // blk*(KH/4) + s/4
-        const int s = (rest % (KH / 4)) * 4 + s_lo;
-        const int blk = rest / (KH / 4);
+        // fp32: idx = ((blk*(KH/4) + s/4)*64 + lane)*4 + s%4 ; bf16: ((blk*(KH/8) + s/8)*64 + lane)*8 + s%8
+        constexpr int G = (PREC == KSR_BF16) ? 8 : 4;
+        const int s_lo = idx % G;
+        const int lane = (idx / G) & 63;
+        const int rest = idx / (G * 64);
+        const int s = (rest % (KH / G)) * G + s_lo;
+        const int blk = rest / (KH / G);
         const int rho = lane & 31, hh = lane >> 5;
         const int o = om(ksr_row_half(rho), 16 * blk + ksr_row_reg(rho));
         const int i = im(hh, s);
         float v = 0.f;
         if (o >= 0 && i >= 0) v = TRANS ? W[(long)i * ldw + o] : W[(long)o * ldw + i];
-        frag[idx] = v;
+        if (PREC == KSR_BF16) frag16[idx] = (__bf16)v;
+        else frag[idx] = v;
     }
     if (biasfrag) {
         for (int idx = tid; idx < NB * 32; idx += nthreads) {
@@ -88,7 +98,7 @@ __device__ __forceinline__ void ksr_stage_weights(float* __restrict__ frag, floa
 }
 
 // acc[blk] = bias + sum_s W_frag * x.  x[s] is this lane's input for k-step s.
-template <int KH, int NB>
+template <int PREC, int KH, int NB>
 __device__ __forceinline__ void ksr_wave_gemm(const float* __restrict__ frag, const float* __restrict__ biasfrag,
                                               const float (&x)[KH], f32x16 (&acc)[NB], int lane) {
     const int h = lane >> 5;
@@ -106,6 +116,29 @@ __device__ __forceinline__ void ksr_wave_gemm(const float* __restrict__ frag, co
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[blk][q] = 0.f;
         }
+    }
+    if (PREC == KSR_BF16) {
+        // activations -> bf16 once; one 16-byte LDS read (8 bf16 of weights) per MFMA
+        bf16x8 xb[KH / 8];
+#pragma unroll
+        for (int s8 = 0; s8 < KH / 8; ++s8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xb[s8][j] = (__bf16)x[8 * s8 + j];
+        const bf16x8* w8 = reinterpret_cast<const bf16x8*>(frag) + lane;
+        bf16x8 w = w8[0];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+            for (int s8 = 0; s8 < KH / 8; ++s8) {
+                constexpr int last = NB * (KH / 8) - 1;
+                const int cur = blk * (KH / 8) + s8;
+                const bf16x8 wn = w8[(cur < last ? cur + 1 : last) * 64];
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, xb[s8], acc[blk], 0, 0, 0);
+                w = wn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
     }
     // One 16-byte LDS read feeds four MFMAs (256 cycles of matrix pipe); the next read is issued
     // one group ahead.  The scheduling barrier keeps the compiler from hoisting every fragment read

@@ -60,16 +60,16 @@ __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* 
 // POST = true: the QKV projection and the attention ran in separate kernels (ksr_pointwise_fwd,
 // ksr_batch_attn_fwd); this kernel starts from ctx and needs neither the QKV weights nor the K/V
 // exchange buffer in LDS (4x the occupancy).
-template <bool TRAIN, bool POST>
+template <int PREC, bool TRAIN, bool POST>
 __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs a) {
     __shared__ TxSmem<POST> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
 
-    if (!POST) ksr_stage_weights<32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
-    ksr_stage_weights<32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, 256);
-    ksr_stage_weights<32, 1, false>(sm.f_l1, sm.b_l1, a.l1_w, 64, a.l1_b, MapSplit{16}, MapHL{32}, tid, 256);
-    ksr_stage_weights<16, 2, false>(sm.f_l2, sm.b_l2, a.l2_w, 32, a.l2_b, MapHL{32}, MapSplit{16}, tid, 256);
+    if (!POST) ksr_stage_weights<PREC, 32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 32, 1, false>(sm.f_l1, sm.b_l1, a.l1_w, 64, a.l1_b, MapSplit{16}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 16, 2, false>(sm.f_l2, sm.b_l2, a.l2_w, 32, a.l2_b, MapHL{32}, MapSplit{16}, tid, 256);
     if (tid < 64) {
         sm.ln[0][tid] = a.n1_w[tid]; sm.ln[1][tid] = a.n1_b[tid];
         sm.ln[2][tid] = a.n2_w[tid]; sm.ln[3][tid] = a.n2_b[tid];
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
         float q[32];
         {
             f32x16 acc[6];
-            ksr_wave_gemm<32, 6>(sm.f_in, sm.b_in, s0, acc, lane);
+            ksr_wave_gemm<PREC, 32, 6>(sm.f_in, sm.b_in, s0, acc, lane);
             float kvr[64];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
         float s1[32];
         {
             f32x16 acc[2];
-            ksr_wave_gemm<32, 2>(sm.f_out, sm.b_out, ctx, acc, lane);
+            ksr_wave_gemm<PREC, 32, 2>(sm.f_out, sm.b_out, ctx, acc, lane);
             float u[32], xhat[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { u[i] = acc[0][i]; u[16 + i] = acc[1][i]; }
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
         float s2[32];
         {
             f32x16 acc1[1];
-            ksr_wave_gemm<32, 1>(sm.f_l1, sm.b_l1, s1, acc1, lane);
+            ksr_wave_gemm<PREC, 32, 1>(sm.f_l1, sm.b_l1, s1, acc1, lane);
             float hm[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) hm[i] = acc1[0][i] > 0.f ? acc1[0][i] : 0.f;
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
             }
             if (TRAIN && a.sv_hmid && live) ksr_store16(a.sv_hmid + n * 32 + 16 * h, hm);
             f32x16 acc2[2];
-            ksr_wave_gemm<16, 2>(sm.f_l2, sm.b_l2, hm, acc2, lane);
+            ksr_wave_gemm<PREC, 16, 2>(sm.f_l2, sm.b_l2, hm, acc2, lane);
             float u[32], xhat[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { u[i] = acc2[0][i]; u[16 + i] = acc2[1][i]; }
@@ -267,8 +267,8 @@ extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* 
     const int PPW = 128 / S;
     const int ntiles = (HW + PPW - 1) / PPW;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    if (saves || p_drop > 0.f) hipLaunchKernelGGL((tx_layer_fwd_kernel<true, false>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((tx_layer_fwd_kernel<false, false>), dim3(grid), dim3(256), 0, stream, a);
+    if (saves || p_drop > 0.f) { if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_BF16, true, false>), dim3(grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32, true, false>), dim3(grid), dim3(256), 0, stream, a); }
+    else { if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_BF16, false, false>), dim3(grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32, false, false>), dim3(grid), dim3(256), 0, stream, a); }
     KSR_LAUNCH_CHECK("batch_tx_layer_fwd");
     return KSR_OK;
 }
@@ -295,8 +295,8 @@ extern "C" int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, fl
     a.S = 1; a.HW = (int)N; a.eps = eps; a.p_drop = p_drop; a.seed = seed;
     const long ntiles = (N + 127) / 128;
     const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
-    if (saves || p_drop > 0.f) hipLaunchKernelGGL((tx_layer_fwd_kernel<true, true>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((tx_layer_fwd_kernel<false, true>), dim3(grid), dim3(256), 0, stream, a);
+    if (saves || p_drop > 0.f) { if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_BF16, true, true>), dim3(grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32, true, true>), dim3(grid), dim3(256), 0, stream, a); }
+    else { if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_BF16, false, true>), dim3(grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32, false, true>), dim3(grid), dim3(256), 0, stream, a); }
     KSR_LAUNCH_CHECK("batch_tx_layer_post_fwd");
     return KSR_OK;
 }

@@ -43,13 +43,14 @@ __device__ __forceinline__ void ln_bwd(const float (&dy)[32], const float* __res
     for (int i = 0; i < 32; ++i) dx[i] = rstd * (dxh[i] - m1 - xhat[i] * m2);
 }
 
+template <int PREC>
 __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
     __shared__ TxBwdTokSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
-    ksr_stage_weights<32, 1, true>(sm.f_l2t, nullptr, a.l2_w, 32, nullptr, MapSplit{16}, MapHL{32}, tid, 256);
-    ksr_stage_weights<16, 2, true>(sm.f_l1t, nullptr, a.l1_w, 64, nullptr, MapHL{32}, MapSplit{16}, tid, 256);
-    ksr_stage_weights<32, 2, true>(sm.f_outt, nullptr, a.out_w, 64, nullptr, MapHL{32}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 32, 1, true>(sm.f_l2t, nullptr, a.l2_w, 32, nullptr, MapSplit{16}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 16, 2, true>(sm.f_l1t, nullptr, a.l1_w, 64, nullptr, MapHL{32}, MapSplit{16}, tid, 256);
+    ksr_stage_weights<PREC, 32, 2, true>(sm.f_outt, nullptr, a.out_w, 64, nullptr, MapHL{32}, MapHL{32}, tid, 256);
     if (tid < 64) {
         sm.ln[0][tid] = a.nf_w ? a.nf_w[tid] : 1.f;
         sm.ln[1][tid] = a.n2_w[tid];
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         float dpre[16];
         {
             f32x16 acc[1];
-            ksr_wave_gemm<32, 1>(sm.f_l2t, nullptr, dm, acc, lane);
+            ksr_wave_gemm<PREC, 32, 1>(sm.f_l2t, nullptr, dm, acc, lane);
             float hm[16];
             ksr_load16(a.hmid + n * 32 + 16 * h, hm);
 #pragma unroll
@@ -98,7 +99,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         float ds1[32];
         {
             f32x16 acc[2];
-            ksr_wave_gemm<16, 2>(sm.f_l1t, nullptr, dpre, acc, lane);
+            ksr_wave_gemm<PREC, 16, 2>(sm.f_l1t, nullptr, dpre, acc, lane);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ds1[i] = du2[i] + acc[0][i]; ds1[16 + i] = du2[16 + i] + acc[1][i]; }
             if (live) ksr_store32(a.ds1 + n * 64 + 32 * h, ds1);
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         if (live && drop) ksr_store32(a.da + n * 64 + 32 * h, da);
         {
             f32x16 acc[2];
-            ksr_wave_gemm<32, 2>(sm.f_outt, nullptr, da, acc, lane);
+            ksr_wave_gemm<PREC, 32, 2>(sm.f_outt, nullptr, da, acc, lane);
             float dc[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dc[i] = acc[0][i]; dc[16 + i] = acc[1][i]; }
@@ -290,7 +291,8 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     KSR_CHECK_ARG(!(p_drop > 0.f) || a.da, "batch_tx_layer_bwd_token: dropout needs the da output");
     a.N = (long)N; a.p_drop = p_drop; a.seed = seed;
     const long ntiles = (N + 127) / 128;
-    hipLaunchKernelGGL(tx_bwd_token_kernel, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a);
+    if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL(tx_bwd_token_kernel<KSR_BF16>, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(tx_bwd_token_kernel<KSR_F32>, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token");
     return KSR_OK;
 }

@@ -12,8 +12,7 @@
 namespace {
 
 constexpr int WG_MAXP = 6;     // output blocks per wave
-constexpr int WG_T = 32;       // pixels per staged chunk
-constexpr int WG_GRID = 512;   // at most this many workgroups / partial slabs
+constexpr int WG_GRID = 1024;  // at most this many workgroups / partial slabs
 
 struct WgArgs {
     const float* dz; int dz_ld, dz_c0, J;
@@ -28,6 +27,7 @@ struct WgArgs {
 // loads of chunk c+1 are in flight while the MFMAs of chunk c run.  Operands are then read from LDS with
 // conflict-free ds_read_b32 (lane = column).  Wave w owns column block kb = w % (K/32) of A and the
 // dz blocks jb = w / (K/32) + i * (4 / (K/32)).
+template <int WG_T, int MAXP>   // pixels per staged chunk; output blocks per wave
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -41,10 +41,10 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     const unsigned inv = (unsigned)((0x100000000ULL + RL4 - 1) / RL4);
     const int npass = (WG_T * RL4) / 256;               // RL4 is a multiple of 8: exact
 
-    f32x16 acc[WG_MAXP];
-    float bsum[WG_MAXP];
+    f32x16 acc[MAXP];
+    float bsum[MAXP];
 #pragma unroll
-    for (int p = 0; p < WG_MAXP; ++p) {
+    for (int p = 0; p < MAXP; ++p) {
         bsum[p] = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[p][q] = 0.f;
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
             if (a.a2) bv *= row[a.J + a.K + 32 * kb + col];
             const bool ok = full || (t0 + 2 * u + kk < n1);
 #pragma unroll
-            for (int p = 0; p < WG_MAXP; ++p) {
+            for (int p = 0; p < MAXP; ++p) {
                 if (p < np) {
                     float av = row[32 * (jb0 + p * jbs) + col];
                     av = ok ? av : 0.f;
@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     }
     float* slab = a.slab + (long)blockIdx.x * ((long)a.J * a.K + a.J);
 #pragma unroll
-    for (int p = 0; p < WG_MAXP; ++p) {
+    for (int p = 0; p < MAXP; ++p) {
         if (p < np) {
             const int jb = jb0 + p * jbs;
 #pragma unroll
@@ -339,18 +339,30 @@ extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const flo
                   "wgrad: leading dimensions and channel offsets must be multiples of 4");
     WgArgs a{dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, a2, a2_ld, a2_c0, slab, (long)N};
     const int RL = J + K + (a2 ? K : 0);
-    const size_t lds_bytes = (size_t)2 * WG_T * RL * sizeof(float);
+    // chunk length: 64 pixels while two buffers stay within 64 KiB (more bytes in flight per workgroup), else 32
+    const int T = (2 * 64 * RL * (int)sizeof(float) <= 64 * 1024) ? 64 : 32;
+    const size_t lds_bytes = (size_t)2 * T * RL * sizeof(float);
     KSR_UNSUPPORTED(lds_bytes > 160 * 1024, "wgrad: J=%d needs %zu bytes of LDS", J, lds_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const bool small = per_wave <= 3;
+    const void* fn = T == 64 ? (small ? (const void*)wgrad_kernel<64, 3> : (const void*)wgrad_kernel<64, WG_MAXP>)
+                             : (small ? (const void*)wgrad_kernel<32, 3> : (const void*)wgrad_kernel<32, WG_MAXP>);
+    static bool attr_set[4] = {false, false, false, false};
+    const int fi = (T == 64 ? 0 : 2) + (small ? 0 : 1);
+    if (!attr_set[fi]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { ksr_set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return KSR_ERR_HIP; }
-        attr_set = true;
+        attr_set[fi] = true;
     }
-    long g = (N + 4 * WG_T - 1) / (4 * WG_T);
+    long g = (N + 4 * T - 1) / (4 * T);
     if (g > WG_GRID) g = WG_GRID;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
+    if (lds_bytes > 40 * 1024 && g > WG_GRID / 2) g = WG_GRID / 2;     // 2 workgroups per CU fit
+    if (T == 64) {
+        if (small) hipLaunchKernelGGL((wgrad_kernel<64, 3>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((wgrad_kernel<64, WG_MAXP>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
+    } else {
+        if (small) hipLaunchKernelGGL((wgrad_kernel<32, 3>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((wgrad_kernel<32, WG_MAXP>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
+    }
     KSR_LAUNCH_CHECK("wgrad");
     int kan_O = 0, kan_nbh = 0;
     if (kan_upscale > 0) {

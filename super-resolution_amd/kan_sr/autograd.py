@@ -55,7 +55,7 @@ class _Ws:
 
     def slab(self, nfloats):
         if self._slab is None or self._slab.numel() < nfloats:
-            self._slab = torch.empty(max(nfloats, 512 * (192 * 64 + 192)), device=self.dev, dtype=torch.float32)
+            self._slab = torch.empty(max(nfloats, 1024 * (192 * 64 + 192)), device=self.dev, dtype=torch.float32)
         return self._slab
 
 
@@ -252,7 +252,7 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
 
 class _ConvSepKanFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pre, g, p_drop, seed, names, *params):
+    def forward(ctx, x, pre, g, p_drop, seed, names, precision, *params):
         p = dict(zip(names, params))
         out = torch.empty(g.B, 3, g.H * g.r, g.W * g.r, device=x.device, dtype=torch.float32)
         bilinear_up_into(x, out, g.r, 1, 2, 1)
@@ -261,12 +261,13 @@ class _ConvSepKanFn(torch.autograd.Function):
         save_us = torch.empty(g.N, g.r * g.r, 2, device=x.device, dtype=torch.float32)
         engine.feed_kan_forward(feat, x, p, pre, g, out, save_us)
         ctx.sv, ctx.save_us, ctx.x, ctx.p = sv, save_us, x, p
-        ctx.cfg = (pre, g, p_drop, seed, names)
+        ctx.cfg = (pre, g, p_drop, seed, names, precision)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        pre, g, p_drop, seed, names = ctx.cfg
+        pre, g, p_drop, seed, names, precision = ctx.cfg
+        engine.set_precision(precision)
         if ctx.needs_input_grad[0]:
             raise KsrError("gradient with respect to the input image is not implemented (the training step "
                            "of the reference never needs it)")
@@ -278,10 +279,11 @@ class _ConvSepKanFn(torch.autograd.Function):
         for n, t in zip(names, ctx.p.values()):
             gr = grads.get(n)
             out.append(None if gr is None else gr.reshape(t.shape))
-        return (None, None, None, None, None, None, *out)
+        return (None, None, None, None, None, None, None, *out)
 
 
-def conv_sep_kan_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_drop: float, seed: int):
+def conv_sep_kan_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_drop: float, seed: int,
+                        precision: str = "fp32"):
     names = [pre + n for n in PARAM_ORDER]
     li_prefix = pre[: -len("encoder.encoder.")]
     # p is keyed "layers.L.encoder.encoder.<name>"
@@ -289,4 +291,4 @@ def conv_sep_kan_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_d
     for t in params:
         if not t.is_contiguous():
             raise KsrError("parameters must be contiguous")
-    return _ConvSepKanFn.apply(x, pre, g, p_drop, seed, names, *params)
+    return _ConvSepKanFn.apply(x, pre, g, p_drop, seed, names, precision, *params)

@@ -55,6 +55,17 @@ def _dims(g: Geometry):
     return c_int(g.B), c_int(g.H), c_int(g.W)
 
 
+PRECISIONS = {"fp32": 0, "bf16": 1}
+
+
+def set_precision(name: str) -> None:
+    """MFMA operand precision of the GEMM kernels for the calls that follow: "fp32" (exact, the parity mode)
+    or "bf16" (bf16 operands, fp32 accumulate; storage and everything else stay fp32).  Process-wide."""
+    if name not in PRECISIONS:
+        raise KsrError(f"precision must be one of {sorted(PRECISIONS)}, got {name!r}")
+    check(lib().ksr_set_precision(c_int(PRECISIONS[name])), "ksr_set_precision")
+
+
 def new_seed() -> int:
     """Dropout stream id drawn from torch's CPU generator (follows torch.manual_seed, no GPU sync)."""
     return int(torch.randint(0, 2 ** 62, (1,)).item())

@@ -102,6 +102,9 @@ class ConvSepKan(nn.Module):
         super().__init__()
         self.upscale = upscale
         self.grid_size, self.spline_order, self.grid_range = grid_size, spline_order, list(grid_range)
+        # "fp32": exact fp32 MFMA (parity with the reference to fp32 round-off); "bf16": bf16 MFMA operands with
+        # fp32 accumulation (separately stated tolerance).  Not part of the reference's constructor.
+        self.precision = "fp32"
         self.layers = nn.ModuleList()
         self.shuffle = nn.PixelShuffle(upscale)          # kept for module-tree parity; no parameters
         for in_ch, out_ch in zip(in_channels, out_channels):
@@ -126,6 +129,7 @@ class ConvSepKan(nn.Module):
         g = engine.Geometry(x, self.upscale, self.grid_size, self.spline_order, self.grid_range)
         p = self._params()
         pre = f"layers.{len(self.layers) - 1}.encoder.encoder."
+        engine.set_precision(self.precision)
         needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in p.values())
         p_drop = self.layers[-1].encoder.encoder.encoder.layers[0].p_drop if self.training else 0.0
         seed = engine.new_seed() if p_drop > 0 else 0
@@ -133,4 +137,4 @@ class ConvSepKan(nn.Module):
             with torch.no_grad():
                 return engine.forward_infer(x, p, pre, g, p_drop, seed)
         from .autograd import conv_sep_kan_train
-        return conv_sep_kan_train(x, p, pre, g, p_drop, seed)
+        return conv_sep_kan_train(x, p, pre, g, p_drop, seed, self.precision)

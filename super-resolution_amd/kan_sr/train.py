@@ -127,6 +127,7 @@ class TrainStep:
         """One optimisation step on this rank's shard.  Returns the (device) loss tensor of the shard."""
         L = lib()
         m = self.model
+        engine.set_precision(m.precision)
         x = x.contiguous()
         g = engine.Geometry(x, m.upscale, m.grid_size, m.spline_order, m.grid_range)
         p_drop = m.layers[-1].encoder.encoder.encoder.layers[0].p_drop if m.training else 0.0

@@ -284,3 +284,27 @@ def test_mfma_attention_matches_valu_attention(S, HW, p_drop):
         o.backward(dctx.cpu())
         ref = x.grad.permute(3, 1, 0, 2, 4).reshape(N, 192)
         assert rel_l2(d1.cpu(), ref) <= 1e-5
+
+
+@pytest.mark.parametrize("r,G,k", [(2, 5, 3), (4, 5, 3), (4, 16, 3)])
+def test_bf16_mfma_mode_golden(r, G, k):
+    """bf16 MFMA operands / fp32 accumulate (a build-side mode the reference does not have).  Stated tolerance:
+    forward rel-L2 <= 2e-2 on the Y plane; every parameter gradient of >= 64 elements cosine >= 0.999 and
+    rel-L2 <= 5e-2; the four stem tensors of 1 or 9 elements (sums of ~1e5 cancelling terms, |g| ~ 1e-5)
+    cosine >= 0.99 and rel-L2 <= 0.3."""
+    g, m = _load_model_golden(r, G, k)
+    m.precision = "bf16"
+    y = m(t(g["x"]).cuda())
+    assert rel_l2(y[:, 0].detach().cpu(), t(g["y"])[:, 0]) <= 2e-2
+    assert_fwd(y[:, 1:], t(g["y"])[:, 1:])           # chroma does not go through a GEMM
+    y.backward(t(g["gy"]).cuda())
+    for n, prm in m.named_parameters():
+        got, ref = prm.grad.cpu().flatten().double(), t(g["g." + n]).flatten().double()
+        cos = float((got * ref).sum() / (got.norm() * ref.norm()).clamp_min(1e-30))
+        big = got.numel() >= 64
+        assert cos >= (0.999 if big else 0.99), f"{n}: cos {cos:.5f}"
+        assert rel_l2(got, ref) <= (5e-2 if big else 0.3), f"{n}: rel-L2 {rel_l2(got, ref):.3e}"
+    # and fp32 mode is restored by the next fp32 module call
+    m.precision = "fp32"
+    with torch.no_grad():
+        assert_fwd(m.eval()(t(g["x"]).cuda()), t(g["y"]), atol=2e-5)
