@@ -206,9 +206,10 @@ int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b, int b_is_p
                   float* slab, float* out, int out_row_stride, ksr_stream_t stream);
 
 /* Depthwise 3x3 parameter gradients (64 channels): in = the conv's input (NHWC, in_ld channels per pixel,
- * 64 channels from in_c0), ds [N,64] = gradient of its output.  dW [64,1,3,3], db [64]. slab: 256*640 floats. */
-int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, float* slab, float* dW, float* db,
-                     int B, int H, int W, ksr_stream_t stream);
+ * 64 channels from in_c0), ds = gradient of its output (ds_ld channels per pixel, 64 from ds_c0).
+ * dW [64,1,3,3], db [64]. slab: 256*640 floats. */
+int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0, float* slab,
+                     float* dW, float* db, int B, int H, int W, ksr_stream_t stream);
 
 /* ffn1's scalar front (pointwise1 1->1, depthwise 3x3 on one channel): out12 = gradients of
  * pointwise1.weight, pointwise1.bias, depthwise.weight (9), depthwise.bias.  slab: 256*12 floats. */
@@ -216,10 +217,64 @@ int ksr_stem_scalar_wgrad(const float* x_img, int64_t img_batch_stride, const fl
                           const float* pw1_b, const float* dw_w, float* slab, float* out12, int B, int H, int W,
                           ksr_stream_t stream);
 
+/* Plain 1x1-conv data gradient dx [N,64] = dz [N,n_out] * W, W [n_out][64], n_out 64 or 192 (backward of
+ * ksr_pointwise_fwd without activation). */
+int ksr_pointwise_bwd(const float* dz, int n_out, const float* w, float* dx, int B, int H, int W, ksr_stream_t stream);
+
 /* out[j][k] = r[j]*u[k] + c[j]*w[k] (weight gradient of ffn2.fn_1, whose input is u*v+w with one scalar v
  * per pixel); c_copy (optional) receives c, the bias gradient. */
 int ksr_outer2(float* out, const float* r, const float* u, const float* c, const float* w, int J, int K,
                float* c_copy, ksr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Channel attention: ConvSepKanAttention.forward (conv_sep_kan/conv_sep_kan_attention.py:48-71) with
+ * in = mid = 64 channels on NHWC pixels.  q | k | v live in one [N,192] tensor.  All 64 x 64 per-image
+ * algebra (normalisation, softmax, a_proj) is folded into per-image matrices so that the attention output
+ * and its gradient are never materialised:  y[n] = (W_a A_b) v[n] + b_a.
+ * Forward:  ksr_pointwise_fwd(n_out=192) -> ksr_chan_dw_fwd -> ksr_gram_batched(q, k, want_sq) ->
+ *           ksr_chan_soft_fwd -> ksr_chan_apply(v, M).
+ * Backward: ksr_gram_batched(dy, v) -> ksr_chan_soft_bwd -> ksr_chan_apply(dy, M^T) / ksr_chan_apply([q|k], Mqk)
+ *           -> ksr_chan_dw_bwd -> ksr_dwconv_wgrad x3, ksr_wgrad, ksr_pointwise_bwd.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Depthwise 3x3 (zero pad 1) over `groups` (1..3) blocks of 64 channels of an NHWC tensor with ld channels
+ * per pixel: q_dw / k_dw / v_dw (conv_sep_kan_attention.py:16-37).  dw_w [groups*64][9], dw_b [groups*64]. */
+int ksr_chan_dw_fwd(const float* in, const float* dw_w, const float* dw_b, float* out, int ld, int groups, int B,
+                    int H, int W, ksr_stream_t stream);
+/* Its data gradient (transposed depthwise conv). */
+int ksr_chan_dw_bwd(const float* dout, const float* dw_w, float* din, int ld, int groups, int B, int H, int W,
+                    ksr_stream_t stream);
+
+/* Batched Gram product over pixels (the q k^T of conv_sep_kan_attention.py:65 and the dy^T v of its
+ * backward): for each of nb entries (consecutive runs of tokens_per_entry pixels)
+ *   out[e][j][k] = sum_n dz[n][dz_c0+j] * a[n][a_c0+k],   tail[e][0:J] = sum_n dz[n][j],
+ * and with want_sq (J % 32 == 0): tail[e][J:2J] = sum_n dz[n][j]^2, tail[e][2J:2J+K] = sum_n a[n][k]^2
+ * (the squared norms F.normalize needs, :63-64).  J % 4 == 0, K 32 or 64.  tail: nb * (want_sq ? 2J+K : J)
+ * floats, may be NULL without want_sq.  slab: ksr_gram_slab_floats(...) floats. */
+int64_t ksr_gram_slab_floats(int J, int K, int nb, int64_t tokens_per_entry);
+int ksr_gram_batched(const float* dz, int dz_ld, int dz_c0, int J, const float* a, int a_ld, int a_c0, int K,
+                     int64_t tokens_per_entry, int nb, float* slab, float* out, float* tail, int want_sq,
+                     ksr_stream_t stream);
+
+/* Per image: from G = q^T k [B][64][64] and tail (sum q | sum q^2 | sum k^2, 192 floats per image):
+ * S = G / (max(|q|,1e-12) max(|k|,1e-12)), A = softmax over the last axis (:63-65), nrm [B][128] = raw
+ * norms, M [B][n_out][64] = a_proj.weight * A (:67-69 folded). */
+int ksr_chan_soft_fwd(const float* G, const float* tail, const float* a_proj_w, float* A, float* S, float* nrm,
+                      float* M, int n_out, int B, ksr_stream_t stream);
+/* Backward of the per-image algebra from Gd [B][n_out][64] = dy^T v: Mqk [B][128][128] such that
+ * [dq | dk][n] = Mqk [q | k][n], and dWa [n_out][64] = gradient of a_proj.weight (dWa_part: B*n_out*64
+ * floats of workspace). */
+int ksr_chan_soft_bwd(const float* Gd, const float* A, const float* S, const float* nrm, const float* a_proj_w,
+                      float* Mqk, float* dWa_part, float* dWa, int n_out, int B, ksr_stream_t stream);
+/* out[i] = sum_b in[b*stride + i], i < n, in a fixed order (bias gradient from per-image column sums). */
+int ksr_sum_entries(const float* in, int B, int64_t stride, int n, float* out, ksr_stream_t stream);
+
+/* Per-image 1x1 conv: out[n, out_c0 : out_c0+n_out] = Wm[b(n)] * in[n, in_c0 : in_c0+n_in] (+ bias [n_out]),
+ * Wm [B][n_out][n_in] row-major, or [B][n_in][n_out] when transposed != 0.  Supported n_in -> n_out:
+ * 64 -> {40, 64, 160, 336};  {40, 64, 160, 336} -> 64 transposed;  128 -> 128. */
+int ksr_chan_apply(const float* in, int in_ld, int in_c0, int n_in, const float* Wm, int transposed,
+                   const float* bias, float* out, int out_ld, int out_c0, int n_out, int B, int HW,
+                   ksr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Training step support (DefaultPipeline.training_step / configure_optimizers,

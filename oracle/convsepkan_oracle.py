@@ -165,6 +165,28 @@ def gazetr(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
     return F.conv2d(feat, p[prefix + "feed.weight"], p[prefix + "feed.bias"])
 
 
+# --------------------------------------------------------------------------- channel attention
+def chan_attention(x: torch.Tensor, p: Params, prefix: str, q=None, k=None, v=None) -> torch.Tensor:
+    """ConvSepKanAttention.forward (conv_sep_kan/conv_sep_kan_attention.py:48-71): q, k, v = dw3x3(pw(x));
+    q, k L2-normalised over the H*W axis (F.normalize, eps 1e-12); a = softmax(q k^T) over the [mid, mid]
+    channel-by-channel scores (no temperature); a_proj(a v).  a_dw is a parameter the forward never uses."""
+    B, C, H, W = x.shape
+
+    def branch(n):
+        t = F.conv2d(x, p[prefix + n + "_proj.weight"], p[prefix + n + "_proj.bias"])
+        return F.conv2d(t, p[prefix + n + "_dw.weight"], p[prefix + n + "_dw.bias"], padding=1, groups=t.shape[1])
+
+    q = branch("q") if q is None else q
+    k = branch("k") if k is None else k
+    v = branch("v") if v is None else v
+    q, k, v = (t.reshape(B, t.shape[1], H * W) for t in (q, k, v))
+    q = q / q.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    k = k / k.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    a = torch.softmax(q @ k.transpose(-2, -1), dim=-1)
+    y = (a @ v).reshape(B, -1, H, W)
+    return F.conv2d(y, p[prefix + "a_proj.weight"], p[prefix + "a_proj.bias"])
+
+
 # --------------------------------------------------------------------------- chroma
 def bilinear_up(x: torch.Tensor, r: int) -> torch.Tensor:
     """Bilinear upsample by integer factor r, align_corners=False, no antialias.

@@ -238,3 +238,16 @@ extern "C" int ksr_in_proj_bwd(const float* dqkv, const float* in_w, const float
     if (y_saved) return launch_dgrad<192, BPRO_PLAIN, BEPI_RESID_SIGGRAD>(a, stream);
     return launch_dgrad<192, BPRO_PLAIN, BEPI_RESID>(a, stream);
 }
+
+// Plain 1x1-conv data gradient: dx [N,64] = dz [N,n_out] * W  (W [n_out][64], n_out 64 or 192).
+extern "C" int ksr_pointwise_bwd(const float* dz, int n_out, const float* w, float* dx, int B, int H, int W,
+                                 hipStream_t stream) {
+    KSR_CHECK_ARG(dz && w && dx, "pointwise_bwd: null pointer");
+    if (int rc = dims_ok(B, H, W, "pointwise_bwd")) return rc;
+    BwdArgs a{};
+    a.dz = dz; a.dz_ld = n_out; a.wt = w; a.out1 = dx; a.out1_ld = 64; a.B = B; a.H = H; a.W = W;
+    if (n_out == 64) return launch_dgrad<64, BPRO_PLAIN, BEPI_STORE>(a, stream);
+    if (n_out == 192) return launch_dgrad<192, BPRO_PLAIN, BEPI_STORE>(a, stream);
+    ksr_set_error("pointwise_bwd: unsupported n_out=%d", n_out);
+    return KSR_ERR_UNSUPPORTED;
+}

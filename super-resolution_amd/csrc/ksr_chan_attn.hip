@@ -1,0 +1,374 @@
+// Channel attention (ConvSepKanAttention.forward, conv_sep_kan/conv_sep_kan_attention.py:48-71) on NHWC
+// activations, 64 mid channels:
+//     q, k, v = dw3x3(pw(x));  q^, k^ = q, k / max(||.||_HW, 1e-12);  A = softmax_c'(q^T k^);  y = a_proj(A v)
+// The [N, 64] tensors are only ever touched by streaming kernels; everything that is 64 x 64 per image is
+// folded into small per-image matrices:
+//     forward   G_b = q^T k (batched Gram product, with the squared norms)  ->  A_b, S_b  ->  M_b = W_a A_b
+//               y[n] = M_b v[n] + b_a                                   (per-image 1x1 conv, MFMA)
+//     backward  Gd_b = dy^T v  ->  dA_b = W_a^T Gd_b, softmax and normalisation derivatives  ->
+//               dv[n] = M_b^T dy[n];  [dq | dk][n] = Mqk_b [q | k][n];  dW_a = sum_b Gd_b A_b^T
+// so neither A v nor its gradient is materialised.
+#include "ksr_conv_common.h"
+
+namespace {
+
+// ---- depthwise 3x3 over `groups` blocks of 64 channels (FLIP: transposed conv, no bias) -------------
+struct DwArgs {
+    const float* in; const float* dw_w; const float* dw_b; float* out;
+    int ld, groups, B, H, W;
+};
+
+template <bool FLIP>
+__global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
+    __shared__ __attribute__((aligned(16))) float halo[HALO_FLOATS];
+    __shared__ __attribute__((aligned(16))) float dww[3 * 9 * 64];
+    __shared__ __attribute__((aligned(16))) float dwb[3 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    for (int gi = 0; gi < a.groups; ++gi) {
+        ksr_stage_dw<FLIP>(dww + gi * 576, a.dw_w + gi * 576, tid);
+        if (tid < 64) dwb[gi * 64 + tid] = (FLIP || !a.dw_b) ? 0.f : a.dw_b[gi * 64 + tid];
+    }
+    __syncthreads();
+    const int HW = a.H * a.W;
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
+    const long ntiles = (long)a.B * tiles_y * tiles_x;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const int b = (int)(tile / ((long)tiles_x * tiles_y));
+        const int y0 = ty * 4, x0 = tx * 32;
+        const int y = y0 + wv, x = x0 + tok;
+        const bool live = (y < a.H) && (x < a.W);
+        const long n = live ? (long)b * HW + (long)y * a.W + x : 0;
+        for (int gi = 0; gi < a.groups; ++gi) {
+            __syncthreads();
+            ksr_stage_halo(halo, a.in, a.ld, 64 * gi, b, y0, x0, a.H, a.W, tid);
+            __syncthreads();
+            float g[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) g[i] = dwb[gi * 64 + 32 * h + i];
+            ksr_dwconv_lane(halo, dww + gi * 576, wv, tok, h, g);
+            if (live) ksr_store32(a.out + n * a.ld + 64 * gi + 32 * h, g);
+        }
+    }
+}
+
+// ---- per-image 1x1 conv: out[n, :NOUT] = W_b(n) in[n, :KIN] + bias -----------------------------------
+// Lane half h holds input channels [h*kin_h, (h+1)*kin_h) and produces outputs [h*nout_h, (h+1)*nout_h).
+struct ApArgs {
+    const float* in; int in_ld, in_c0, kin_h;
+    const float* w; long w_bstride; int ldw;
+    const float* bias;
+    float* out; int out_ld, out_c0, nout_h;
+    int HW;
+};
+
+template <int PREC, int KH, int NB, bool TRANS>
+__global__ void __launch_bounds__(256) chan_apply_kernel(ApArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float apmem[];
+    float* frag = apmem;
+    float* biasfrag = apmem + NB * KH * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    ksr_stage_weights<PREC, KH, NB, TRANS>(frag, biasfrag, a.w + (long)b * a.w_bstride, a.ldw, a.bias,
+                                          MapSplit{a.nout_h}, MapSplit{a.kin_h}, tid, 256);
+    __syncthreads();
+    const int ntiles = (a.HW + 127) / 128;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int t = tile * 128 + wv * 32 + tok;
+        const bool live = t < a.HW;
+        const long n = (long)b * a.HW + (live ? t : 0);
+        float x[KH];
+        const float4* src = reinterpret_cast<const float4*>(a.in + n * a.in_ld + a.in_c0 + h * a.kin_h);
+#pragma unroll
+        for (int q = 0; q < KH / 4; ++q) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * q < a.kin_h) v = src[q];
+            x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+        f32x16 acc[NB];
+        ksr_wave_gemm<PREC, KH, NB>(frag, biasfrag, x, acc, lane);
+        if (live) {
+            float4* dst = reinterpret_cast<float4*>(a.out + n * a.out_ld + a.out_c0 + h * a.nout_h);
+#pragma unroll
+            for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4)
+                    if (16 * blk + 4 * q4 < a.nout_h)
+                        dst[4 * blk + q4] = make_float4(acc[blk][4 * q4 + 0], acc[blk][4 * q4 + 1], acc[blk][4 * q4 + 2],
+                                                        acc[blk][4 * q4 + 3]);
+        }
+    }
+}
+
+template <int PREC, int KH, int NB, bool TRANS>
+int launch_apply_p(const ApArgs& a, int B, hipStream_t s) {
+    const size_t lds = (size_t)(NB * KH * 64 + NB * 32) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)chan_apply_kernel<PREC, KH, NB, TRANS>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { ksr_set_error("chan_apply: hipFuncSetAttribute: %s", hipGetErrorString(e)); return KSR_ERR_HIP; }
+        attr_set = true;
+    }
+    const int ntiles = (a.HW + 127) / 128;
+    int gx = 1024 / B;
+    if (gx < 1) gx = 1;
+    if (gx > ntiles) gx = ntiles;
+    hipLaunchKernelGGL((chan_apply_kernel<PREC, KH, NB, TRANS>), dim3(gx, B), dim3(256), lds, s, a);
+    KSR_LAUNCH_CHECK("chan_apply");
+    return KSR_OK;
+}
+
+template <int KH, int NB, bool TRANS>
+int launch_apply(const ApArgs& a, int B, hipStream_t s) {
+    return ksr_prec() == KSR_BF16 ? launch_apply_p<KSR_BF16, KH, NB, TRANS>(a, B, s) : launch_apply_p<KSR_F32, KH, NB, TRANS>(a, B, s);
+}
+
+// ---- per-image 64 x 64 algebra ----------------------------------------------------------------------
+struct SoftArgs {
+    const float* G;        // [B][64][64]  q^T k
+    const float* tail;     // [B][192]     (sum q | sum q^2 | sum k^2)
+    const float* Wa;       // [P][64]
+    float* A;              // [B][64][64]  softmax
+    float* S;              // [B][64][64]  normalised scores
+    float* nrm;            // [B][128]     raw norms of q, k
+    float* M;              // [B][P][64]   W_a A_b
+    int P;
+};
+
+__global__ void __launch_bounds__(256) chan_soft_fwd_kernel(SoftArgs a) {
+    __shared__ float As[64][65];
+    __shared__ float nq[64], nk[64];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid < 128) {
+        const float raw = sqrtf(a.tail[(long)b * 192 + 64 + tid]);
+        a.nrm[(long)b * 128 + tid] = raw;
+        const float cl = fmaxf(raw, 1e-12f);
+        if (tid < 64) nq[tid] = cl; else nk[tid - 64] = cl;
+    }
+    __syncthreads();
+    const int c = tid >> 2, part = tid & 3;
+    const float* Gr = a.G + (long)b * 4096 + c * 64 + part * 16;
+    float s[16];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        s[j] = Gr[j] / (nq[c] * nk[part * 16 + j]);
+        mx = fmaxf(mx, s[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    float e[16], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) { e[j] = expf(s[j] - mx); sum += e[j]; }
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float p = e[j] * inv;
+        As[c][part * 16 + j] = p;
+        a.A[(long)b * 4096 + c * 64 + part * 16 + j] = p;
+        a.S[(long)b * 4096 + c * 64 + part * 16 + j] = s[j];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < a.P * 64; idx += 256) {
+        const int p = idx >> 6, cc = idx & 63;
+        const float* w = a.Wa + p * 64;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int ci = 0; ci < 64; ++ci) acc += w[ci] * As[ci][cc];
+        a.M[(long)b * a.P * 64 + idx] = acc;
+    }
+}
+
+struct SoftBwdArgs {
+    const float* Gd;       // [B][P][64]  dy^T v
+    const float* A; const float* S; const float* nrm; const float* Wa;
+    float* Mqk;            // [B][128][128]
+    float* dWa_part;       // [B][P][64]
+    int P;
+};
+
+__global__ void __launch_bounds__(256) chan_soft_bwd_kernel(SoftBwdArgs a) {
+    __shared__ float As[64][65], Ss[64][65], dS[64][65];
+    __shared__ float nq[64], nk[64], pq[64], pk[64], r[64], rp[64];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int idx = tid; idx < 4096; idx += 256) {
+        As[idx >> 6][idx & 63] = a.A[(long)b * 4096 + idx];
+        Ss[idx >> 6][idx & 63] = a.S[(long)b * 4096 + idx];
+    }
+    if (tid < 128) {
+        const float raw = a.nrm[(long)b * 128 + tid];
+        const float cl = fmaxf(raw, 1e-12f), pr = raw >= 1e-12f ? 1.f : 0.f;
+        if (tid < 64) { nq[tid] = cl; pq[tid] = pr; } else { nk[tid - 64] = cl; pk[tid - 64] = pr; }
+    }
+    const float* Gd = a.Gd + (long)b * a.P * 64;
+    // dA = W_a^T Gd
+    for (int idx = tid; idx < 4096; idx += 256) {
+        const int c = idx >> 6, cc = idx & 63;
+        float acc = 0.f;
+        for (int p = 0; p < a.P; ++p) acc += a.Wa[p * 64 + c] * Gd[p * 64 + cc];
+        dS[c][cc] = acc;
+    }
+    __syncthreads();
+    {   // softmax derivative, row sums of dS * S
+        const int c = tid >> 2, part = tid & 3;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dot += dS[c][part * 16 + j] * As[c][part * 16 + j];
+        dot += __shfl_xor(dot, 1, 64);
+        dot += __shfl_xor(dot, 2, 64);
+        float rr = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int cc = part * 16 + j;
+            const float d = As[c][cc] * (dS[c][cc] - dot);
+            dS[c][cc] = d;
+            rr += d * Ss[c][cc];
+        }
+        rr += __shfl_xor(rr, 1, 64);
+        rr += __shfl_xor(rr, 2, 64);
+        if (part == 0) r[c] = rr;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s = 0.f;
+        for (int c = 0; c < 64; ++c) s += dS[c][tid] * Ss[c][tid];
+        rp[tid] = s;
+    }
+    __syncthreads();
+    // [dq | dk] = Mqk [q | k]
+    float* Mqk = a.Mqk + (long)b * 16384;
+    for (int idx = tid; idx < 16384; idx += 256) {
+        const int o = idx >> 7, i = idx & 127;
+        float v;
+        if (o < 64) {
+            if (i < 64) v = (i == o) ? -pq[o] * r[o] / (nq[o] * nq[o]) : 0.f;
+            else v = dS[o][i - 64] / (nq[o] * nk[i - 64]);
+        } else {
+            const int cc = o - 64;
+            if (i < 64) v = dS[i][cc] / (nq[i] * nk[cc]);
+            else v = (i - 64 == cc) ? -pk[cc] * rp[cc] / (nk[cc] * nk[cc]) : 0.f;
+        }
+        Mqk[idx] = v;
+    }
+    // dW_a contribution of this image: Gd A^T
+    for (int idx = tid; idx < a.P * 64; idx += 256) {
+        const int p = idx >> 6, c = idx & 63;
+        const float* g = Gd + p * 64;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int cc = 0; cc < 64; ++cc) acc += g[cc] * As[c][cc];
+        a.dWa_part[(long)b * a.P * 64 + idx] = acc;
+    }
+}
+
+// out[i] = sum_g in[g][i]  (fixed order)
+__global__ void __launch_bounds__(256) sum_entries_kernel(const float* in, int G, long stride, int n, float* out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += in[(long)g * stride + i];
+    out[i] = s;
+}
+
+int dims_ok(int B, int H, int W, const char* who) {
+    KSR_CHECK_ARG(B > 0 && B <= 65535 && H > 0 && W > 0 && (long)B * H * W < (1L << 31), "%s: bad dimensions", who);
+    return KSR_OK;
+}
+
+}  // namespace
+
+// q | k | v = dw3x3(pq) for `groups` (1..3) blocks of 64 channels of an NHWC tensor with `ld` channels per
+// pixel (q_dw, k_dw, v_dw: conv_sep_kan_attention.py:16-37); dw_w [groups*64][9], dw_b [groups*64].
+extern "C" int ksr_chan_dw_fwd(const float* in, const float* dw_w, const float* dw_b, float* out, int ld, int groups,
+                               int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(in && dw_w && dw_b && out, "chan_dw_fwd: null pointer");
+    KSR_CHECK_ARG(groups >= 1 && groups <= 3 && ld >= 64 * groups && ld % 4 == 0, "chan_dw_fwd: bad channel layout");
+    if (int rc = dims_ok(B, H, W, "chan_dw_fwd")) return rc;
+    DwArgs a{in, dw_w, dw_b, out, ld, groups, B, H, W};
+    const long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
+    hipLaunchKernelGGL(chan_dw_kernel<false>, dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("chan_dw_fwd");
+    return KSR_OK;
+}
+
+// Transposed depthwise conv of the same layout: din = convT(dout).
+extern "C" int ksr_chan_dw_bwd(const float* dout, const float* dw_w, float* din, int ld, int groups, int B, int H, int W,
+                               hipStream_t stream) {
+    KSR_CHECK_ARG(dout && dw_w && din, "chan_dw_bwd: null pointer");
+    KSR_CHECK_ARG(groups >= 1 && groups <= 3 && ld >= 64 * groups && ld % 4 == 0, "chan_dw_bwd: bad channel layout");
+    if (int rc = dims_ok(B, H, W, "chan_dw_bwd")) return rc;
+    DwArgs a{dout, dw_w, nullptr, din, ld, groups, B, H, W};
+    const long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
+    hipLaunchKernelGGL(chan_dw_kernel<true>, dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("chan_dw_bwd");
+    return KSR_OK;
+}
+
+// From the per-image Gram matrix G = q^T k and the squared norms (tail = (sum q | sum q^2 | sum k^2), 192
+// floats per image, as ksr_gram_batched emits with want_sq): A = softmax(q^^T k^), S = q^^T k^, raw norms,
+// and M = W_a A (a_proj folded into the attention matrix).
+extern "C" int ksr_chan_soft_fwd(const float* G, const float* tail, const float* a_proj_w, float* A, float* S,
+                                 float* nrm, float* M, int n_out, int B, hipStream_t stream) {
+    KSR_CHECK_ARG(G && tail && a_proj_w && A && S && nrm && M && n_out > 0 && B > 0, "chan_soft_fwd: bad argument");
+    SoftArgs a{G, tail, a_proj_w, A, S, nrm, M, n_out};
+    hipLaunchKernelGGL(chan_soft_fwd_kernel, dim3(B), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("chan_soft_fwd");
+    return KSR_OK;
+}
+
+// Backward of the per-image algebra.  Gd [B][n_out][64] = dy^T v.  Emits Mqk [B][128][128] with
+// [dq | dk] = Mqk [q | k], and dW_a [n_out][64] (dWa_part: [B][n_out][64] workspace).
+extern "C" int ksr_chan_soft_bwd(const float* Gd, const float* A, const float* S, const float* nrm,
+                                 const float* a_proj_w, float* Mqk, float* dWa_part, float* dWa, int n_out, int B,
+                                 hipStream_t stream) {
+    KSR_CHECK_ARG(Gd && A && S && nrm && a_proj_w && Mqk && dWa_part && dWa && n_out > 0 && B > 0, "chan_soft_bwd: bad argument");
+    SoftBwdArgs a{Gd, A, S, nrm, a_proj_w, Mqk, dWa_part, n_out};
+    hipLaunchKernelGGL(chan_soft_bwd_kernel, dim3(B), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("chan_soft_bwd");
+    const int n = n_out * 64;
+    hipLaunchKernelGGL(sum_entries_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dWa_part, B, (long)n, n, dWa);
+    KSR_LAUNCH_CHECK("chan_soft_bwd(sum)");
+    return KSR_OK;
+}
+
+// out[i] = sum over B entries of in[b][i], i < n (entries `stride` floats apart): bias gradient from the
+// per-image column sums.
+extern "C" int ksr_sum_entries(const float* in, int B, int64_t stride, int n, float* out, hipStream_t stream) {
+    KSR_CHECK_ARG(in && out && B > 0 && n > 0 && stride >= n, "sum_entries: bad argument");
+    hipLaunchKernelGGL(sum_entries_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, B, (long)stride, n, out);
+    KSR_LAUNCH_CHECK("sum_entries");
+    return KSR_OK;
+}
+
+// Per-image 1x1 conv on NHWC pixels: out[n, out_c0 : out_c0+n_out] = Wm[b(n)] * in[n, in_c0 : in_c0+n_in] (+ bias),
+// Wm [B][n_out][n_in] row-major, or [B][n_in][n_out] with transposed != 0.  Supported (n_in -> n_out):
+// 64 -> {40, 64, 160, 336}; {40, 64, 160, 336} -> 64 ; 128 -> 128.
+extern "C" int ksr_chan_apply(const float* in, int in_ld, int in_c0, int n_in, const float* Wm, int transposed,
+                              const float* bias, float* out, int out_ld, int out_c0, int n_out, int B, int HW,
+                              hipStream_t stream) {
+    KSR_CHECK_ARG(in && Wm && out, "chan_apply: null pointer");
+    KSR_CHECK_ARG(B > 0 && B <= 65535 && HW > 0 && (long)B * HW < (1L << 31), "chan_apply: bad dimensions");
+    KSR_CHECK_ARG(n_in % 8 == 0 && n_out % 8 == 0 && in_ld % 4 == 0 && in_c0 % 4 == 0 && out_ld % 4 == 0 && out_c0 % 4 == 0,
+                  "chan_apply: channel counts must be multiples of 8, offsets multiples of 4");
+    ApArgs a{in, in_ld, in_c0, n_in / 2, Wm, (long)n_in * n_out, transposed ? n_out : n_in, bias,
+             out, out_ld, out_c0, n_out / 2, HW};
+    if (!transposed && n_in == 64) {
+        if (n_out == 40 || n_out == 64) return launch_apply<32, 2, false>(a, B, stream);
+        if (n_out == 160) return launch_apply<32, 5, false>(a, B, stream);
+        if (n_out == 336) return launch_apply<32, 11, false>(a, B, stream);
+    }
+    if (!transposed && n_in == 128 && n_out == 128) return launch_apply<64, 4, false>(a, B, stream);
+    if (transposed && n_out == 64) {
+        if (n_in == 40) return launch_apply<24, 2, true>(a, B, stream);
+        if (n_in == 64) return launch_apply<32, 2, true>(a, B, stream);
+        if (n_in == 160) return launch_apply<80, 2, true>(a, B, stream);
+        if (n_in == 336) return launch_apply<168, 2, true>(a, B, stream);
+    }
+    ksr_set_error("chan_apply: unsupported (n_in=%d, n_out=%d, transposed=%d)", n_in, n_out, transposed);
+    return KSR_ERR_UNSUPPORTED;
+}

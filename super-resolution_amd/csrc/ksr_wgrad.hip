@@ -19,10 +19,13 @@ struct WgArgs {
     const float* a1; int a1_ld, a1_c0, K;
     const float* a2; int a2_ld, a2_c0;
     float* slab;
-    long N;
+    long N;        // pixels per batch entry (blockIdx.y selects the entry: rows [y*N, (y+1)*N) of every tensor)
+    int Jv;        // valid channels of dz (multiple of 4, J - 32 < Jv <= J); rows >= Jv of dW are zero
+    int sq;        // also emit sum dz^2 per row and sum a^2 per column
+    long stride;   // slab floats per workgroup: J*K + J (+ J + K with sq)
 };
 
-// Each workgroup walks its pixel range in chunks of 32 pixels.  A chunk's rows [dz | a1 | a2] are copied
+// Each workgroup walks its pixel range in chunks of WG_T pixels.  A chunk's rows [dz | a1 | a2] are copied
 // global -> LDS by 16-byte LDS-DMA loads (lane-linear image = row-major [32][RL]), double buffered: the
 // loads of chunk c+1 are in flight while the MFMAs of chunk c run.  Operands are then read from LDS with
 // conflict-free ds_read_b32 (lane = column).  Wave w owns column block kb = w % (K/32) of A and the
@@ -36,22 +39,24 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     const int kb = wv % NKB, jb0 = wv / NKB, jbs = 4 / NKB;
     int np = 0;
     for (int jb = jb0; jb < NJB; jb += jbs) ++np;
-    const int RL = a.J + a.K + (a.a2 ? a.K : 0);       // floats per staged row
+    const int RL = a.Jv + a.K + (a.a2 ? a.K : 0);      // floats per staged row
     const int RL4 = RL / 4;
     const unsigned inv = (unsigned)((0x100000000ULL + RL4 - 1) / RL4);
-    const int npass = (WG_T * RL4) / 256;               // RL4 is a multiple of 8: exact
+    const int nvec = WG_T * RL4;                        // 16-byte pieces per chunk
+    const int npass = (nvec + 255) / 256;
 
     f32x16 acc[MAXP];
-    float bsum[MAXP];
+    float bsum[MAXP], sqa[MAXP], sqb = 0.f;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
-        bsum[p] = 0.f;
+        bsum[p] = 0.f; sqa[p] = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[p][q] = 0.f;
     }
     const long per = (((a.N + gridDim.x - 1) / gridDim.x) + WG_T - 1) / WG_T * WG_T;
-    const long n0 = (long)blockIdx.x * per;
-    const long n1 = (n0 + per < a.N) ? n0 + per : a.N;
+    const long base = (long)blockIdx.y * a.N;
+    const long n0 = base + (long)blockIdx.x * per;
+    const long n1 = ((long)(blockIdx.x + 1) * per < a.N) ? n0 + per : base + a.N;
     const int nchunks = n1 > n0 ? (int)((n1 - n0 + WG_T - 1) / WG_T) : 0;
 
     auto issue = [&](int c) {
@@ -59,14 +64,15 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
         const long t0 = n0 + (long)c * WG_T;
         for (int i = 0; i < npass; ++i) {
             const unsigned f = (unsigned)(i * 256 + tid);
+            if ((int)f >= nvec) break;                  // ragged last pass: the remaining lanes stage nothing
             const unsigned trow = __umulhi(f, inv);
             const int q = (int)(f - trow * RL4) * 4;
             long tokn = t0 + trow;
             if (tokn >= n1) tokn = n1 - 1;
             const float* src;
-            if (q < a.J) src = a.dz + tokn * a.dz_ld + a.dz_c0 + q;
-            else if (q < a.J + a.K) src = a.a1 + tokn * a.a1_ld + a.a1_c0 + (q - a.J);
-            else src = a.a2 + tokn * a.a2_ld + a.a2_c0 + (q - a.J - a.K);
+            if (q < a.Jv) src = a.dz + tokn * a.dz_ld + a.dz_c0 + q;
+            else if (q < a.Jv + a.K) src = a.a1 + tokn * a.a1_ld + a.a1_c0 + (q - a.Jv);
+            else src = a.a2 + tokn * a.a2_ld + a.a2_c0 + (q - a.Jv - a.K);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dstbuf + (i * 256 + wv * 64) * 4),
                                              16, 0, 0);
@@ -83,21 +89,24 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
 #pragma unroll 4
         for (int u = 0; u < WG_T / 2; ++u) {
             const float* row = buf + (2 * u + kk) * RL;
-            float bv = row[a.J + 32 * kb + col];
-            if (a.a2) bv *= row[a.J + a.K + 32 * kb + col];
+            float bv = row[a.Jv + 32 * kb + col];
+            if (a.a2) bv *= row[a.Jv + a.K + 32 * kb + col];
             const bool ok = full || (t0 + 2 * u + kk < n1);
+            sqb += ok ? bv * bv : 0.f;
 #pragma unroll
             for (int p = 0; p < MAXP; ++p) {
                 if (p < np) {
-                    float av = row[32 * (jb0 + p * jbs) + col];
-                    av = ok ? av : 0.f;
+                    const int j = 32 * (jb0 + p * jbs) + col;
+                    float av = row[j];                   // j >= Jv reads the neighbouring columns: masked below
+                    av = (ok && j < a.Jv) ? av : 0.f;
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p], 0, 0, 0);
                     bsum[p] += av;
+                    sqa[p] += av * av;
                 }
             }
         }
     }
-    float* slab = a.slab + (long)blockIdx.x * ((long)a.J * a.K + a.J);
+    float* slab = a.slab + ((long)blockIdx.y * gridDim.x + blockIdx.x) * a.stride;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
         if (p < np) {
@@ -110,19 +119,30 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
             if (kb == 0) {
                 const float bs = ksr_pair_sum(bsum[p]);
                 if (kk == 0) slab[(long)a.J * a.K + 32 * jb + col] = bs;
+                if (a.sq) {
+                    const float ss = ksr_pair_sum(sqa[p]);
+                    if (kk == 0) slab[(long)a.J * a.K + a.J + 32 * jb + col] = ss;
+                }
             }
         }
     }
+    if (a.sq && jb0 == 0) {
+        const float ss = ksr_pair_sum(sqb);
+        if (kk == 0) slab[(long)a.J * a.K + 2 * a.J + 32 * kb + col] = ss;
+    }
 }
 
-// out[j*sj + k*sk] = sum_g slab[g][j*K + k];  bias[j] = sum_g slab[g][J*K + j].  With kan_O > 0 the rows
-// are in lane order (half, e) of the fused feed+KAN kernel and are scattered to the reference's
-// channel numbering (rows that are padding are dropped).
+// out[j*sj + k*sk] = sum_g slab[g][j*K + k];  bias[j] = sum_g slab[g][tail_off + j] for j < tail_len.
+// With kan_O > 0 the rows are in lane order (half, e) of the fused feed+KAN kernel and are scattered to
+// the reference's channel numbering (rows that are padding are dropped).  blockIdx.y selects a batch
+// entry: slab advances by G*stride, out by out_bstride, bias by tail_len.
 struct RedArgs {
     const float* slab; int G; int J, K; long stride;
     float* out; int sj, sk;
     float* bias;
     int kan_O, kan_Kc, kan_nbh;   // nbh = per-half padded length (NB*16)
+    int tail_off, tail_len;
+    long out_bstride;
 };
 
 __global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
@@ -130,10 +150,12 @@ __global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
     __shared__ float part[16][17];
     const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int idx = blockIdx.x * 16 + o;
-    const int total = a.J * a.K + (a.bias ? a.J : 0);
+    const int total = a.J * a.K + (a.bias ? a.tail_len : 0);
+    const bool is_bias = idx >= a.J * a.K;
+    const float* slab = a.slab + (long)blockIdx.y * a.G * a.stride + (is_bias ? a.tail_off + idx - a.J * a.K : idx);
     float s = 0.f;
     if (idx < total)
-        for (int g = grp; g < a.G; g += 16) s += a.slab[(long)g * a.stride + idx];
+        for (int g = grp; g < a.G; g += 16) s += slab[(long)g * a.stride];
     part[grp][o] = s;
     __syncthreads();
     if (grp != 0 || idx >= total) return;
@@ -141,7 +163,6 @@ __global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += part[r][o];
     int j, k;
-    const bool is_bias = idx >= a.J * a.K;
     if (is_bias) { j = idx - a.J * a.K; k = 0; }
     else { j = idx / a.K; k = idx - j * a.K; }
     if (a.kan_O > 0) {
@@ -149,8 +170,8 @@ __global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
         j = MapKan{a.kan_O, a.kan_Kc}(h, e);
         if (j < 0) return;
     }
-    if (is_bias) a.bias[j] = s;
-    else a.out[(long)j * a.sj + (long)k * a.sk] = s;
+    if (is_bias) a.bias[(long)blockIdx.y * a.tail_len + j] = s;
+    else a.out[(long)blockIdx.y * a.out_bstride + (long)j * a.sj + (long)k * a.sk] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -201,7 +222,7 @@ __global__ void __launch_bounds__(256) colreduce_kernel(ColArgs a) {
 // ---------------------------------------------------------------------------------------------
 struct DwgArgs {
     const float* in; int in_ld, in_c0;     // conv input (NHWC)
-    const float* ds;                       // [N,64] gradient of the conv output
+    const float* ds; int ds_ld, ds_c0;     // gradient of the conv output, 64 channels from ds_c0
     float* slab;                           // [grid][10][64]: 9 taps + bias
     int B, H, W;
 };
@@ -227,7 +248,7 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
         if (y < a.H) {
             const int xmax = (a.W - x0) < 32 ? (a.W - x0) : 32;
             for (int col = 0; col < xmax; ++col) {
-                const float d = a.ds[((long)b * HW + (long)y * a.W + x0 + col) * 64 + c];
+                const float d = a.ds[((long)b * HW + (long)y * a.W + x0 + col) * a.ds_ld + a.ds_c0 + c];
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -313,12 +334,56 @@ __global__ void __launch_bounds__(256) outer2_kernel(float* out, const float* r,
 }
 
 int launch_reduce(const float* slab, int G, int J, int K, long stride, float* out, int sj, int sk, float* bias,
-                  int kan_O, int kan_Kc, int kan_nbh, hipStream_t s) {
-    RedArgs r{slab, G, J, K, stride, out, sj, sk, bias, kan_O, kan_Kc, kan_nbh};
-    const int total = J * K + (bias ? J : 0);
-    hipLaunchKernelGGL(reduce_kernel, dim3((total + 15) / 16), dim3(256), 0, s, r);
+                  int kan_O, int kan_Kc, int kan_nbh, hipStream_t s, int tail_off = -1, int tail_len = -1, int nb = 1,
+                  long out_bstride = 0) {
+    if (tail_off < 0) { tail_off = J * K; tail_len = J; }
+    RedArgs r{slab, G, J, K, stride, out, sj, sk, bias, kan_O, kan_Kc, kan_nbh, tail_off, tail_len, out_bstride};
+    const int total = J * K + (bias ? tail_len : 0);
+    hipLaunchKernelGGL(reduce_kernel, dim3((total + 15) / 16, nb), dim3(256), 0, s, r);
     KSR_LAUNCH_CHECK("reduce");
     return KSR_OK;
+}
+
+// Launches the accumulation kernel on a (g, nb) grid; a.stride and a.slab are set by the caller.
+int launch_wgrad_kernel(const WgArgs& a, int per_wave, int T, size_t lds_bytes, unsigned g, unsigned nb, hipStream_t stream) {
+    const bool small = per_wave <= 3;
+    const void* fn = T == 64 ? (small ? (const void*)wgrad_kernel<64, 3> : (const void*)wgrad_kernel<64, WG_MAXP>)
+                             : (small ? (const void*)wgrad_kernel<32, 3> : (const void*)wgrad_kernel<32, WG_MAXP>);
+    static bool attr_set[4] = {false, false, false, false};
+    const int fi = (T == 64 ? 0 : 2) + (small ? 0 : 1);
+    if (!attr_set[fi]) {
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { ksr_set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return KSR_ERR_HIP; }
+        attr_set[fi] = true;
+    }
+    const dim3 grid(g, nb);
+    if (T == 64) {
+        if (small) hipLaunchKernelGGL((wgrad_kernel<64, 3>), grid, dim3(256), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((wgrad_kernel<64, WG_MAXP>), grid, dim3(256), lds_bytes, stream, a);
+    } else {
+        if (small) hipLaunchKernelGGL((wgrad_kernel<32, 3>), grid, dim3(256), lds_bytes, stream, a);
+        else hipLaunchKernelGGL((wgrad_kernel<32, WG_MAXP>), grid, dim3(256), lds_bytes, stream, a);
+    }
+    KSR_LAUNCH_CHECK("wgrad");
+    return KSR_OK;
+}
+
+// Chunk length and LDS bytes for staged rows of RL floats: 64 pixels while two buffers stay within 64 KiB
+// (more bytes in flight per workgroup), else 32.
+void wgrad_shape(int RL, int* T, size_t* lds_bytes) {
+    *T = (2 * 64 * RL * (int)sizeof(float) <= 64 * 1024) ? 64 : 32;
+    *lds_bytes = (size_t)2 * *T * RL * sizeof(float);
+}
+
+// Workgroups per batch entry of a batched Gram product (nb entries of `tokens` pixels, Jp = J rounded up to 32).
+long gram_grid(int Jp, int K, int nb, long tokens) {
+    int T; size_t lds;
+    wgrad_shape(Jp + K, &T, &lds);
+    long cap = WG_GRID / nb;
+    if (lds > 40 * 1024) cap = (WG_GRID / 2) / nb;
+    if (cap < 1) cap = 1;
+    long g = (tokens + 4 * T - 1) / (4 * T);
+    return g < 1 ? 1 : (g > cap ? cap : g);
 }
 
 }  // namespace
@@ -337,39 +402,53 @@ extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const flo
     KSR_UNSUPPORTED(per_wave > WG_MAXP, "wgrad: J=%d too large", J);
     KSR_CHECK_ARG(dz_ld % 4 == 0 && dz_c0 % 4 == 0 && a1_ld % 4 == 0 && a1_c0 % 4 == 0 && a2_ld % 4 == 0 && a2_c0 % 4 == 0,
                   "wgrad: leading dimensions and channel offsets must be multiples of 4");
-    WgArgs a{dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, a2, a2_ld, a2_c0, slab, (long)N};
-    const int RL = J + K + (a2 ? K : 0);
-    // chunk length: 64 pixels while two buffers stay within 64 KiB (more bytes in flight per workgroup), else 32
-    const int T = (2 * 64 * RL * (int)sizeof(float) <= 64 * 1024) ? 64 : 32;
-    const size_t lds_bytes = (size_t)2 * T * RL * sizeof(float);
+    WgArgs a{dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, a2, a2_ld, a2_c0, slab, (long)N, J, 0, (long)J * K + J};
+    int T; size_t lds_bytes;
+    wgrad_shape(J + K + (a2 ? K : 0), &T, &lds_bytes);
     KSR_UNSUPPORTED(lds_bytes > 160 * 1024, "wgrad: J=%d needs %zu bytes of LDS", J, lds_bytes);
-    const bool small = per_wave <= 3;
-    const void* fn = T == 64 ? (small ? (const void*)wgrad_kernel<64, 3> : (const void*)wgrad_kernel<64, WG_MAXP>)
-                             : (small ? (const void*)wgrad_kernel<32, 3> : (const void*)wgrad_kernel<32, WG_MAXP>);
-    static bool attr_set[4] = {false, false, false, false};
-    const int fi = (T == 64 ? 0 : 2) + (small ? 0 : 1);
-    if (!attr_set[fi]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { ksr_set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return KSR_ERR_HIP; }
-        attr_set[fi] = true;
-    }
     long g = (N + 4 * T - 1) / (4 * T);
     if (g > WG_GRID) g = WG_GRID;
     if (lds_bytes > 40 * 1024 && g > WG_GRID / 2) g = WG_GRID / 2;     // 2 workgroups per CU fit
-    if (T == 64) {
-        if (small) hipLaunchKernelGGL((wgrad_kernel<64, 3>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
-        else hipLaunchKernelGGL((wgrad_kernel<64, WG_MAXP>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
-    } else {
-        if (small) hipLaunchKernelGGL((wgrad_kernel<32, 3>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
-        else hipLaunchKernelGGL((wgrad_kernel<32, WG_MAXP>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);
-    }
-    KSR_LAUNCH_CHECK("wgrad");
+    if (int rc = launch_wgrad_kernel(a, per_wave, T, lds_bytes, (unsigned)g, 1, stream)) return rc;
     int kan_O = 0, kan_nbh = 0;
     if (kan_upscale > 0) {
         kan_O = kan_upscale * kan_upscale;
         kan_nbh = J / 2;
     }
     return launch_reduce(slab, (int)g, J, K, (long)J * K + J, dW, K, 1, db, kan_O, kan_n_coef, kan_nbh, stream);
+}
+
+extern "C" int64_t ksr_gram_slab_floats(int J, int K, int nb, int64_t tokens_per_entry) {
+    const int Jp = (J + 31) / 32 * 32;
+    if (J <= 0 || K <= 0 || nb <= 0 || tokens_per_entry <= 0) return 0;
+    return (int64_t)nb * gram_grid(Jp, K, nb, (long)tokens_per_entry) * ((long)Jp * K + 2 * Jp + K);
+}
+
+// Batched Gram product over pixels: for each of nb entries (consecutive runs of tokens_per_entry pixels),
+//   out[e][j][k] = sum_n dz[n][j] * a[n][k],  tail[e][0:J] = sum_n dz[n][j]
+// and with want_sq (J a multiple of 32)  tail[e][J:2J] = sum_n dz[n][j]^2,  tail[e][2J:2J+K] = sum_n a[n][k]^2.
+// J a multiple of 4 (the last 32-row block may be partial), K 32 or 64.  slab: ksr_gram_slab_floats floats.
+extern "C" int ksr_gram_batched(const float* dz, int dz_ld, int dz_c0, int J, const float* a1, int a1_ld, int a1_c0,
+                                int K, int64_t tokens_per_entry, int nb, float* slab, float* out, float* tail,
+                                int want_sq, hipStream_t stream) {
+    KSR_CHECK_ARG(dz && a1 && slab && out, "gram_batched: null pointer");
+    KSR_CHECK_ARG(J > 0 && J % 4 == 0 && (K == 32 || K == 64), "gram_batched: J must be a multiple of 4 and K 32 or 64");
+    KSR_CHECK_ARG(tokens_per_entry > 0 && nb > 0 && nb <= 65535, "gram_batched: bad batch");
+    KSR_CHECK_ARG(!want_sq || (J % 32 == 0 && tail), "gram_batched: sums of squares need J % 32 == 0 and a tail buffer");
+    KSR_CHECK_ARG(dz_ld % 4 == 0 && dz_c0 % 4 == 0 && a1_ld % 4 == 0 && a1_c0 % 4 == 0,
+                  "gram_batched: leading dimensions and channel offsets must be multiples of 4");
+    const int Jp = (J + 31) / 32 * 32;
+    const int NKB = K / 32, per_wave = (Jp / 32 + (4 / NKB) - 1) / (4 / NKB);
+    KSR_UNSUPPORTED(per_wave > WG_MAXP, "gram_batched: J=%d too large", J);
+    const long stride = (long)Jp * K + 2 * Jp + K;
+    WgArgs a{dz, dz_ld, dz_c0, Jp, a1, a1_ld, a1_c0, K, nullptr, 0, 0, slab, (long)tokens_per_entry, J, want_sq ? 1 : 0, stride};
+    int T; size_t lds_bytes;
+    wgrad_shape(Jp + K, &T, &lds_bytes);        // sized for padded rows: the masked reads stay inside the buffer
+    KSR_UNSUPPORTED(lds_bytes > 160 * 1024, "gram_batched: J=%d needs %zu bytes of LDS", J, lds_bytes);
+    const long g = gram_grid(Jp, K, nb, (long)tokens_per_entry);
+    if (int rc = launch_wgrad_kernel(a, per_wave, T, lds_bytes, (unsigned)g, (unsigned)nb, stream)) return rc;
+    const int tail_len = want_sq ? 2 * J + K : J;
+    return launch_reduce(slab, (int)g, J, K, stride, out, K, 1, tail, 0, 0, 0, stream, Jp * K, tail_len, nb, (long)J * K);
 }
 
 // out[0][c] = sum_n a[n][c]*b, out[1][c] = sum_n a[n][c] for 64 channels c; rows out_row_stride apart.
@@ -387,10 +466,10 @@ extern "C" int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b,
 }
 
 // Depthwise 3x3 (64 channels) parameter gradients: dW [64][1][3][3], db [64]. slab: 256*640 floats.
-extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, float* slab, float* dW,
-                                float* db, int B, int H, int W, hipStream_t stream) {
-    KSR_CHECK_ARG(in && ds && slab && dW && db && B > 0 && H > 0 && W > 0, "dwconv_wgrad: bad argument");
-    DwgArgs d{in, in_ld, in_c0, ds, slab, B, H, W};
+extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0,
+                                float* slab, float* dW, float* db, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(in && ds && slab && dW && db && B > 0 && H > 0 && W > 0 && ds_ld >= 64, "dwconv_wgrad: bad argument");
+    DwgArgs d{in, in_ld, in_c0, ds, ds_ld, ds_c0, slab, B, H, W};
     long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
     const long g = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)g), dim3(256), 0, stream, d);

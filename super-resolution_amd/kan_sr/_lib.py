@@ -36,7 +36,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2")):
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries")):
             return fn
 
         def timed(*args):
@@ -71,6 +71,7 @@ def _declare(L: ctypes.CDLL) -> None:
     for name in EXPORTS:
         getattr(L, name).restype = c_int
     L.ksr_last_error.restype = c_char_p
+    L.ksr_gram_slab_floats.restype = c_int64
 
 
 # every symbol include/ksr.h declares (checked by tests/test_abi_symbols.py)
@@ -86,6 +87,8 @@ EXPORTS = [
     "ksr_wgrad_slab_floats", "ksr_wgrad", "ksr_colreduce", "ksr_dwconv_wgrad", "ksr_stem_scalar_wgrad", "ksr_outer2",
     "ksr_l1_y_loss", "ksr_adam_step", "ksr_comm_unique_id", "ksr_comm_init", "ksr_allreduce_sum", "ksr_comm_nranks",
     "ksr_comm_destroy",
+    "ksr_pointwise_bwd", "ksr_chan_dw_fwd", "ksr_chan_dw_bwd", "ksr_gram_slab_floats", "ksr_gram_batched",
+    "ksr_chan_soft_fwd", "ksr_chan_soft_bwd", "ksr_sum_entries", "ksr_chan_apply",
 ]
 
 

@@ -1,0 +1,175 @@
+"""ConvSepKanAttention on the HIP path (reference: conv_sep_kan/conv_sep_kan_attention.py:9-71).
+
+Same constructor, parameter names and forward signature as the reference module.  The forward and
+backward are sequences of libksr kernels over NHWC pixels; PyTorch only owns the buffers, carries the
+tape nodes and does the NCHW <-> NHWC relayout at the module boundary.  Only in = mid = 64 channels and
+out in {40, 64, 160, 336} have kernels; anything else raises KsrError.
+"""
+from __future__ import annotations
+
+from ctypes import c_int, c_int64
+
+import torch
+import torch.nn as nn
+
+from . import engine
+from ._lib import KsrError, check, lib, ptr, stream
+
+SUPPORTED_OUT = (40, 64, 160, 336)
+
+
+def _new(dev, *shape):
+    return torch.empty(*shape, device=dev, dtype=torch.float32)
+
+
+def _gram(dz, dz_c0, J, a, a_c0, HW, B, want_sq):
+    """Per-image sum over pixels of dz[:, dz_c0:dz_c0+J]^T a[:, a_c0:a_c0+64]; returns (out [B,J,64], tail)."""
+    L = lib()
+    dev = dz.device
+    slab = _new(dev, max(1, int(L.ksr_gram_slab_floats(c_int(J), c_int(64), c_int(B), c_int64(HW)))))
+    out = _new(dev, B, J, 64)
+    tail = _new(dev, B, 2 * J + 64 if want_sq else J)
+    check(L.ksr_gram_batched(ptr(dz), c_int(dz.shape[1]), c_int(dz_c0), c_int(J), ptr(a), c_int(a.shape[1]), c_int(a_c0),
+                             c_int(64), c_int64(HW), c_int(B), ptr(slab), ptr(out), ptr(tail), c_int(int(want_sq)),
+                             stream()), "ksr_gram_batched")
+    return out, tail
+
+
+class _QkvFn(torch.autograd.Function):
+    """qkv [N,192] = dw3x3(pw(x)) for the three branches at once (weights concatenated q | k | v)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, dw_w, dw_b, dims, precision):
+        B, H, W = dims
+        engine.set_precision(precision)
+        L = lib()
+        N = x.shape[0]
+        pq = _new(x.device, N, 192)
+        check(L.ksr_pointwise_fwd(ptr(x), ptr(w), ptr(b), ptr(pq), c_int(192), c_int(0), c_int(B), c_int(H), c_int(W),
+                                  stream()), "ksr_pointwise_fwd")
+        qkv = _new(x.device, N, 192)
+        check(L.ksr_chan_dw_fwd(ptr(pq), ptr(dw_w), ptr(dw_b), ptr(qkv), c_int(192), c_int(3), c_int(B), c_int(H),
+                                c_int(W), stream()), "ksr_chan_dw_fwd")
+        ctx.save_for_backward(x, w, dw_w, pq)
+        ctx.cfg = (dims, precision)
+        return qkv
+
+    @staticmethod
+    def backward(ctx, dqkv):
+        x, w, dw_w, pq = ctx.saved_tensors
+        (B, H, W), precision = ctx.cfg
+        engine.set_precision(precision)
+        L = lib()
+        dev = x.device
+        N = x.shape[0]
+        dqkv = dqkv.contiguous()
+        dpq = _new(dev, N, 192)
+        check(L.ksr_chan_dw_bwd(ptr(dqkv), ptr(dw_w), ptr(dpq), c_int(192), c_int(3), c_int(B), c_int(H), c_int(W),
+                                stream()), "ksr_chan_dw_bwd")
+        g_dw_w, g_dw_b = _new(dev, 192, 9), _new(dev, 192)
+        slab = _new(dev, max(256 * 640, int(L.ksr_wgrad_slab_floats(c_int(192), c_int(64)))))
+        for gi in range(3):
+            check(L.ksr_dwconv_wgrad(ptr(pq), c_int(192), c_int(64 * gi), ptr(dqkv), c_int(192), c_int(64 * gi), ptr(slab),
+                                     ptr(g_dw_w[64 * gi:64 * gi + 64]), ptr(g_dw_b[64 * gi:64 * gi + 64]),
+                                     c_int(B), c_int(H), c_int(W), stream()), "ksr_dwconv_wgrad")
+        g_w, g_b = _new(dev, 192, 64), _new(dev, 192)
+        check(L.ksr_wgrad(ptr(dpq), c_int(192), c_int(0), c_int(192), ptr(x), c_int(64), c_int(0), c_int(64),
+                          ptr(None), c_int(0), c_int(0), c_int64(N), ptr(slab), ptr(g_w), ptr(g_b), c_int(0), c_int(0),
+                          stream()), "ksr_wgrad")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _new(dev, N, 64)
+            check(L.ksr_pointwise_bwd(ptr(dpq), c_int(192), ptr(w), ptr(dx), c_int(B), c_int(H), c_int(W), stream()),
+                  "ksr_pointwise_bwd")
+        return dx, g_w, g_b, g_dw_w, g_dw_b, None, None
+
+
+class _AttnCoreFn(torch.autograd.Function):
+    """y [N,P] = a_proj(softmax(q^^T k^) v) from qkv [N,192]."""
+
+    @staticmethod
+    def forward(ctx, qkv, wa, ba, dims, precision):
+        B, H, W = dims
+        HW = H * W
+        engine.set_precision(precision)
+        L = lib()
+        dev = qkv.device
+        P = wa.shape[0]
+        G, tail = _gram(qkv, 0, 64, qkv, 64, HW, B, True)
+        A, S, nrm, M = _new(dev, B, 64, 64), _new(dev, B, 64, 64), _new(dev, B, 128), _new(dev, B, P, 64)
+        check(L.ksr_chan_soft_fwd(ptr(G), ptr(tail), ptr(wa), ptr(A), ptr(S), ptr(nrm), ptr(M), c_int(P), c_int(B),
+                                  stream()), "ksr_chan_soft_fwd")
+        y = _new(dev, qkv.shape[0], P)
+        check(L.ksr_chan_apply(ptr(qkv), c_int(192), c_int(128), c_int(64), ptr(M), c_int(0), ptr(ba), ptr(y), c_int(P),
+                               c_int(0), c_int(P), c_int(B), c_int(HW), stream()), "ksr_chan_apply")
+        ctx.save_for_backward(qkv, wa, A, S, nrm, M)
+        ctx.cfg = (dims, precision)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        qkv, wa, A, S, nrm, M = ctx.saved_tensors
+        (B, H, W), precision = ctx.cfg
+        HW = H * W
+        engine.set_precision(precision)
+        L = lib()
+        dev = qkv.device
+        P = wa.shape[0]
+        dy = dy.contiguous()
+        Gd, colsum = _gram(dy, 0, P, qkv, 128, HW, B, False)
+        g_ba = _new(dev, P)
+        check(L.ksr_sum_entries(ptr(colsum), c_int(B), c_int64(P), c_int(P), ptr(g_ba), stream()), "ksr_sum_entries")
+        Mqk, part, g_wa = _new(dev, B, 128, 128), _new(dev, B, P, 64), _new(dev, P, 64)
+        check(L.ksr_chan_soft_bwd(ptr(Gd), ptr(A), ptr(S), ptr(nrm), ptr(wa), ptr(Mqk), ptr(part), ptr(g_wa), c_int(P),
+                                  c_int(B), stream()), "ksr_chan_soft_bwd")
+        dqkv = _new(dev, qkv.shape[0], 192)
+        check(L.ksr_chan_apply(ptr(dy), c_int(P), c_int(0), c_int(P), ptr(M), c_int(1), ptr(None), ptr(dqkv), c_int(192),
+                               c_int(128), c_int(64), c_int(B), c_int(HW), stream()), "ksr_chan_apply")
+        check(L.ksr_chan_apply(ptr(qkv), c_int(192), c_int(0), c_int(128), ptr(Mqk), c_int(0), ptr(None), ptr(dqkv),
+                               c_int(192), c_int(0), c_int(128), c_int(B), c_int(HW), stream()), "ksr_chan_apply")
+        return dqkv, g_wa, g_ba, None, None
+
+
+def _to_nhwc(t):
+    B, C, H, W = t.shape
+    return t.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+class ConvSepKanAttention(nn.Module):
+    """Drop-in for the reference class of the same name; `precision` ("fp32" | "bf16") is the only addition."""
+
+    def __init__(self, in_channels: int, mid_channels: int, out_channels: int):
+        super().__init__()
+        for n in ("q", "k", "v"):
+            setattr(self, n + "_proj", nn.Conv2d(in_channels, mid_channels, kernel_size=1))
+            setattr(self, n + "_dw", nn.Conv2d(mid_channels, mid_channels, kernel_size=3, stride=1, padding=1,
+                                               groups=mid_channels))
+        self.a_proj = nn.Conv2d(mid_channels, out_channels, kernel_size=1)
+        # defined by the reference (conv_sep_kan_attention.py:41-46) and never used by its forward
+        self.a_dw = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, groups=out_channels)
+        self.in_channels, self.mid_channels, self.out_channels = in_channels, mid_channels, out_channels
+        self.precision = "fp32"
+
+    def forward_nhwc(self, x, dims, q=None, k=None, v=None):
+        """x [N,64] (N = B*H*W pixels, NHWC order) -> [N,out]; q, k, v optional precomputed [N,64] branches."""
+        if self.in_channels != 64 or self.mid_channels != 64 or self.out_channels not in SUPPORTED_OUT:
+            raise KsrError(f"ConvSepKanAttention({self.in_channels}, {self.mid_channels}, {self.out_channels}): the HIP "
+                           f"path has kernels for in = mid = 64 and out in {SUPPORTED_OUT}")
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise KsrError("ConvSepKanAttention needs fp32 GPU tensors (the HIP path is the only path)")
+        w = torch.cat([getattr(self, n + "_proj").weight.reshape(64, 64) for n in "qkv"])
+        b = torch.cat([getattr(self, n + "_proj").bias for n in "qkv"])
+        dw_w = torch.cat([getattr(self, n + "_dw").weight.reshape(64, 9) for n in "qkv"])
+        dw_b = torch.cat([getattr(self, n + "_dw").bias for n in "qkv"])
+        qkv = _QkvFn.apply(x.contiguous(), w, b, dw_w, dw_b, dims, self.precision)
+        if q is not None or k is not None or v is not None:
+            parts = [qkv[:, 0:64] if q is None else q, qkv[:, 64:128] if k is None else k,
+                     qkv[:, 128:192] if v is None else v]
+            qkv = torch.cat(parts, dim=1)
+        return _AttnCoreFn.apply(qkv, self.a_proj.weight.reshape(self.out_channels, 64), self.a_proj.bias, dims,
+                                 self.precision)
+
+    def forward(self, x, q=None, k=None, v=None):
+        B, C, H, W = x.shape
+        y = self.forward_nhwc(_to_nhwc(x), (B, H, W), *(None if t is None else _to_nhwc(t) for t in (q, k, v)))
+        return y.reshape(B, H, W, self.out_channels).permute(0, 3, 1, 2).contiguous()

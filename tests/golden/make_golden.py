@@ -24,6 +24,7 @@ from conv_sep_kan.conv_sep_kan_cells import ConvSepKanCell             # noqa: E
 from conv_sep_kan.unet_blocks import FFN, GatedFFN                     # noqa: E402
 from conv_sep_kan.gazetr import GazeTR                                 # noqa: E402
 from conv_sep_kan import ConvSepKan                                    # noqa: E402
+from conv_sep_kan.conv_sep_kan_attention import ConvSepKanAttention    # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 torch.set_num_threads(4)
@@ -222,7 +223,30 @@ def gold_dropout_stats():
     save("dropout_stats", **out)
 
 
+# ---------------------------------------------------------------- (7) channel attention
+def gold_chan_attention():
+    out = {}
+    for tag, cout, (B, H, W) in [("o64", 64, (2, 8, 8)), ("o160", 160, (2, 8, 8)), ("o336", 336, (3, 9, 11))]:
+        torch.manual_seed(70 + cout)
+        gen = torch.Generator().manual_seed(70 + cout)
+        m = ConvSepKanAttention(64, 64, cout)
+        x = torch.randn(B, 64, H, W, generator=gen).requires_grad_()
+        y = m(x)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out.update({f"{tag}.x": x, f"{tag}.y": y, f"{tag}.gy": gy, f"{tag}.gx": x.grad})
+        for n, p in m.named_parameters():
+            out[f"{tag}.p.{n}"] = p
+            if p.grad is not None:
+                out[f"{tag}.g.{n}"] = p.grad
+    save("chan_attention", **out)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()["gold_" + name]()
+        sys.exit(0)
     gold_bspline()
     gold_kan_layer()
     gold_cell()
@@ -231,3 +255,4 @@ if __name__ == "__main__":
     gold_model()
     gold_cfg1()
     gold_dropout_stats()
+    gold_chan_attention()

@@ -1,0 +1,140 @@
+"""ConvSepKanAttention on the HIP path against the reference goldens and the CPU oracle."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2, t
+from oracle import convsepkan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+FWD_ATOL, FWD_RTOL, GRAD_REL = 1e-5, 1e-4, 1e-4
+
+
+def assert_fwd(a, ref, atol=FWD_ATOL, rtol=FWD_RTOL):
+    a, ref = a.detach().cpu(), ref.detach().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    err = (a - ref).abs()
+    assert bool((err <= atol + rtol * ref.abs()).all()), f"max err {float(err.max()):.3e} (ref max {float(ref.abs().max()):.3e})"
+
+
+def _module(cout, params):
+    from kan_sr.chan_attention import ConvSepKanAttention
+    m = ConvSepKanAttention(64, 64, cout)
+    m.load_state_dict({k: v.detach().clone() for k, v in params.items()})
+    return m.cuda()
+
+
+@pytest.mark.parametrize("tag,cout", [("o64", 64), ("o160", 160), ("o336", 336)])
+def test_golden_forward_and_gradients(tag, cout):
+    g = load_golden("chan_attention")
+    params = {k[len(tag) + 3:]: t(v) for k, v in g.items() if k.startswith(tag + ".p.")}
+    m = _module(cout, params)
+    x = t(g[tag + ".x"]).cuda().requires_grad_()
+    y = m(x)
+    assert y.is_contiguous()
+    assert_fwd(y, t(g[tag + ".y"]))
+    y.backward(t(g[tag + ".gy"]).cuda())
+    assert rel_l2(x.grad.cpu(), t(g[tag + ".gx"])) <= GRAD_REL
+    for n, p in m.named_parameters():
+        if n.startswith("a_dw."):
+            assert p.grad is None
+        else:
+            assert rel_l2(p.grad.cpu(), t(g[f"{tag}.g.{n}"])) <= GRAD_REL, n
+
+
+def _oracle_run(params, x, gy, q=None, k=None, v=None):
+    p = {n: w.clone().requires_grad_() for n, w in params.items()}
+    xs = [None if a is None else a.clone().requires_grad_() for a in (x, q, k, v)]
+    y = orc.chan_attention(xs[0], p, "", *xs[1:])
+    (y * gy).sum().backward()
+    return y.detach(), p, xs
+
+
+@pytest.mark.parametrize("B,H,W,cout", [(1, 5, 7, 40), (3, 37, 45, 160), (2, 64, 96, 336), (5, 3, 130, 64)])
+def test_vs_oracle_ragged_sizes(B, H, W, cout):
+    """Sizes that are not multiples of the 4x32 conv tile, the 128-pixel GEMM tile or the 64-pixel Gram chunk."""
+    torch.manual_seed(B * 1000 + H)
+    from kan_sr.chan_attention import ConvSepKanAttention
+    ref = ConvSepKanAttention(64, 64, cout)
+    params = {n: w.detach().clone() for n, w in ref.state_dict().items()}
+    x, gy = torch.randn(B, 64, H, W), torch.randn(B, cout, H, W)
+    y_ref, p_ref, xs = _oracle_run(params, x, gy)
+    m = _module(cout, params)
+    xg = x.cuda().requires_grad_()
+    y = m(xg)
+    assert_fwd(y, y_ref)
+    y.backward(gy.cuda())
+    assert rel_l2(xg.grad.cpu(), xs[0].grad) <= GRAD_REL
+    for n, p in m.named_parameters():
+        if not n.startswith("a_dw."):
+            assert rel_l2(p.grad.cpu(), p_ref[n].grad) <= GRAD_REL, n
+
+
+def test_precomputed_branches():
+    """forward(x, q, k, v) with caller-supplied branches (conv_sep_kan_attention.py:52-57)."""
+    torch.manual_seed(5)
+    from kan_sr.chan_attention import ConvSepKanAttention
+    ref = ConvSepKanAttention(64, 64, 160)
+    params = {n: w.detach().clone() for n, w in ref.state_dict().items()}
+    B, H, W = 2, 9, 12
+    x, gy = torch.randn(B, 64, H, W), torch.randn(B, 160, H, W)
+    k, v = torch.randn(B, 64, H, W), torch.randn(B, 64, H, W)
+    y_ref, p_ref, xs = _oracle_run(params, x, gy, None, k, v)
+    m = _module(160, params)
+    xg, kg, vg = (a.cuda().requires_grad_() for a in (x, k, v))
+    y = m(xg, k=kg, v=vg)
+    assert_fwd(y, y_ref)
+    y.backward(gy.cuda())
+    assert rel_l2(xg.grad.cpu(), xs[0].grad) <= GRAD_REL
+    assert rel_l2(kg.grad.cpu(), xs[2].grad) <= GRAD_REL
+    assert rel_l2(vg.grad.cpu(), xs[3].grad) <= GRAD_REL
+    assert rel_l2(m.q_proj.weight.grad.cpu(), p_ref["q_proj.weight"].grad) <= GRAD_REL
+    # the k and v branches are computed but unused: their parameters get zero gradient
+    assert float(m.k_proj.weight.grad.abs().max()) == 0.0
+
+
+def test_gram_batched_properties():
+    """Batched Gram product at a size the oracle does not cover: equals torch.einsum in fp64 and is
+    independent of how the pixels are split into workgroups (bitwise reproducible)."""
+    from ctypes import c_int, c_int64
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(1)
+    B, HW, J = 6, 40000, 336
+    dz = torch.randn(B * HW, J, device="cuda")
+    a = torch.randn(B * HW, 192, device="cuda")
+    L = lib()
+    outs = []
+    for _ in range(2):
+        slab = torch.empty(int(L.ksr_gram_slab_floats(c_int(J), c_int(64), c_int(B), c_int64(HW))), device="cuda")
+        out, tail = torch.empty(B, J, 64, device="cuda"), torch.empty(B, J, device="cuda")
+        check(L.ksr_gram_batched(ptr(dz), c_int(J), c_int(0), c_int(J), ptr(a), c_int(192), c_int(128), c_int(64), c_int64(HW),
+                                 c_int(B), ptr(slab), ptr(out), ptr(tail), c_int(0), stream()), "gram")
+        outs.append((out.clone(), tail.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.einsum("bnj,bnk->bjk", dz.view(B, HW, J).double(), a.view(B, HW, 192)[:, :, 128:].double())
+    assert rel_l2(outs[0][0].double().cpu(), ref.cpu()) <= 1e-5
+    assert rel_l2(outs[0][1].double().cpu(), dz.view(B, HW, J).double().sum(1).cpu()) <= 1e-5
+
+
+def test_bf16_mode():
+    """bf16 MFMA operands in the 1x1 convs (build-side mode).  Stated tolerance: forward rel-L2 <= 2e-2,
+    gradients cosine >= 0.999 and rel-L2 <= 5e-2."""
+    g = load_golden("chan_attention")
+    tag, cout = "o160", 160
+    params = {k[len(tag) + 3:]: t(v) for k, v in g.items() if k.startswith(tag + ".p.")}
+    m = _module(cout, params)
+    m.precision = "bf16"
+    x = t(g[tag + ".x"]).cuda().requires_grad_()
+    y = m(x)
+    assert rel_l2(y.detach().cpu(), t(g[tag + ".y"])) <= 2e-2
+    y.backward(t(g[tag + ".gy"]).cuda())
+    for n, p in list(m.named_parameters()) + [("x", x)]:
+        if n.startswith("a_dw."):
+            continue
+        ref = t(g[f"{tag}.gx"]) if n == "x" else t(g[f"{tag}.g.{n}"])
+        got = p.grad.cpu().flatten().double()
+        ref = ref.flatten().double()
+        cos = float((got * ref).sum() / (got.norm() * ref.norm()))
+        assert cos >= 0.999 and rel_l2(got, ref) <= 5e-2, (n, cos, rel_l2(got, ref))
+    from kan_sr import engine
+    engine.set_precision("fp32")

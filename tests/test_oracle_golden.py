@@ -152,3 +152,20 @@ def test_cfg1_shape_smoke():
     assert_fwd(y[:, :, :4, :4], t(g["y_corner"]))
     assert_fwd(y[1, 0, 77], t(g["y_row"]))
     assert abs(float(y.double().sum()) - float(g["y_sum"])) < 1e-2
+
+
+@pytest.mark.parametrize("tag", ["o64", "o160", "o336"])
+def test_chan_attention(tag):
+    """ConvSepKanAttention (conv_sep_kan/conv_sep_kan_attention.py:48-71) forward and gradients."""
+    g = load_golden("chan_attention")
+    p = {k[len(tag) + 3:]: t(v).requires_grad_() for k, v in g.items() if k.startswith(tag + ".p.")}
+    x = t(g[tag + ".x"]).requires_grad_()
+    y = orc.chan_attention(x, p, "")
+    assert_fwd(y.detach(), t(g[tag + ".y"]))
+    (y * t(g[tag + ".gy"])).sum().backward()
+    assert rel_l2(x.grad, t(g[tag + ".gx"])) <= GRAD_REL
+    for n, v in p.items():
+        if n.startswith("a_dw."):
+            assert v.grad is None and f"{tag}.g.{n}" not in g      # defined, never used by the forward
+        else:
+            assert rel_l2(v.grad, t(g[f"{tag}.g.{n}"])) <= GRAD_REL, n
