@@ -212,14 +212,19 @@ def bilinear_up(x: torch.Tensor, r: int) -> torch.Tensor:
 # --------------------------------------------------------------------------- whole model
 def conv_sep_kan_forward(x: torch.Tensor, p: Params, *, out_channels: Sequence[int],
                          grid_size: int, spline_order: int, grid_range: Sequence[float],
-                         upscale: int, in_channels: Sequence[int] = (1,)) -> torch.Tensor:
+                         upscale: int, in_channels: Sequence[int] = (1,), attention: bool = False) -> torch.Tensor:
     """x [B,3,H,W] (Y,Cb,Cr) -> [B,3,rH,rW].  Every layer sees the Y plane; only the
-    last layer's output survives (the reference's loop overwrites y)."""
+    last layer's output survives (the reference's loop overwrites y).
+    attention=True: the `feed` 1x1 conv is replaced by chan_attention (parameters under `...feed.`), a wiring
+    the reference itself does not contain (its ConvSepKanAttention is a stand-alone module)."""
     n_layers = len(out_channels)
     li = n_layers - 1
     prefix = f"layers.{li}.encoder.encoder."
     yplane = x[:, :1]
-    w = gazetr(yplane, p, prefix)
+    if attention:
+        w = chan_attention(gazetr_features(yplane, p, prefix), p, prefix + "feed.")
+    else:
+        w = gazetr(yplane, p, prefix)
     y = kan_cell(yplane, w, out_channels[li], grid_size, spline_order, grid_range)
     y = pixel_shuffle(y, upscale)
     cb = bilinear_up(x[:, 1:2], upscale)

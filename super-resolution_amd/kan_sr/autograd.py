@@ -222,6 +222,16 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
     gw, gb = ws.grad(pre + "feed.weight", P, 64, 1, 1), ws.grad(pre + "feed.bias", P)
     _wgrad(ws, gparam, 2 * lane_len, 0, 2 * lane_len, sv["feat"], 64, 0, 64, N, gw, gb, kan=(g.r, g.n_coef))
     grads[pre + "feed.weight"], grads[pre + "feed.bias"] = gw, gb
+    trunk_backward(ws, gfeat, x, p, pre, g, sv, p_drop, seed, grads, on_tail_done)
+    return grads
+
+
+def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Geometry,
+                   sv: dict, p_drop: float, seed: int, grads: Dict[str, torch.Tensor], on_tail_done=None) -> None:
+    """Backward of engine.encoder_forward from gfeat [N,64] (gradient of the final-LayerNormed features):
+    fills `grads` for every encoder parameter except `feed`."""
+    L = lib()
+    N = g.N
     # ---- transformer layers ----
     d = _tx_layer_backward(ws, gfeat, 1, p, pre, g, sv["tx1"], p_drop, seed, grads, None)
     dz6 = _tx_layer_backward(ws, d, 0, p, pre, g, sv["tx0"], p_drop, seed, grads, sv["x6"])
@@ -247,7 +257,6 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
     grads[q + "pointwise1.weight"], grads[q + "pointwise1.bias"] = gw, gb
     # ---- ffn2 (gated) + ffn1 ----
     _gated_backward(ws, dz2, "ffn2", p, pre, g, sv["t2"], sv["g2"], grads, None, stem_saves=sv["v"], x_img=x)
-    return grads
 
 
 class _ConvSepKanFn(torch.autograd.Function):
@@ -292,3 +301,41 @@ def conv_sep_kan_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_d
         if not t.is_contiguous():
             raise KsrError("parameters must be contiguous")
     return _ConvSepKanFn.apply(x, pre, g, p_drop, seed, names, precision, *params)
+
+
+class _TrunkFn(torch.autograd.Function):
+    """Encoder trunk alone (everything before `feed`): x [B,3,H,W] -> features [N,64], for heads other
+    than the fused feed+KAN kernel."""
+
+    @staticmethod
+    def forward(ctx, x, pre, g, p_drop, seed, names, precision, *params):
+        p = dict(zip(names, params))
+        sv: dict = {}
+        feat = engine.encoder_forward(x, p, pre, g, sv, p_drop, seed)
+        ctx.sv, ctx.x, ctx.p = sv, x, p
+        ctx.cfg = (pre, g, p_drop, seed, names, precision)
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        pre, g, p_drop, seed, names, precision = ctx.cfg
+        engine.set_precision(precision)
+        if ctx.needs_input_grad[0]:
+            raise KsrError("gradient with respect to the input image is not implemented")
+        grads: Dict[str, torch.Tensor] = {}
+        trunk_backward(_Ws(ctx.x.device), gfeat.contiguous(), ctx.x, ctx.p, pre, g, ctx.sv, p_drop, seed, grads)
+        ctx.sv = None
+        out = []
+        for n, t in zip(names, ctx.p.values()):
+            gr = grads.get(n)
+            out.append(None if gr is None else gr.reshape(t.shape))
+        return (None, None, None, None, None, None, None, *out)
+
+
+def trunk_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_drop: float, seed: int, precision: str = "fp32"):
+    names = [pre + n for n in PARAM_ORDER if not n.startswith("feed.")]
+    params = [p[n] for n in names]
+    for t in params:
+        if not t.is_contiguous():
+            raise KsrError("parameters must be contiguous")
+    return _TrunkFn.apply(x, pre, g, p_drop, seed, names, precision, *params)

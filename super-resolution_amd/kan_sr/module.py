@@ -61,7 +61,7 @@ class TransformerEncoder(_Container):       # conv_sep_kan/gazetr.py:16-22
 
 
 class GazeTR(_Container):                   # conv_sep_kan/gazetr.py:69-98
-    def __init__(self, in_channels, out_channels):
+    def __init__(self, in_channels, out_channels, attention=False):
         super().__init__()
         self.ffn1 = FFN(in_channels, MID)
         self.ffn2 = GatedFFN(MID)
@@ -69,13 +69,17 @@ class GazeTR(_Container):                   # conv_sep_kan/gazetr.py:69-98
         self.ffn4 = GatedFFN(MID)
         layer = TransformerEncoderLayer(MID, 2, 32, 0.1)
         self.encoder = TransformerEncoder(layer, 2, nn.LayerNorm(MID))
-        self.feed = nn.Conv2d(MID, out_channels, kernel_size=1)
+        if attention:
+            from .chan_attention import ConvSepKanAttention
+            self.feed = ConvSepKanAttention(MID, MID, out_channels)
+        else:
+            self.feed = nn.Conv2d(MID, out_channels, kernel_size=1)
 
 
 class ConvSepKanEncoder(_Container):        # conv_sep_kan/conv_sep_kan_encoder.py:12-17
-    def __init__(self, in_channels, out_channels):
+    def __init__(self, in_channels, out_channels, attention=False):
         super().__init__()
-        self.encoder = GazeTR(in_channels, out_channels)
+        self.encoder = GazeTR(in_channels, out_channels, attention)
 
 
 class ConvSepKanCell(_Container):           # conv_sep_kan/conv_sep_kan_cells.py:106-134 (no parameters)
@@ -87,20 +91,26 @@ class ConvSepKanCell(_Container):           # conv_sep_kan/conv_sep_kan_cells.py
 
 
 class ConvSepKanLayer(_Container):          # conv_sep_kan/conv_sep_kan_layer.py:7-15
-    def __init__(self, in_channels, out_channels, grid_size, spline_order, residual_std, grid_range):
+    def __init__(self, in_channels, out_channels, grid_size, spline_order, residual_std, grid_range, attention=False):
         super().__init__()
         self.kan_cell = ConvSepKanCell(in_channels, out_channels, grid_size, spline_order, residual_std, grid_range)
-        self.encoder = ConvSepKanEncoder(in_channels, self.kan_cell.size)
+        self.encoder = ConvSepKanEncoder(in_channels, self.kan_cell.size, attention)
 
 
 class ConvSepKan(nn.Module):
     """Same constructor arguments as the reference; `kernel_sizes` and `residual_std` are accepted and
-    unused there too.  forward(x[B,3,H,W]) -> [B,3,rH,rW] (Y', Cb, Cr)."""
+    unused there too.  forward(x[B,3,H,W]) -> [B,3,rH,rW] (Y', Cb, Cr).
+
+    attention=True (keyword only, not in the reference's constructor) is this build's wiring of the
+    reference's stand-alone ConvSepKanAttention (conv_sep_kan/conv_sep_kan_attention.py) into the model: the
+    `feed` 1x1 conv that maps the 64 encoder features to the per-pixel KAN parameters is replaced by
+    ConvSepKanAttention(64, 64, P) (state_dict keys `...encoder.encoder.feed.{q,k,v,a}_{proj,dw}.*`)."""
 
     def __init__(self, in_channels: list, out_channels: list, kernel_sizes: list, grid_size, spline_order,
-                 residual_std, grid_range, upscale):
+                 residual_std, grid_range, upscale, *, attention: bool = False):
         super().__init__()
         self.upscale = upscale
+        self.attention = attention
         self.grid_size, self.spline_order, self.grid_range = grid_size, spline_order, list(grid_range)
         # "fp32": exact fp32 MFMA (parity with the reference to fp32 round-off); "bf16": bf16 MFMA operands with
         # fp32 accumulation (separately stated tolerance).  Not part of the reference's constructor.
@@ -108,7 +118,8 @@ class ConvSepKan(nn.Module):
         self.layers = nn.ModuleList()
         self.shuffle = nn.PixelShuffle(upscale)          # kept for module-tree parity; no parameters
         for in_ch, out_ch in zip(in_channels, out_channels):
-            self.layers.append(ConvSepKanLayer(in_ch, out_ch, grid_size, spline_order, residual_std, grid_range))
+            self.layers.append(ConvSepKanLayer(in_ch, out_ch, grid_size, spline_order, residual_std, grid_range,
+                                               attention))
         if len(self.layers) == 0:
             raise KsrError("ConvSepKan needs at least one layer")
         # Every layer is fed the Y plane and only the last layer's output survives the reference's
@@ -133,8 +144,24 @@ class ConvSepKan(nn.Module):
         needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in p.values())
         p_drop = self.layers[-1].encoder.encoder.encoder.layers[0].p_drop if self.training else 0.0
         seed = engine.new_seed() if p_drop > 0 else 0
+        if self.attention:
+            return self._forward_attention(x, p, pre, g, p_drop, seed, needs_grad)
         if not needs_grad:
             with torch.no_grad():
                 return engine.forward_infer(x, p, pre, g, p_drop, seed)
         from .autograd import conv_sep_kan_train
         return conv_sep_kan_train(x, p, pre, g, p_drop, seed, self.precision)
+
+    def _forward_attention(self, x, p, pre, g, p_drop, seed, needs_grad):
+        """Encoder trunk -> channel attention head -> KAN + pixel shuffle + chroma."""
+        from .ops import kan_head
+        head = self.layers[-1].encoder.encoder.feed
+        head.precision = self.precision
+        with torch.set_grad_enabled(needs_grad):
+            if needs_grad:
+                from .autograd import trunk_train
+                feat = trunk_train(x, p, pre, g, p_drop, seed, self.precision)
+            else:
+                feat = engine.encoder_forward(x, p, pre, g, None, p_drop, seed)
+            w = head.forward_nhwc(feat, (g.B, g.H, g.W))
+            return kan_head(x, w, self.grid_size, self.spline_order, self.grid_range, self.upscale)

@@ -73,6 +73,49 @@ def kan_cell(x: torch.Tensor, w: torch.Tensor, out_dim: int, grid_size: int, spl
     return _KanCell.apply(x, w, out_dim, grid_size + spline_order, knots, spline_order, shuffle_r, w_nhwc)
 
 
+class _KanHead(torch.autograd.Function):
+    """Output assembly of ConvSepKan.forward (conv_sep_kan/conv_sep_kan.py:28-41) from a materialised
+    per-pixel parameter tensor w [B*H*W, P]: Y' = PixelShuffle(KAN(Y; w)) into plane 0, bilinear Cb/Cr
+    into planes 1, 2 of one [B,3,rH,rW] tensor."""
+
+    @staticmethod
+    def forward(ctx, x, w, n_coef, knots, spline_order, r):
+        x, w = _f32c(x), _f32c(w)
+        B, _, H, W = x.shape
+        out = torch.empty(B, 3, H * r, W * r, device=x.device, dtype=torch.float32)
+        bilinear_up_into(x, out, r, 1, 2, 1)
+        y = x[:, :1].contiguous()
+        kn = host_floats(knots)
+        check(lib().ksr_kan_cell_fwd(ptr(y), ptr(w), ptr(out), c_int(B), c_int(1), c_int(r * r), c_int(H), c_int(W),
+                                     c_int(n_coef), kn, c_int(len(knots)), c_int(spline_order), c_int(1), c_int(r),
+                                     c_int64(3 * H * r * W * r), stream()), "ksr_kan_cell_fwd")
+        ctx.save_for_backward(y, w)
+        ctx.cfg = (n_coef, knots, spline_order, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, w = ctx.saved_tensors
+        n_coef, knots, spline_order, r = ctx.cfg
+        B, _, H, W = y.shape
+        if ctx.needs_input_grad[0]:
+            raise _lib.KsrError("gradient with respect to the input image is not implemented")
+        gout = _f32c(gout)
+        gw = torch.empty_like(w)
+        kn = host_floats(knots)
+        check(lib().ksr_kan_cell_bwd(ptr(y), ptr(w), ptr(gout), ptr(gw), ptr(None), c_int(B), c_int(1), c_int(r * r),
+                                     c_int(H), c_int(W), c_int(n_coef), kn, c_int(len(knots)), c_int(spline_order),
+                                     c_int(1), c_int(r), c_int64(3 * H * r * W * r), stream()), "ksr_kan_cell_bwd")
+        return None, gw, None, None, None, None
+
+
+def kan_head(x: torch.Tensor, w: torch.Tensor, grid_size: int, spline_order: int, grid_range: Sequence[float],
+             r: int) -> torch.Tensor:
+    """x [B,3,H,W], w [B*H*W, r*r*(G+k+2)] -> [B,3,rH,rW]."""
+    knots = make_knots(grid_size, spline_order, grid_range)
+    return _KanHead.apply(x, w, grid_size + spline_order, knots, spline_order, r)
+
+
 def bilinear_up_into(x: torch.Tensor, out: torch.Tensor, r: int, in_channel0: int, n_channels: int,
                      out_channel0: int) -> None:
     """Upsample planes [in_channel0, in_channel0+n) of x [B,C,H,W] into planes out_channel0.. of

@@ -138,3 +138,34 @@ def test_bf16_mode():
         assert cos >= 0.999 and rel_l2(got, ref) <= 5e-2, (n, cos, rel_l2(got, ref))
     from kan_sr import engine
     engine.set_precision("fp32")
+
+
+@pytest.mark.parametrize("r,G,B,H,W", [(4, 16, 2, 12, 20), (4, 5, 3, 16, 16), (2, 5, 1, 9, 33)])
+def test_model_with_attention_head(r, G, B, H, W):
+    """ConvSepKan(..., attention=True): encoder trunk -> ConvSepKanAttention(64, 64, P) -> KAN -> shuffle, against
+    the oracle built from the same reference-pinned pieces (the wiring itself is not in the reference)."""
+    from kan_sr.module import ConvSepKan
+    torch.manual_seed(40 + G)
+    m = ConvSepKan([1], [r * r], [3], G, 3, 0.1, [-1, 1], r, attention=True).eval()
+    with torch.no_grad():
+        for n, prm in m.named_parameters():          # non-degenerate LayerNorm gains / biases
+            if "norm" in n:
+                prm.add_(0.1 * torch.randn_like(prm))
+    params = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    x, gy = torch.rand(B, 3, H, W), torch.randn(B, 3, r * H, r * W)
+    p_ref = {n: v.clone().requires_grad_() for n, v in params.items()}
+    y_ref = orc.conv_sep_kan_forward(x, p_ref, out_channels=[r * r], grid_size=G, spline_order=3, grid_range=[-1, 1],
+                                     upscale=r, attention=True)
+    (y_ref * gy).sum().backward()
+    m = m.cuda()
+    with torch.no_grad():
+        assert_fwd(m(x.cuda()), y_ref, atol=2e-5)
+    y = m(x.cuda())
+    assert_fwd(y, y_ref, atol=2e-5)
+    y.backward(gy.cuda())
+    for n, prm in m.named_parameters():
+        if ".a_dw." in n:
+            assert prm.grad is None
+            continue
+        ref = p_ref[n].grad
+        assert rel_l2(prm.grad.cpu(), ref) <= 2e-4 or float((prm.grad.cpu() - ref).norm()) <= 1e-7, (n, rel_l2(prm.grad.cpu(), ref))
