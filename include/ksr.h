@@ -207,7 +207,7 @@ int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b, int b_is_p
 
 /* Depthwise 3x3 parameter gradients (64 channels): in = the conv's input (NHWC, in_ld channels per pixel,
  * 64 channels from in_c0), ds = gradient of its output (ds_ld channels per pixel, 64 from ds_c0).
- * dW [64,1,3,3], db [64]. slab: 256*640 floats. */
+ * dW [64,1,3,3], db [64]. slab: 512*640 floats. */
 int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0, float* slab,
                      float* dW, float* db, int B, int H, int W, ksr_stream_t stream);
 

@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int WG_MAXP = 6;     // output blocks per wave
+constexpr int WG_MAXP = 6;     // at most this many dz blocks per wave
 constexpr int WG_GRID = 1024;  // at most this many workgroups / partial slabs
 
 struct WgArgs {
@@ -26,29 +26,41 @@ struct WgArgs {
 };
 
 // Each workgroup walks its pixel range in chunks of WG_T pixels.  A chunk's rows [dz | a1 | a2] are copied
-// global -> LDS by 16-byte LDS-DMA loads (lane-linear image = row-major [32][RL]), double buffered: the
+// global -> LDS by 16-byte LDS-DMA loads (lane-linear image = row-major [WG_T][RL]), double buffered: the
 // loads of chunk c+1 are in flight while the MFMAs of chunk c run.  Operands are then read from LDS with
-// conflict-free ds_read_b32 (lane = column).  Wave w owns column block kb = w % (K/32) of A and the
-// dz blocks jb = w / (K/32) + i * (4 / (K/32)).
-template <int WG_T, int MAXP>   // pixels per staged chunk; output blocks per wave
+// conflict-free ds_read_b32 (lane = column), four pixel pairs ahead of the MFMAs that consume them.
+// Wave w owns column block kb = w % (K/32) of A and the dz blocks jb = w / (K/32) + p * (4 / (K/32)),
+// p < NP; blocks past the end (and channels >= Jv of a partial block) are multiplied by 0.
+template <int WG_T, int NP, bool HAS2>   // pixels per staged chunk; dz blocks per wave; a2 present
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kk = lane >> 5;
     const int NJB = a.J / 32, NKB = a.K / 32;
     const int kb = wv % NKB, jb0 = wv / NKB, jbs = 4 / NKB;
-    int np = 0;
-    for (int jb = jb0; jb < NJB; jb += jbs) ++np;
-    const int RL = a.Jv + a.K + (a.a2 ? a.K : 0);      // floats per staged row
+    const int RL = a.Jv + a.K + (HAS2 ? a.K : 0);      // floats per staged row
     const int RL4 = RL / 4;
     const unsigned inv = (unsigned)((0x100000000ULL + RL4 - 1) / RL4);
     const int nvec = WG_T * RL4;                        // 16-byte pieces per chunk
     const int npass = (nvec + 255) / 256;
 
-    f32x16 acc[MAXP];
-    float bsum[MAXP], sqa[MAXP], sqb = 0.f;
+    int joff[NP];
+    float jmask[NP];
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
+    for (int p = 0; p < NP; ++p) {
+        const int jb = jb0 + p * jbs;
+        const bool vb = jb < NJB;
+        const int j = 32 * (vb ? jb : jb0) + col;       // < Jv + 32 <= Jv + K: inside the staged row
+        joff[p] = j;
+        jmask[p] = (vb && j < a.Jv) ? 1.f : 0.f;
+    }
+    const int boff = a.Jv + 32 * kb + col;
+
+    f32x16 acc[NP];
+    float bsum[NP], sqa[NP], sqb = 0.f;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
         bsum[p] = 0.f; sqa[p] = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[p][q] = 0.f;
@@ -69,13 +81,30 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
             const int q = (int)(f - trow * RL4) * 4;
             long tokn = t0 + trow;
             if (tokn >= n1) tokn = n1 - 1;
-            const float* src;
-            if (q < a.Jv) src = a.dz + tokn * a.dz_ld + a.dz_c0 + q;
-            else if (q < a.Jv + a.K) src = a.a1 + tokn * a.a1_ld + a.a1_c0 + (q - a.Jv);
-            else src = a.a2 + tokn * a.a2_ld + a.a2_c0 + (q - a.Jv - a.K);
+            const float* s_dz = a.dz + tokn * a.dz_ld + a.dz_c0 + q;
+            const float* s_a1 = a.a1 + tokn * a.a1_ld + a.a1_c0 + (q - a.Jv);
+            const float* src = q < a.Jv ? s_dz : s_a1;
+            if (HAS2) {
+                const float* s_a2 = a.a2 + tokn * a.a2_ld + a.a2_c0 + (q - a.Jv - a.K);
+                src = q < a.Jv + a.K ? src : s_a2;
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dstbuf + (i * 256 + wv * 64) * 4),
                                              16, 0, 0);
+        }
+    };
+
+    constexpr int UG = 4;                // pixel pairs per operand group
+    constexpr int NG = WG_T / 2 / UG;
+    static_assert(NG % 2 == 0, "operand groups are consumed in pairs");
+    auto load_group = [&](const float* buf, int g, float (&bv)[UG], float (&av)[UG][NP]) {
+#pragma unroll
+        for (int i = 0; i < UG; ++i) {
+            const float* row = buf + (2 * (g * UG + i) + kk) * RL;
+            bv[i] = row[boff];
+            if (HAS2) bv[i] *= row[boff + a.K];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) av[i][p] = row[joff[p]];
         }
     };
 
@@ -85,32 +114,42 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
         if (c + 1 < nchunks) issue(c + 1);
         const float* buf = wlds + (c & 1) * (WG_T * RL);
         const long t0 = n0 + (long)c * WG_T;
-        const bool full = t0 + WG_T <= n1;
-#pragma unroll 4
-        for (int u = 0; u < WG_T / 2; ++u) {
-            const float* row = buf + (2 * u + kk) * RL;
-            float bv = row[a.Jv + 32 * kb + col];
-            if (a.a2) bv *= row[a.Jv + a.K + 32 * kb + col];
-            const bool ok = full || (t0 + 2 * u + kk < n1);
-            sqb += ok ? bv * bv : 0.f;
+        const int nvalid = (n1 - t0 < WG_T) ? (int)(n1 - t0) : WG_T;
+        float bvA[UG], avA[UG][NP], bvB[UG], avB[UG][NP];
+        auto consume = [&](int g, const float (&bv)[UG], const float (&av)[UG][NP]) {
 #pragma unroll
-            for (int p = 0; p < MAXP; ++p) {
-                if (p < np) {
-                    const int j = 32 * (jb0 + p * jbs) + col;
-                    float av = row[j];                   // j >= Jv reads the neighbouring columns: masked below
-                    av = (ok && j < a.Jv) ? av : 0.f;
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[p], 0, 0, 0);
-                    bsum[p] += av;
-                    sqa[p] += av * av;
+            for (int i = 0; i < UG; ++i) {
+                // rows past n1 were staged from pixel n1-1 (finite): zero them by multiplication
+                const float okf = (2 * (g * UG + i) + kk < nvalid) ? 1.f : 0.f;
+                const float b = bv[i];
+                sqb += okf * b * b;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const float v = av[i][p] * (jmask[p] * okf);
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, b, acc[p], 0, 0, 0);
+                    bsum[p] += v;
+                    sqa[p] += v * v;
                 }
             }
+        };
+        load_group(buf, 0, bvA, avA);
+#pragma unroll 1
+        for (int g = 0; g < NG; g += 2) {
+            load_group(buf, g + 1, bvB, avB);             // NG is even
+            __builtin_amdgcn_sched_barrier(0);
+            consume(g, bvA, avA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NG) load_group(buf, g + 2, bvA, avA);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(g + 1, bvB, avB);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     float* slab = a.slab + ((long)blockIdx.y * gridDim.x + blockIdx.x) * a.stride;
 #pragma unroll
-    for (int p = 0; p < MAXP; ++p) {
-        if (p < np) {
-            const int jb = jb0 + p * jbs;
+    for (int p = 0; p < NP; ++p) {
+        const int jb = jb0 + p * jbs;
+        if (jb < NJB) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int row = (q & 3) + 8 * (q >> 2) + 4 * kk;
@@ -241,20 +280,40 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const int b = (int)(tile / ((long)tiles_x * tiles_y));
         const int y0 = ty * 4, x0 = tx * 32;
+        // all 32 gradient values of this (row, channel) first: independent loads whose latency overlaps
+        // the halo staging (rows / columns outside the image are loaded from a clamped address and zeroed)
+        const int y = y0 + row;
+        const int yc = y < a.H ? y : a.H - 1;
+        const int xmax = (a.W - x0) < 32 ? (a.W - x0) : 32;
+        const float* dsp = a.ds + ((long)b * HW + (long)yc * a.W + x0) * a.ds_ld + a.ds_c0 + c;
+        float dv[32];
+#pragma unroll
+        for (int col = 0; col < 32; ++col) {
+            const int cc = col < xmax ? col : xmax - 1;
+            dv[col] = dsp[(long)cc * a.ds_ld];
+        }
         __syncthreads();
         ksr_stage_halo(halo, a.in, a.in_ld, a.in_c0, b, y0, x0, a.H, a.W, tid);
         __syncthreads();
-        const int y = y0 + row;
-        if (y < a.H) {
-            const int xmax = (a.W - x0) < 32 ? (a.W - x0) : 32;
-            for (int col = 0; col < xmax; ++col) {
-                const float d = a.ds[((long)b * HW + (long)y * a.W + x0 + col) * a.ds_ld + a.ds_c0 + c];
+        {
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
+            for (int col = 0; col < 32; ++col) {
+                dv[col] = (col < xmax && y < a.H) ? dv[col] : 0.f;
+                acc[9] += dv[col];
+            }
+            // sliding 3-wide window along the row: 34 LDS reads per tap row instead of 96
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx)
-                        acc[dy * 3 + dx] += d * halo[((row + dy) * HALO_W + (col + dx)) * HALO_LD + c];
-                acc[9] += d;
+            for (int dy = 0; dy < 3; ++dy) {
+                const float* hp = halo + (row + dy) * HALO_W * HALO_LD + c;
+                float h0 = hp[0], h1 = hp[HALO_LD];
+#pragma unroll
+                for (int col = 0; col < 32; ++col) {
+                    const float h2 = hp[(col + 2) * HALO_LD];
+                    acc[dy * 3 + 0] += dv[col] * h0;
+                    acc[dy * 3 + 1] += dv[col] * h1;
+                    acc[dy * 3 + 2] += dv[col] * h2;
+                    h0 = h1; h1 = h2;
+                }
             }
         }
     }
@@ -345,40 +404,49 @@ int launch_reduce(const float* slab, int G, int J, int K, long stride, float* ou
 }
 
 // Launches the accumulation kernel on a (g, nb) grid; a.stride and a.slab are set by the caller.
-int launch_wgrad_kernel(const WgArgs& a, int per_wave, int T, size_t lds_bytes, unsigned g, unsigned nb, hipStream_t stream) {
-    const bool small = per_wave <= 3;
-    const void* fn = T == 64 ? (small ? (const void*)wgrad_kernel<64, 3> : (const void*)wgrad_kernel<64, WG_MAXP>)
-                             : (small ? (const void*)wgrad_kernel<32, 3> : (const void*)wgrad_kernel<32, WG_MAXP>);
-    static bool attr_set[4] = {false, false, false, false};
-    const int fi = (T == 64 ? 0 : 2) + (small ? 0 : 1);
-    if (!attr_set[fi]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+template <int T, int NP, bool HAS2>
+int launch_wgrad_inst(const WgArgs& a, size_t lds_bytes, dim3 grid, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<T, NP, HAS2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { ksr_set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return KSR_ERR_HIP; }
-        attr_set[fi] = true;
+        attr_set = true;
     }
-    const dim3 grid(g, nb);
-    if (T == 64) {
-        if (small) hipLaunchKernelGGL((wgrad_kernel<64, 3>), grid, dim3(256), lds_bytes, stream, a);
-        else hipLaunchKernelGGL((wgrad_kernel<64, WG_MAXP>), grid, dim3(256), lds_bytes, stream, a);
-    } else {
-        if (small) hipLaunchKernelGGL((wgrad_kernel<32, 3>), grid, dim3(256), lds_bytes, stream, a);
-        else hipLaunchKernelGGL((wgrad_kernel<32, WG_MAXP>), grid, dim3(256), lds_bytes, stream, a);
-    }
+    hipLaunchKernelGGL((wgrad_kernel<T, NP, HAS2>), grid, dim3(256), lds_bytes, stream, a);
     KSR_LAUNCH_CHECK("wgrad");
     return KSR_OK;
 }
 
+int launch_wgrad_kernel(const WgArgs& a, int per_wave, int T, size_t lds_bytes, unsigned g, unsigned nb, hipStream_t stream) {
+    const dim3 grid(g, nb);
+    if (a.a2) {     // the one layer with a product operand (fn_2 of the gated blocks) has one block per wave
+        KSR_UNSUPPORTED(per_wave != 1, "wgrad: a2 is only supported for J = K = 64");
+        return T == 64 ? launch_wgrad_inst<64, 1, true>(a, lds_bytes, grid, stream)
+                       : launch_wgrad_inst<32, 1, true>(a, lds_bytes, grid, stream);
+    }
+#define KSR_WG_CASE(NP)                                                                             \
+    case NP: return T == 64 ? launch_wgrad_inst<64, (NP <= 3 ? NP : 1), false>(a, lds_bytes, grid, stream) \
+                            : launch_wgrad_inst<32, NP, false>(a, lds_bytes, grid, stream);
+    switch (per_wave) {     // wgrad_shape picks 64-pixel chunks only for per_wave <= 3
+        KSR_WG_CASE(1) KSR_WG_CASE(2) KSR_WG_CASE(3) KSR_WG_CASE(4) KSR_WG_CASE(5) KSR_WG_CASE(6)
+    }
+#undef KSR_WG_CASE
+    ksr_set_error("wgrad: %d row blocks per wave not supported", per_wave);
+    return KSR_ERR_UNSUPPORTED;
+}
+
 // Chunk length and LDS bytes for staged rows of RL floats: 64 pixels while two buffers stay within 64 KiB
-// (more bytes in flight per workgroup), else 32.
-void wgrad_shape(int RL, int* T, size_t* lds_bytes) {
-    *T = (2 * 64 * RL * (int)sizeof(float) <= 64 * 1024) ? 64 : 32;
+// (more bytes in flight per workgroup) and a wave owns at most 3 row blocks (register budget), else 32.
+void wgrad_shape(int RL, int per_wave, int* T, size_t* lds_bytes) {
+    *T = (2 * 64 * RL * (int)sizeof(float) <= 64 * 1024 && per_wave <= 3) ? 64 : 32;
     *lds_bytes = (size_t)2 * *T * RL * sizeof(float);
 }
 
 // Workgroups per batch entry of a batched Gram product (nb entries of `tokens` pixels, Jp = J rounded up to 32).
 long gram_grid(int Jp, int K, int nb, long tokens) {
     int T; size_t lds;
-    wgrad_shape(Jp + K, &T, &lds);
+    const int NKB = K / 32;
+    wgrad_shape(Jp + K, (Jp / 32 + (4 / NKB) - 1) / (4 / NKB), &T, &lds);
     long cap = WG_GRID / nb;
     if (lds > 40 * 1024) cap = (WG_GRID / 2) / nb;
     if (cap < 1) cap = 1;
@@ -404,7 +472,7 @@ extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const flo
                   "wgrad: leading dimensions and channel offsets must be multiples of 4");
     WgArgs a{dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, a2, a2_ld, a2_c0, slab, (long)N, J, 0, (long)J * K + J};
     int T; size_t lds_bytes;
-    wgrad_shape(J + K + (a2 ? K : 0), &T, &lds_bytes);
+    wgrad_shape(J + K + (a2 ? K : 0), per_wave, &T, &lds_bytes);
     KSR_UNSUPPORTED(lds_bytes > 160 * 1024, "wgrad: J=%d needs %zu bytes of LDS", J, lds_bytes);
     long g = (N + 4 * T - 1) / (4 * T);
     if (g > WG_GRID) g = WG_GRID;
@@ -443,7 +511,7 @@ extern "C" int ksr_gram_batched(const float* dz, int dz_ld, int dz_c0, int J, co
     const long stride = (long)Jp * K + 2 * Jp + K;
     WgArgs a{dz, dz_ld, dz_c0, Jp, a1, a1_ld, a1_c0, K, nullptr, 0, 0, slab, (long)tokens_per_entry, J, want_sq ? 1 : 0, stride};
     int T; size_t lds_bytes;
-    wgrad_shape(Jp + K, &T, &lds_bytes);        // sized for padded rows: the masked reads stay inside the buffer
+    wgrad_shape(Jp + K, per_wave, &T, &lds_bytes);        // sized for padded rows: the masked reads stay inside the buffer
     KSR_UNSUPPORTED(lds_bytes > 160 * 1024, "gram_batched: J=%d needs %zu bytes of LDS", J, lds_bytes);
     const long g = gram_grid(Jp, K, nb, (long)tokens_per_entry);
     if (int rc = launch_wgrad_kernel(a, per_wave, T, lds_bytes, (unsigned)g, (unsigned)nb, stream)) return rc;
@@ -465,13 +533,13 @@ extern "C" int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b,
     return launch_reduce(slab, (int)g, 2, 64, 128, out, out_row_stride, 1, nullptr, 0, 0, 0, stream);
 }
 
-// Depthwise 3x3 (64 channels) parameter gradients: dW [64][1][3][3], db [64]. slab: 256*640 floats.
+// Depthwise 3x3 (64 channels) parameter gradients: dW [64][1][3][3], db [64]. slab: 512*640 floats.
 extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0,
                                 float* slab, float* dW, float* db, int B, int H, int W, hipStream_t stream) {
     KSR_CHECK_ARG(in && ds && slab && dW && db && B > 0 && H > 0 && W > 0 && ds_ld >= 64, "dwconv_wgrad: bad argument");
     DwgArgs d{in, in_ld, in_c0, ds, ds_ld, ds_c0, slab, B, H, W};
     long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
-    const long g = ntiles < 256 ? ntiles : 256;
+    const long g = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)g), dim3(256), 0, stream, d);
     KSR_LAUNCH_CHECK("dwconv_wgrad");
     // slab rows: tap t (J = 9) x channel (K = 64) then the bias row handled as a 10th row via two calls

@@ -78,7 +78,7 @@ def _colreduce(ws: _Ws, a, a_ld, a_c0, b, b_scalar, N, out, out_c0=0):
 def _dwconv_wgrad(ws: _Ws, inp, in_ld, in_c0, ds, g: Geometry, name_w, name_b):
     dW = ws.grad(name_w, 64, 1, 3, 3)
     db = ws.grad(name_b, 64)
-    slab = ws.slab(256 * 640)
+    slab = ws.slab(512 * 640)
     check(lib().ksr_dwconv_wgrad(ptr(inp), c_int(in_ld), c_int(in_c0), ptr(ds), c_int(64), c_int(0), ptr(slab), ptr(dW), ptr(db),
                                  *_dims(g), stream()), "ksr_dwconv_wgrad")
     return dW, db

@@ -67,7 +67,7 @@ class _QkvFn(torch.autograd.Function):
         check(L.ksr_chan_dw_bwd(ptr(dqkv), ptr(dw_w), ptr(dpq), c_int(192), c_int(3), c_int(B), c_int(H), c_int(W),
                                 stream()), "ksr_chan_dw_bwd")
         g_dw_w, g_dw_b = _new(dev, 192, 9), _new(dev, 192)
-        slab = _new(dev, max(256 * 640, int(L.ksr_wgrad_slab_floats(c_int(192), c_int(64)))))
+        slab = _new(dev, max(512 * 640, int(L.ksr_wgrad_slab_floats(c_int(192), c_int(64)))))
         for gi in range(3):
             check(L.ksr_dwconv_wgrad(ptr(pq), c_int(192), c_int(64 * gi), ptr(dqkv), c_int(192), c_int(64 * gi), ptr(slab),
                                      ptr(g_dw_w[64 * gi:64 * gi + 64]), ptr(g_dw_b[64 * gi:64 * gi + 64]),
