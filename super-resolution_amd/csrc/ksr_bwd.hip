@@ -28,18 +28,21 @@ struct BwdArgs {
     int B, H, W;
 };
 
-template <int KIN, int BPRO>
+template <int PREC, int KIN, int BPRO>
 struct __attribute__((aligned(16))) BwdSmem {
-    float frag[2 * (KIN / 2) * 64];
+    float frag[2 * (KIN / 2) * 64 / (PREC == KSR_BF16 ? 2 : 1)];
     float dww[BPRO == BPRO_PLAIN ? 4 : 9 * 64];
     float p2w[64];
     float halo[BPRO == BPRO_PLAIN ? 4 : HALO_FLOATS];
+    // per-wave LDS transposers of the coalesced loads / stores (the stencil variants reuse the halo tile)
+    float xpose[BPRO == BPRO_PLAIN ? 4 * KSR_XPOSE_FLOATS : 4];
 };
+static_assert(4 * KSR_XPOSE_FLOATS <= HALO_FLOATS, "transposers must fit in the halo tile");
 
 template <int PREC, int KIN, int BPRO, int BEPI>
 __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     constexpr int KH = KIN / 2;
-    __shared__ BwdSmem<KIN, BPRO> sm;
+    __shared__ BwdSmem<PREC, KIN, BPRO> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
     ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.wt, 64, nullptr, MapHL{32}, MapHL{KH}, tid, 256);
@@ -55,7 +58,8 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         bool live;
-        long n;
+        long n, n0w;          // this lane's pixel; first pixel of the wave's 32-pixel run
+        int nvalid;           // real pixels of that run
         if (spatial) {
             const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
             const int b = (int)(tile / ((long)tiles_x * tiles_y));
@@ -63,6 +67,8 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             const int y = y0 + wv, x = x0 + tok;
             live = (y < a.H) && (x < a.W);
             n = live ? (long)b * HW + (long)y * a.W + x : 0;
+            n0w = (long)b * HW + (long)y * a.W + x0;
+            nvalid = (y < a.H) ? ((a.W - x0) < 32 ? a.W - x0 : 32) : 0;
             __syncthreads();
             ksr_stage_halo(sm.halo, a.halo_src, 64, 0, b, y0, x0, a.H, a.W, tid);
             __syncthreads();
@@ -70,25 +76,34 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             n = tile * 128 + wv * 32 + tok;
             live = n < N;
             if (!live) n = 0;
+            n0w = tile * 128 + wv * 32;
+            nvalid = (N - n0w) < 32 ? (int)(N - n0w > 0 ? N - n0w : 0) : 32;
         }
+        float* xb = (spatial ? sm.halo : sm.xpose) + wv * KSR_XPOSE_FLOATS;
 
         float dz[KH];
         if (BPRO == BPRO_PLAIN) {
 #pragma unroll
-            for (int grp = 0; grp < KIN / 64; ++grp) ksr_load32(a.dz + n * a.dz_ld + 64 * grp + 32 * h, dz + 32 * grp);
+            for (int grp = 0; grp < KIN / 64; ++grp) {
+                float t[32];
+                ksr_load32_co(xb, a.dz, n0w, nvalid, a.dz_ld, 64 * grp, lane, t);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) dz[32 * grp + i] = t[i];
+            }
         } else {
             float g[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = 0.f;
             ksr_dwconv_lane(sm.halo, sm.dww, wv, tok, h, g);
+            __syncthreads();       // every wave is done with the halo tile: it now serves as the transposers
             if (BPRO == BPRO_CONVT_G) {
-                float mk[32];
-                ksr_load32(a.mask_src + n * a.mask_ld + a.mask_c0 + 32 * h, mk);
+                float mk[32], t[32];
+                ksr_load32_co(xb, a.mask_src, n0w, nvalid, a.mask_ld, a.mask_c0, lane, mk);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) g[i] = mk[i] > 0.f ? g[i] : 0.f;
-                ksr_load32(a.dz + n * a.dz_ld + 32 * h, dz);
+                ksr_load32_co(xb, a.dz, n0w, nvalid, a.dz_ld, 0, lane, t);
 #pragma unroll
-                for (int i = 0; i < 32; ++i) dz[32 + i] = g[i];
+                for (int i = 0; i < 32; ++i) { dz[i] = t[i]; dz[32 + i] = g[i]; }
             } else {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) dz[i] = g[i];
@@ -101,9 +116,11 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         ksr_wave_gemm<PREC, KH, 2>(sm.frag, nullptr, dz, acc, lane);
         __builtin_amdgcn_sched_barrier(0);
         if (BPRO != BPRO_PLAIN) {
-            // the conv-transposed gradient is also an output (stored here, after the GEMM: a conditional
-            // store right behind the stencil makes the compiler duplicate it and spill)
-            if (live) ksr_store32(a.dz_store + n * a.dz_store_ld + a.dz_store_c0 + 32 * h, dz + (BPRO == BPRO_CONVT_G ? 32 : 0));
+            // the conv-transposed gradient is also an output
+            float t[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) t[i] = dz[(BPRO == BPRO_CONVT_G ? 32 : 0) + i];
+            ksr_store32_co(xb, a.dz_store, n0w, nvalid, a.dz_store_ld, a.dz_store_c0, lane, t);
             __builtin_amdgcn_sched_barrier(0);
         }
         float dA[32];
@@ -112,32 +129,32 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
 
         if (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD) {
             float r[32];
-            ksr_load32(a.resid + n * 64 + 32 * h, r);
+            ksr_load32_co(xb, a.resid, n0w, nvalid, 64, 0, lane, r);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] += r[i];
         }
         if (BEPI == BEPI_RELUMASK) {
             float e[32];
-            ksr_load32(a.e1 + n * a.e1_ld + a.e1_c0 + 32 * h, e);
+            ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] = e[i] > 0.f ? dA[i] : 0.f;
         }
         if (BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD) {
             float e[32];
-            ksr_load32(a.e1 + n * a.e1_ld + a.e1_c0 + 32 * h, e);
+            ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] = dA[i] * e[i] * (1.f - e[i]);
         }
         if (BEPI == BEPI_GATE) {
             float gte[32], val[32], o2[32];
-            ksr_load32(a.e1 + n * a.e1_ld + a.e1_c0 + 32 * h, gte);
-            ksr_load32(a.e2 + n * a.e2_ld + a.e2_c0 + 32 * h, val);
+            ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, gte);
+            ksr_load32_co(xb, a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, val);
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 o2[i] = dA[i] * val[i];
                 dA[i] = val[i] > 0.f ? dA[i] * gte[i] : 0.f;
             }
-            if (live) ksr_store32(a.out2 + n * 64 + 32 * h, o2);
+            ksr_store32_co(xb, a.out2, n0w, nvalid, 64, 0, lane, o2);
         }
         if (BEPI == BEPI_STEM) {
             float s = 0.f;
@@ -146,7 +163,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             s = ksr_pair_sum(s);
             if (live && h == 0) a.dpre[n] = a.v[n] > 0.f ? s : 0.f;
         }
-        if (live) ksr_store32(a.out1 + n * a.out1_ld + a.out1_c0 + 32 * h, dA);
+        ksr_store32_co(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
     }
 }
 

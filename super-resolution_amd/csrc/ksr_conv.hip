@@ -34,16 +34,20 @@ struct ConvArgs {
 };
 
 
-template <int PRO, int NB>
+template <int PREC, int PRO, int NB>
 struct __attribute__((aligned(16))) ConvSmem {
-    float frag[NB * 32 * 64];
+    float frag[NB * 32 * 64 / (PREC == KSR_BF16 ? 2 : 1)];
     float biasfrag[NB * 32];
     float dww[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? 9 * 64 : 16];
     float dwb[64];
     float p2w[64];
     float p2b[64];
     float halo[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? HALO_H * HALO_W * HALO_LD : 4];
+    // one LDS transposer per wave for the coalesced loads / stores; the stencil kernels reuse the halo tile
+    // for it once every wave has finished reading the tile
+    float xpose[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? 4 : 4 * KSR_XPOSE_FLOATS];
 };
+static_assert(4 * KSR_XPOSE_FLOATS <= HALO_H * HALO_W * HALO_LD, "transposers must fit in the halo tile");
 
 template <int ACT>
 __device__ __forceinline__ float apply_act(float v) {
@@ -55,7 +59,7 @@ __device__ __forceinline__ float apply_act(float v) {
 template <int PREC, int PRO, int NOUT, int ACT>
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
     constexpr int NB = NOUT / 32;   // 16-register blocks per lane half (NOUT/2 outputs per half)
-    __shared__ ConvSmem<PRO, NB> sm;
+    __shared__ ConvSmem<PREC, PRO, NB> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
 
@@ -101,13 +105,15 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             y = hw / a.W; x = hw % a.W;
         }
 
+        float* xb = (spatial ? sm.halo : sm.xpose) + wv * KSR_XPOSE_FLOATS;
+        // first row and number of real rows of this wave's 32-pixel run (consecutive pixel indices)
+        const long n0w = spatial ? (long)b * HW + (long)y * a.W + (x - tok) : tile * 128 + wv * 32;
+        int nvalid;
+        if (spatial) nvalid = (y < a.H) ? (a.W - (x - tok) < 32 ? a.W - (x - tok) : 32) : 0;
+        else nvalid = (N - n0w) < 32 ? (int)(N - n0w > 0 ? N - n0w : 0) : 32;
         float op[32];
         if (PRO == PRO_PLAIN) {
-            if (live) ksr_load32(a.in + n * a.in_ld + 32 * h, op);
-            else {
-#pragma unroll
-                for (int i = 0; i < 32; ++i) op[i] = 0.f;
-            }
+            ksr_load32_co(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, op);
         } else if (PRO == PRO_STEM) {
             const float w1 = a.p1[0], b1 = a.p1b[0];
             const float* Y = a.in + (long)b * a.img_bstride;
@@ -131,18 +137,15 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = sm.dwb[32 * h + i];
             ksr_dwconv_lane(sm.halo, sm.dww, wv, tok, h, g);
+            __syncthreads();       // every wave is done with the halo tile: it now serves as the transposers
             if (PRO == PRO_DWRELU) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) op[i] = g[i] > 0.f ? g[i] : 0.f;
-                if (a.save && live) ksr_store32(a.save + n * 64 + 32 * h, op);
+                if (a.save) ksr_store32_co(xb, a.save, n0w, nvalid, 64, 0, lane, op);
             } else {
-                if (a.save && live) ksr_store32(a.save + n * 64 + 32 * h, g);
+                if (a.save) ksr_store32_co(xb, a.save, n0w, nvalid, 64, 0, lane, g);
                 float val[32];
-                if (live) ksr_load32(a.in + n * a.in_ld + 32 * h, val);
-                else {
-#pragma unroll
-                    for (int i = 0; i < 32; ++i) val[i] = 0.f;
-                }
+                ksr_load32_co(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, val);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) op[i] = val[i] * g[i];
             }
@@ -151,17 +154,15 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
         f32x16 acc[NB];
         ksr_wave_gemm<PREC, 32, NB>(sm.frag, sm.biasfrag, op, acc, lane);
 
-        if (live) {
 #pragma unroll
-            for (int grp = 0; grp < NB / 2; ++grp) {
-                float o[32];
+        for (int grp = 0; grp < NB / 2; ++grp) {
+            float o[32];
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    o[q] = apply_act<ACT>(acc[2 * grp][q]);
-                    o[16 + q] = apply_act<ACT>(acc[2 * grp + 1][q]);
-                }
-                ksr_store32(a.out + n * NOUT + 64 * grp + 32 * h, o);
+            for (int q = 0; q < 16; ++q) {
+                o[q] = apply_act<ACT>(acc[2 * grp][q]);
+                o[16 + q] = apply_act<ACT>(acc[2 * grp + 1][q]);
             }
+            ksr_store32_co(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
         }
     }
 }

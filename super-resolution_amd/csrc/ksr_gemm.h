@@ -190,6 +190,64 @@ __device__ __forceinline__ void ksr_store16(float* __restrict__ p, const float* 
     for (int q = 0; q < 4; ++q) p4[q] = make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
 }
 
+// ---- coalesced HL loads / stores through a wave-private LDS transposer --------------------------
+// A lane moving its own 128 contiguous bytes with eight 16-byte accesses makes every access of the wave
+// touch 64 different cache lines; such streams top out near 3.5 TB/s on MI355X where lane-linear 16-byte
+// accesses reach 5+ TB/s.  These helpers move a wave's tile (32 consecutive rows x 64 channels) with
+// lane-linear accesses (16 lanes cover one row's 256 bytes) and transpose to / from the half layout in a
+// wave-private LDS buffer of KSR_XPOSE_FLOATS floats (rows padded to 68 floats: conflict-free both ways).
+// Only the owning wave touches its buffer and LDS operations of one wave complete in order, so no
+// workgroup barrier is needed; the compiler barriers keep the phases in program order.
+constexpr int KSR_XPOSE_LD = 68;
+constexpr int KSR_XPOSE_FLOATS = 32 * KSR_XPOSE_LD;
+
+__device__ __forceinline__ void ksr_wave_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// x <- rows [n0, n0+32) (nvalid real rows, the rest read as 0), channels [c0, c0+64) of a tensor with ld floats
+// per row, in half layout (this lane: row n0 + (lane&31), channels 32*(lane>>5) ..+31).
+__device__ __forceinline__ void ksr_load32_co(float* __restrict__ xb, const float* __restrict__ base, long n0,
+                                              int nvalid, int ld, int c0, int lane, float (&x)[32]) {
+    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + r4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nvalid) v[i] = *reinterpret_cast<const float4*>(base + (n0 + row) * ld + c0 + c4);
+    }
+    ksr_wave_fence();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(xb + (4 * i + r4) * KSR_XPOSE_LD + c4) = v[i];
+    ksr_wave_fence();
+    const float* rp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
+        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+    }
+}
+
+// The reverse: x (half layout) -> rows [n0, n0 + nvalid).
+__device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, float* __restrict__ base, long n0, int nvalid,
+                                               int ld, int c0, int lane, const float (&x)[32]) {
+    float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
+    ksr_wave_fence();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    ksr_wave_fence();
+    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + r4;
+        const float4 t = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE_LD + c4);
+        if (row < nvalid) *reinterpret_cast<float4*>(base + (n0 + row) * ld + c0 + c4) = t;
+    }
+}
+
 // Sum of v over the two lanes that share a token (lanes l and l^32).
 __device__ __forceinline__ float ksr_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 

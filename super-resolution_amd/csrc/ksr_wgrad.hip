@@ -31,7 +31,9 @@ struct WgArgs {
 // conflict-free ds_read_b32 (lane = column), four pixel pairs ahead of the MFMAs that consume them.
 // Wave w owns column block kb = w % (K/32) of A and the dz blocks jb = w / (K/32) + p * (4 / (K/32)),
 // p < NP; blocks past the end (and channels >= Jv of a partial block) are multiplied by 0.
-template <int WG_T, int NP, bool HAS2>   // pixels per staged chunk; dz blocks per wave; a2 present
+// PREC = KSR_BF16: the products run on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16 after the fp32
+// LDS read, fp32 accumulation; 16 pixels per instruction); the bias / square sums stay exact fp32.
+template <int PREC, int WG_T, int NP, bool HAS2>   // pixels per staged chunk; dz blocks per wave; a2 present
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     extern __shared__ __attribute__((aligned(16))) float wlds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -94,13 +96,16 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
         }
     };
 
-    constexpr int UG = 4;                // pixel pairs per operand group
+    constexpr bool BF = PREC == KSR_BF16;
+    constexpr int UG = BF ? 8 : 4;       // operand registers per group: fp32 4 pixel pairs, bf16 one 16-pixel step
     constexpr int NG = WG_T / 2 / UG;
     static_assert(NG % 2 == 0, "operand groups are consumed in pairs");
     auto load_group = [&](const float* buf, int g, float (&bv)[UG], float (&av)[UG][NP]) {
 #pragma unroll
         for (int i = 0; i < UG; ++i) {
-            const float* row = buf + (2 * (g * UG + i) + kk) * RL;
+            // pixel of register i: fp32 MFMA k = 2*pair + kk; bf16 MFMA k = 8*kk + i within the 16-pixel step
+            const int px = BF ? 16 * g + 8 * kk + i : 2 * (g * UG + i) + kk;
+            const float* row = buf + px * RL;
             bv[i] = row[boff];
             if (HAS2) bv[i] *= row[boff + a.K];
 #pragma unroll
@@ -117,19 +122,27 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
         const int nvalid = (n1 - t0 < WG_T) ? (int)(n1 - t0) : WG_T;
         float bvA[UG], avA[UG][NP], bvB[UG], avB[UG][NP];
         auto consume = [&](int g, const float (&bv)[UG], const float (&av)[UG][NP]) {
+            bf16x8 bpk, apk[NP];
 #pragma unroll
             for (int i = 0; i < UG; ++i) {
                 // rows past n1 were staged from pixel n1-1 (finite): zero them by multiplication
-                const float okf = (2 * (g * UG + i) + kk < nvalid) ? 1.f : 0.f;
+                const int px = BF ? 16 * g + 8 * kk + i : 2 * (g * UG + i) + kk;
+                const float okf = (px < nvalid) ? 1.f : 0.f;
                 const float b = bv[i];
                 sqb += okf * b * b;
+                if (BF) bpk[i] = (__bf16)b;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
                     const float v = av[i][p] * (jmask[p] * okf);
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, b, acc[p], 0, 0, 0);
+                    if (BF) apk[p][i] = (__bf16)v;
+                    else acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, b, acc[p], 0, 0, 0);
                     bsum[p] += v;
                     sqa[p] += v * v;
                 }
+            }
+            if (BF) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apk[p], bpk, acc[p], 0, 0, 0);
             }
         };
         load_group(buf, 0, bvA, avA);
@@ -404,17 +417,23 @@ int launch_reduce(const float* slab, int G, int J, int K, long stride, float* ou
 }
 
 // Launches the accumulation kernel on a (g, nb) grid; a.stride and a.slab are set by the caller.
-template <int T, int NP, bool HAS2>
-int launch_wgrad_inst(const WgArgs& a, size_t lds_bytes, dim3 grid, hipStream_t stream) {
+template <int PREC, int T, int NP, bool HAS2>
+int launch_wgrad_inst_p(const WgArgs& a, size_t lds_bytes, dim3 grid, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<T, NP, HAS2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)wgrad_kernel<PREC, T, NP, HAS2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) { ksr_set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return KSR_ERR_HIP; }
         attr_set = true;
     }
-    hipLaunchKernelGGL((wgrad_kernel<T, NP, HAS2>), grid, dim3(256), lds_bytes, stream, a);
+    hipLaunchKernelGGL((wgrad_kernel<PREC, T, NP, HAS2>), grid, dim3(256), lds_bytes, stream, a);
     KSR_LAUNCH_CHECK("wgrad");
     return KSR_OK;
+}
+
+template <int T, int NP, bool HAS2>
+int launch_wgrad_inst(const WgArgs& a, size_t lds_bytes, dim3 grid, hipStream_t stream) {
+    return ksr_prec() == KSR_BF16 ? launch_wgrad_inst_p<KSR_BF16, T, NP, HAS2>(a, lds_bytes, grid, stream)
+                                  : launch_wgrad_inst_p<KSR_F32, T, NP, HAS2>(a, lds_bytes, grid, stream);
 }
 
 int launch_wgrad_kernel(const WgArgs& a, int per_wave, int T, size_t lds_bytes, unsigned g, unsigned nb, hipStream_t stream) {

@@ -80,6 +80,29 @@ def bench_wgrad():
                mfma_tflops=round(2 * J * K * N / ms / 1e9, 2))
 
 
+def bench_pointwise():
+    L = lib()
+    B, H, W = 64, 128, 128
+    N = B * H * W
+    x = torch.randn(N, 64, device="cuda")
+    for n_out, act in [(64, 0), (128, 1), (192, 0)]:
+        w, b = torch.randn(n_out, 64, device="cuda") * 0.1, torch.randn(n_out, device="cuda")
+        out = torch.empty(N, n_out, device="cuda")
+
+        def run():
+            check(L.ksr_pointwise_fwd(ptr(x), ptr(w), ptr(b), ptr(out), c_int(n_out), c_int(act), c_int(B), c_int(H), c_int(W),
+                                      stream()), "pw")
+        report(f"pointwise_fwd[64->{n_out}]", timeit(run), N * 4 * (64 + n_out))
+    dz = torch.randn(N, 192, device="cuda")
+    dx = torch.empty(N, 64, device="cuda")
+    for n_out in (64, 192):
+        w = torch.randn(n_out, 64, device="cuda") * 0.1
+
+        def run():
+            check(L.ksr_pointwise_bwd(ptr(dz), c_int(n_out), ptr(w), ptr(dx), c_int(B), c_int(H), c_int(W), stream()), "pwb")
+        report(f"pointwise_bwd[{n_out}->64]", timeit(run), N * 4 * (64 + n_out))
+
+
 def bench_gram():
     L = lib()
     B, HW = 64, 128 * 128
@@ -97,6 +120,8 @@ def bench_gram():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["kan_cell", "wgrad", "gram"]
+    from kan_sr import engine
+    engine.set_precision(os.environ.get("KSR_PRECISION", "fp32"))
+    which = sys.argv[1:] or ["kan_cell", "wgrad", "gram", "pointwise"]
     for w in which:
         globals()["bench_" + w]()
