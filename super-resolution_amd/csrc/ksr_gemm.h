@@ -248,6 +248,46 @@ __device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, float* __
     }
 }
 
+// 32-channel rows (lane half h holds channels 16h .. 16h+15): same scheme with rows padded to 36 floats.
+constexpr int KSR_XPOSE16_LD = 36;
+__device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const float* __restrict__ base, long n0,
+                                              int nvalid, int lane, float (&x)[16]) {
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nvalid) v[i] = *reinterpret_cast<const float4*>(base + (n0 + row) * 32 + c4);
+    }
+    ksr_wave_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+        *reinterpret_cast<float4*>(xb + row * KSR_XPOSE16_LD + c4) = v[i];
+    }
+    ksr_wave_fence();
+    const float* rp = xb + (lane & 31) * KSR_XPOSE16_LD + 16 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
+        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+    }
+}
+__device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, float* __restrict__ base, long n0, int nvalid,
+                                               int lane, const float (&x)[16]) {
+    float* wp = xb + (lane & 31) * KSR_XPOSE16_LD + 16 * (lane >> 5);
+    ksr_wave_fence();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    ksr_wave_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+        const float4 t = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE16_LD + c4);
+        if (row < nvalid) *reinterpret_cast<float4*>(base + (n0 + row) * 32 + c4) = t;
+    }
+}
+
 // Sum of v over the two lanes that share a token (lanes l and l^32).
 __device__ __forceinline__ float ksr_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 

@@ -44,6 +44,7 @@ struct __attribute__((aligned(16))) TxSmem {
     float b_in[6 * 32], b_out[2 * 32], b_l1[32], b_l2[2 * 32];
     float ln[6][64];              // n1_w, n1_b, n2_w, n2_b, nf_w, nf_b
     float kv[POST ? 4 : 128 * KV_LD];
+    float xpose[POST ? 4 * KSR_XPOSE_FLOATS : 4];   // POST: per-wave transposers of the coalesced loads / stores
 };
 
 __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* __restrict__ g,
@@ -92,8 +93,18 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
         const bool live = POST ? (nrow < (long)S * HW) : ((b < S) && (p < HW));
         const long n = live ? (POST ? nrow : ((long)b * HW + p)) : 0;
 
+        // POST: a wave's 32 rows are consecutive, loads and stores go through the LDS transposer (coalesced)
+        const long n0w = (long)tile * 128 + wv * 32;
+        const int nvalid = POST ? (((long)S * HW - n0w) < 32 ? (int)((long)S * HW - n0w > 0 ? (long)S * HW - n0w : 0) : 32) : 0;
+        float* xb = sm.xpose + (POST ? wv * KSR_XPOSE_FLOATS : 0);
+        auto st32 = [&](float* base, const float (&v)[32]) {
+            if (POST) ksr_store32_co(xb, base, n0w, nvalid, 64, 0, lane, v);
+            else if (live) ksr_store32(base + n * 64 + 32 * h, v);
+        };
+
         float s0[32];
-        if (live) ksr_load32(a.in + n * 64 + 32 * h, s0);
+        if (POST) ksr_load32_co(xb, a.in, n0w, nvalid, 64, 0, lane, s0);
+        else if (live) ksr_load32(a.in + n * 64 + 32 * h, s0);
         else {
 #pragma unroll
             for (int i = 0; i < 32; ++i) s0[i] = 0.f;
@@ -101,7 +112,7 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
 
         float ctx[32];
         if (POST) {
-            ksr_load32(a.ctx_in + n * 64 + 32 * h, ctx);
+            ksr_load32_co(xb, a.ctx_in, n0w, nvalid, 64, 0, lane, ctx);
         } else {
         // ---- QKV projection -------------------------------------------------------------
         float q[32];
@@ -186,10 +197,10 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
             for (int i = 0; i < 32; ++i) u[i] += s0[i];
             const float rstd = ksr_layernorm64(u, xhat, a.eps);
             ln_affine(xhat, sm.ln[0], sm.ln[1], h, s1);
-            if (TRAIN && live) {
-                if (a.sv_xhat1) ksr_store32(a.sv_xhat1 + n * 64 + 32 * h, xhat);
-                if (a.sv_s1) ksr_store32(a.sv_s1 + n * 64 + 32 * h, s1);
-                if (a.sv_rstd1 && h == 0) a.sv_rstd1[n] = rstd;
+            if (TRAIN) {
+                if (a.sv_xhat1) st32(a.sv_xhat1, xhat);
+                if (a.sv_s1) st32(a.sv_s1, s1);
+                if (live && a.sv_rstd1 && h == 0) a.sv_rstd1[n] = rstd;
             }
         }
 
@@ -206,7 +217,10 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
                 for (int i = 0; i < 16; ++i)
                     hm[i] = ksr_uniform(a.seed, 2u, (unsigned long long)n * 32 + 16 * h + i) < keep ? hm[i] * inv_keep : 0.f;
             }
-            if (TRAIN && a.sv_hmid && live) ksr_store16(a.sv_hmid + n * 32 + 16 * h, hm);
+            if (TRAIN && a.sv_hmid) {
+                if (POST) ksr_store16_co(xb, a.sv_hmid, n0w, nvalid, lane, hm);
+                else if (live) ksr_store16(a.sv_hmid + n * 32 + 16 * h, hm);
+            }
             f32x16 acc2[2];
             ksr_wave_gemm<PREC, 16, 2>(sm.f_l2, sm.b_l2, hm, acc2, lane);
             float u[32], xhat[32];
@@ -221,9 +235,9 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
             for (int i = 0; i < 32; ++i) u[i] += s1[i];
             const float rstd = ksr_layernorm64(u, xhat, a.eps);
             ln_affine(xhat, sm.ln[2], sm.ln[3], h, s2);
-            if (TRAIN && live) {
-                if (a.sv_xhat2) ksr_store32(a.sv_xhat2 + n * 64 + 32 * h, xhat);
-                if (a.sv_rstd2 && h == 0) a.sv_rstd2[n] = rstd;
+            if (TRAIN) {
+                if (a.sv_xhat2) st32(a.sv_xhat2, xhat);
+                if (live && a.sv_rstd2 && h == 0) a.sv_rstd2[n] = rstd;
             }
         }
 
@@ -232,13 +246,13 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
             float xhat[32], y[32];
             const float rstd = ksr_layernorm64(s2, xhat, a.eps);
             ln_affine(xhat, sm.ln[4], sm.ln[5], h, y);
-            if (TRAIN && live) {
-                if (a.sv_xhatf) ksr_store32(a.sv_xhatf + n * 64 + 32 * h, xhat);
-                if (a.sv_rstdf && h == 0) a.sv_rstdf[n] = rstd;
+            if (TRAIN) {
+                if (a.sv_xhatf) st32(a.sv_xhatf, xhat);
+                if (live && a.sv_rstdf && h == 0) a.sv_rstdf[n] = rstd;
             }
-            if (live) ksr_store32(a.out + n * 64 + 32 * h, y);
+            st32(a.out, y);
         } else {
-            if (live) ksr_store32(a.out + n * 64 + 32 * h, s2);
+            st32(a.out, s2);
         }
     }
 }

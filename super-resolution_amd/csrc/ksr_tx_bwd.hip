@@ -27,6 +27,7 @@ struct __attribute__((aligned(16))) TxBwdTokSmem {
     float f_l1t[2 * 16 * 64];      // 32 -> 64
     float f_outt[2 * 32 * 64];     // 64 -> 64
     float ln[3][64];
+    float xpose[4 * KSR_XPOSE_FLOATS];   // per-wave transposers of the coalesced loads / stores
 };
 
 __device__ __forceinline__ void ln_bwd(const float (&dy)[32], const float* __restrict__ gain, int h,
@@ -64,20 +65,23 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         const long n0 = tile * 128 + wv * 32 + tok;
         const bool live = n0 < a.N;
         const long n = live ? n0 : 0;
+        const long n0w = tile * 128 + wv * 32;             // the wave's 32 consecutive rows
+        const int nvalid = (a.N - n0w) < 32 ? (int)(a.N - n0w > 0 ? a.N - n0w : 0) : 32;
+        float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
 
         float g[32], xh[32];
-        ksr_load32(a.dy + n * 64 + 32 * h, g);
+        ksr_load32_co(xb, a.dy, n0w, nvalid, 64, 0, lane, g);
         if (a.nf_w) {
             float t[32];
-            ksr_load32(a.xhatf + n * 64 + 32 * h, xh);
+            ksr_load32_co(xb, a.xhatf, n0w, nvalid, 64, 0, lane, xh);
             ln_bwd(g, sm.ln[0], h, xh, a.rstdf[n], t);
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = t[i];
-            if (live) ksr_store32(a.ds2 + n * 64 + 32 * h, g);
+            ksr_store32_co(xb, a.ds2, n0w, nvalid, 64, 0, lane, g);
         }
         // LayerNorm 2
         float du2[32];
-        ksr_load32(a.xhat2 + n * 64 + 32 * h, xh);
+        ksr_load32_co(xb, a.xhat2, n0w, nvalid, 64, 0, lane, xh);
         ln_bwd(g, sm.ln[1], h, xh, a.rstd2[n], du2);
         // MLP
         float dm[32];
@@ -85,16 +89,16 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         for (int i = 0; i < 32; ++i)
             dm[i] = drop ? (ksr_uniform(a.seed, 3u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du2[i] * inv_keep : 0.f)
                          : du2[i];
-        if (live) ksr_store32(a.dm + n * 64 + 32 * h, dm);
+        ksr_store32_co(xb, a.dm, n0w, nvalid, 64, 0, lane, dm);
         float dpre[16];
         {
             f32x16 acc[1];
             ksr_wave_gemm<PREC, 32, 1>(sm.f_l2t, nullptr, dm, acc, lane);
             float hm[16];
-            ksr_load16(a.hmid + n * 32 + 16 * h, hm);
+            ksr_load16_co(xb, a.hmid, n0w, nvalid, lane, hm);
 #pragma unroll
             for (int i = 0; i < 16; ++i) dpre[i] = hm[i] > 0.f ? (drop ? acc[0][i] * inv_keep : acc[0][i]) : 0.f;
-            if (live) ksr_store16(a.dpre + n * 32 + 16 * h, dpre);
+            ksr_store16_co(xb, a.dpre, n0w, nvalid, lane, dpre);
         }
         float ds1[32];
         {
@@ -102,26 +106,26 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
             ksr_wave_gemm<PREC, 16, 2>(sm.f_l1t, nullptr, dpre, acc, lane);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ds1[i] = du2[i] + acc[0][i]; ds1[16 + i] = du2[16 + i] + acc[1][i]; }
-            if (live) ksr_store32(a.ds1 + n * 64 + 32 * h, ds1);
+            ksr_store32_co(xb, a.ds1, n0w, nvalid, 64, 0, lane, ds1);
         }
         // LayerNorm 1
         float du1[32];
-        ksr_load32(a.xhat1 + n * 64 + 32 * h, xh);
+        ksr_load32_co(xb, a.xhat1, n0w, nvalid, 64, 0, lane, xh);
         ln_bwd(ds1, sm.ln[2], h, xh, a.rstd1[n], du1);
-        if (live) ksr_store32(a.du1 + n * 64 + 32 * h, du1);
+        ksr_store32_co(xb, a.du1, n0w, nvalid, 64, 0, lane, du1);
         float da[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i)
             da[i] = drop ? (ksr_uniform(a.seed, 1u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du1[i] * inv_keep : 0.f)
                          : du1[i];
-        if (live && drop) ksr_store32(a.da + n * 64 + 32 * h, da);
+        if (drop) ksr_store32_co(xb, a.da, n0w, nvalid, 64, 0, lane, da);
         {
             f32x16 acc[2];
             ksr_wave_gemm<PREC, 32, 2>(sm.f_outt, nullptr, da, acc, lane);
             float dc[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dc[i] = acc[0][i]; dc[16 + i] = acc[1][i]; }
-            if (live) ksr_store32(a.dctx + n * 64 + 32 * h, dc);
+            ksr_store32_co(xb, a.dctx, n0w, nvalid, 64, 0, lane, dc);
         }
     }
 }
