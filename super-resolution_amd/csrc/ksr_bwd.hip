@@ -82,11 +82,22 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         float* xb = (spatial ? sm.halo : sm.xpose) + wv * KSR_XPOSE_FLOATS;
 
         float dz[KH];
+        // PLAIN: the epilogue operands are fetched together with dz (one memory latency for the whole tile)
+        constexpr bool PRE_R = BPRO == BPRO_PLAIN && (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD);
+        constexpr bool PRE_E1 = BPRO == BPRO_PLAIN && (BEPI == BEPI_RELUMASK || BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD || BEPI == BEPI_GATE);
+        constexpr bool PRE_E2 = BPRO == BPRO_PLAIN && BEPI == BEPI_GATE;
+        float4 pf_r[PRE_R ? 8 : 1], pf_e1[PRE_E1 ? 8 : 1], pf_e2[PRE_E2 ? 8 : 1];
         if (BPRO == BPRO_PLAIN) {
+            float4 f[KIN / 64][8];
+#pragma unroll
+            for (int grp = 0; grp < KIN / 64; ++grp) ksr_co_fetch(a.dz, n0w, nvalid, a.dz_ld, 64 * grp, lane, f[grp]);
+            if constexpr (PRE_R) ksr_co_fetch(a.resid, n0w, nvalid, 64, 0, lane, pf_r);
+            if constexpr (PRE_E1) ksr_co_fetch(a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, pf_e1);
+            if constexpr (PRE_E2) ksr_co_fetch(a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, pf_e2);
 #pragma unroll
             for (int grp = 0; grp < KIN / 64; ++grp) {
                 float t[32];
-                ksr_load32_co(xb, a.dz, n0w, nvalid, a.dz_ld, 64 * grp, lane, t);
+                ksr_co_finish(xb, lane, f[grp], t);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) dz[32 * grp + i] = t[i];
             }
@@ -129,26 +140,31 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
 
         if (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD) {
             float r[32];
-            ksr_load32_co(xb, a.resid, n0w, nvalid, 64, 0, lane, r);
+            if constexpr (PRE_R) ksr_co_finish(xb, lane, pf_r, r);
+            else ksr_load32_co(xb, a.resid, n0w, nvalid, 64, 0, lane, r);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] += r[i];
         }
         if (BEPI == BEPI_RELUMASK) {
             float e[32];
-            ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
+            if constexpr (PRE_E1) ksr_co_finish(xb, lane, pf_e1, e);
+            else ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] = e[i] > 0.f ? dA[i] : 0.f;
         }
         if (BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD) {
             float e[32];
-            ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
+            if constexpr (PRE_E1) ksr_co_finish(xb, lane, pf_e1, e);
+            else ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] = dA[i] * e[i] * (1.f - e[i]);
         }
         if (BEPI == BEPI_GATE) {
             float gte[32], val[32], o2[32];
-            ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, gte);
-            ksr_load32_co(xb, a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, val);
+            if constexpr (PRE_E1) ksr_co_finish(xb, lane, pf_e1, gte);
+            else ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, gte);
+            if constexpr (PRE_E2) ksr_co_finish(xb, lane, pf_e2, val);
+            else ksr_load32_co(xb, a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, val);
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 o2[i] = dA[i] * val[i];

@@ -207,6 +207,32 @@ __device__ __forceinline__ void ksr_wave_fence() {
     asm volatile("" ::: "memory");
 }
 
+// Two-phase form of ksr_load32_co: ksr_co_fetch only issues the global loads (several tiles can be in
+// flight), ksr_co_finish transposes one fetched tile into the half layout.
+__device__ __forceinline__ void ksr_co_fetch(const float* __restrict__ base, long n0, int nvalid, int ld, int c0,
+                                             int lane, float4 (&v)[8]) {
+    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 4 * i + r4;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nvalid) v[i] = *reinterpret_cast<const float4*>(base + (n0 + row) * ld + c0 + c4);
+    }
+}
+__device__ __forceinline__ void ksr_co_finish(float* __restrict__ xb, int lane, const float4 (&v)[8], float (&x)[32]) {
+    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+    ksr_wave_fence();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(xb + (4 * i + r4) * KSR_XPOSE_LD + c4) = v[i];
+    ksr_wave_fence();
+    const float* rp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
+        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+    }
+}
+
 // x <- rows [n0, n0+32) (nvalid real rows, the rest read as 0), channels [c0, c0+64) of a tensor with ld floats
 // per row, in half layout (this lane: row n0 + (lane&31), channels 32*(lane>>5) ..+31).
 __device__ __forceinline__ void ksr_load32_co(float* __restrict__ xb, const float* __restrict__ base, long n0,
