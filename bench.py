@@ -25,30 +25,67 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X dense fp32 matrix peak (spec)
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
-def kernel_models(S: int, P: int):
+def kernel_models(S: int, P: int, bf16: bool):
     """Per entry point: (bound, algorithmic flops per LR pixel per step, algorithmic HBM bytes per LR pixel per
-    step) summed over that entry point's launches in one step.  Flops: 2*Cin*Cout per 1x1 conv / linear,
-    2*9 per depthwise output, 256*S per token for the two attention products (x2.5 in the backward, which
-    recomputes the scores).  Bytes: tensors each launch must read + write once, fp32."""
-    lin = 2 * (64 * 192 + 64 * 64 + 64 * 32 + 32 * 64)
+    step, MFMA peak in TFLOP/s) summed over that entry point's launches in one training step.
+    Flops: 2*Cin*Cout per 1x1 conv / linear, 2*9 per depthwise output; attention: 2 products of 64 flops per
+    (query, key, head) forward, 5 in the backward (recomputed scores not counted).  Bytes: the tensors each launch
+    must read + write once (fp32 storage).  The GEMM kernels are priced against the MFMA peak of their operand
+    type (bf16 mode: dense bf16 peak); the attention products and, in fp32 mode, everything else run on fp32 MFMA."""
+    pk = PEAK_MFMA_BF16_TFLOPS if bf16 else PEAK_MFMA_F32_TFLOPS
+    f32 = PEAK_MFMA_F32_TFLOPS
     wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64 + 64 * 64 + 192 * 64) + (64 * 64 + 128 * 64) + 2 * 64 * 64 + 64 * 64
     wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64) + (64 + 64) + (192 + 64)) + (64 * 3 + 128 + 64)
                     + 2 * (64 + 64) + 64 * 3)
+    lin_post = 2 * (64 * 64 + 64 * 32 + 32 * 64)
     return {
-        "ksr_stem_fwd": ("mfma", 2 * 64 * 128 + 150, 4 + 512),
-        "ksr_gate_pw_fwd": ("mfma", 2 * (2 * 64 * 64 + 2 * 9 * 64 + 64), 2 * (512 + 256)),
-        "ksr_pointwise_fwd": ("mfma", 2 * 64 * 64 + 2 * 64 * 128, (256 + 256) + (256 + 512)),
-        "ksr_dwrelu_pw_fwd": ("mfma", 2 * 64 * 64 + 2 * 9 * 64, 512),
-        "ksr_batch_tx_layer_fwd": ("mfma", 2 * (lin + 256 * S), 2 * 512),
-        "ksr_feed_kan_fwd": ("mfma", 2 * 64 * P + 400, 256 + 4 + 4 * 16),
-        "ksr_batch_tx_layer_bwd_attn": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192)),
-        "ksr_batch_tx_layer_bwd_token": ("mfma", 2 * 2 * (64 * 32 + 32 * 64 + 64 * 64), 2 * 4 * (64 * 4 + 32 + 64 * 5 + 32)),
-        "ksr_wgrad": ("hbm", 2 * wg_jk, wg_bytes),
-        "ksr_bilinear_up": ("hbm", 0, 8 + 8 * 16),
+        # forward
+        "ksr_stem_fwd": ("hbm", 2 * 64 * 128 + 150, 4 + 512 + 4, pk),
+        "ksr_gate_pw_fwd": ("hbm", 2 * (2 * 64 * 64 + 2 * 9 * 64 + 64), 2 * (512 + 256 + 256), pk),
+        "ksr_pointwise_fwd": ("hbm", 2 * 64 * 64 + 2 * 64 * 128 + 2 * 2 * 64 * 192, (256 + 256) + (256 + 512) + 2 * (256 + 768), pk),
+        "ksr_dwrelu_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 256 + 256 + 256, pk),
+        "ksr_batch_tx_layer_fwd": ("mfma", 2 * (2 * 64 * 192 + lin_post + 256 * S), 2 * 512, pk),
+        "ksr_batch_attn_fwd": ("mfma", 2 * 256 * S, 2 * (768 + 256), f32),
+        "ksr_batch_tx_layer_post_fwd": ("hbm", 2 * lin_post, 1664 + 1920, pk),
+        "ksr_feed_kan_fwd": ("mfma" if not bf16 else "hbm", 2 * 64 * P + 400, 256 + 4 + 4 * 16, pk),
+        "ksr_bilinear_up": ("hbm", 0, 8 + 8 * 16, pk),
+        # backward
+        "ksr_feed_kan_bwd": ("hbm", 2 * 64 * P + 800, 64 + 4 + 128 + 256 + 4 * P, pk),
+        "ksr_batch_tx_layer_bwd_token": ("hbm", 2 * lin_post, 2304 + 2816, pk),
+        "ksr_batch_attn_bwd": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
+        "ksr_batch_tx_layer_bwd_attn": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
+        "ksr_in_proj_bwd": ("hbm", 2 * 2 * 192 * 64, 2 * (768 + 256 + 256 + 256), pk),
+        "ksr_gate_pw_bwd": ("hbm", 2 * 2 * 64 * 64, 2 * 1280, pk),
+        "ksr_fn1_bwd": ("hbm", 2 * (2 * 128 * 64 + 2 * 9 * 64), 2 * 1280, pk),
+        "ksr_pw2_bwd": ("hbm", 2 * 64 * 64, 768, pk),
+        "ksr_pw1_bwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 1024, pk),
+        "ksr_wgrad": ("hbm", 2 * wg_jk, wg_bytes, pk),
+        "ksr_colreduce": ("hbm", 0, 5 * 512 + 2 * 260, pk),
+        "ksr_dwconv_wgrad": ("hbm", 3 * 2 * 10 * 64, 3 * 512, pk),
     }
+
+
+# entry point -> device kernel of the default (bf16 training, S = 64) workload, for looking up the HBM bytes per
+# launch measured with the rocprofv3 PMC passes (profiles/pmc_hbm_bytes_per_launch.json)
+ENTRY_KERNEL = {
+    "ksr_batch_attn_bwd": "attn_bwd_kernel<2, true>", "ksr_batch_attn_fwd": "attn_fwd_kernel<2>",
+    "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<1>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<1, true, true>",
+    "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<1, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<1, 4, 8, 3>",
+    "ksr_gate_pw_fwd": "conv_fwd_kernel<1, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<1, 64, 0, 3>",
+}
+
+
+def measured_traffic(entry: str):
+    """HBM bytes per launch of the entry point's kernel from the committed PMC summary, or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_bytes_per_launch.json")
+    if entry not in ENTRY_KERNEL or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh).get(ENTRY_KERNEL[entry])
 
 
 def build_model(upscale=4, G=5, k=3, seed=0):
@@ -104,8 +141,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "fp32"), choices=["fp32", "bf16"],
-                    help="MFMA operand precision of the training workload (inference is always fp32)")
+    ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "bf16"), choices=["fp32", "bf16"],
+                    help="MFMA operand precision of the training workload: bf16 operands / fp32 accumulate and "
+                         "storage (BASELINE configs[2] is the bf16 training configuration) or exact fp32; "
+                         "inference is always fp32")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,8 +183,8 @@ def main():
         x = torch.rand(B, 3, H, W, device=dev)
         tgt = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
         ts = TrainStep(model, world_size=world, rank=rank)
-        wl = ("x4 SR training step fp32 (fwd + bwd + RCCL gradient all-reduce + Adam), 64 patches of 128x128 per GPU "
-              "(BASELINE configs[2], per-rank batch), dropout live")
+        wl = (f"x4 SR training step, {args.precision} MFMA operands / fp32 accumulate and storage (fwd + bwd + RCCL "
+              "gradient all-reduce + Adam), 64 patches of 128x128 per GPU (BASELINE configs[2], per-rank batch), dropout live")
 
         def step():
             return ts.step(x, tgt)
@@ -188,24 +227,31 @@ def main():
         dom = max(totals, key=totals.get)
         avg_ms = sum(prof[dom]) / len(prof[dom])
         P = 16 * (5 + 3 + 2)
-        kmodel = kernel_models(B, P).get(dom)
+        bf16 = args.workload == "train" and args.precision == "bf16"
+        models = kernel_models(B, P, bf16)
+        kmodel = models.get(dom)
         npx = B * H * W
         roofline = {"kernel": dom, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
                     "traffic": None}
-        if kmodel is not None:
-            bound, fl, by = kmodel
-            t = totals[dom] * 1e-3
+        def price(name):
+            bound, fl, by, peak = models[name]
+            t = totals[name] * 1e-3
             if bound == "mfma":
                 ach = fl * npx / t / 1e12
-                roofline.update(bound="mfma", achieved=round(ach, 3), peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s",
-                                frac=round(ach / PEAK_MFMA_F32_TFLOPS, 4))
-            else:
-                ach = by * npx / t / 1e9
-                roofline.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                                frac=round(ach / PEAK_HBM_GBS, 4))
+                return dict(bound="mfma", achieved=round(ach, 3), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4))
+            ach = by * npx / t / 1e9
+            return dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+
+        if kmodel is not None:
+            roofline.update(price(dom))
+        if bf16 and B == 64:
+            roofline["traffic"] = measured_traffic(dom)
+            roofline["traffic_source"] = "profiles/r01_train_b64_bf16_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
+            roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
         roofline["avg_launch_ms"] = round(avg_ms, 4)
         roofline["launches_per_step"] = len(prof[dom]) // nlaunch
         roofline["ms_per_step_by_entry_point"] = {k: round(v, 4) for k, v in sorted(totals.items())}
+        roofline["frac_by_entry_point"] = {k: [price(k)["bound"], price(k)["frac"]] for k in sorted(totals) if k in models}
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(args.workload)
         if world == 1 and args.workload == "train":
@@ -232,7 +278,8 @@ def main():
         print(json.dumps({
             "metric": "output megapixels/sec", "value": round(value, 3), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if (args.workload == "train" and args.precision == "bf16") else "f32",
             "data": "synthetic", "config": {"workload": wl, "upscale": 4, "grid_size": 5, "spline_order": 3,
                                             "per_gpu_batch": B, "lr_patch": [H, W]},
             "roofline": roofline, "cpu_baseline": cpu, "inference": inference}))
