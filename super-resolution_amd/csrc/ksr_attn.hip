@@ -10,17 +10,9 @@
 // (register r of lane half h is key (r&3)+8(r>>2)+4h of the block: the k-order of the A operand is
 // arranged to match), so scores and probabilities never leave the register file.  The softmax row
 // statistics need one exchange between the two lanes of a query.
-#include "ksr_gemm.h"
+#include "ksr_attn.h"
 
 namespace {
-
-struct AttnArgs {
-    const float* qkv;   // [N,192]
-    float* ctx;         // [N,64]
-    int S, Sp, HW;
-    float p_drop;
-    unsigned long long seed;
-};
 
 constexpr int KLD = 68;      // K rows: 64 channels + 4 pad
 constexpr int VLD = 132;     // V^T rows: 128 slots + 4 pad
@@ -28,18 +20,6 @@ constexpr int VLD = 132;     // V^T rows: 128 slots + 4 pad
 struct __attribute__((aligned(16))) AttnSmem {
     float k[128 * KLD];
     float vt[64 * VLD];
-};
-
-__device__ __forceinline__ int key_of_reg(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
-
-// Slot decoding without integer division.  Sp >= 32: a wave's blocks all belong to its own pixel, the image
-// index of block kb / index i is 32*kb + i.  Sp < 32 (a power of two): slot = 32*wave + i, pixel = slot >> lg.
-struct SlotMap {
-    int Sp, lg, big;
-    __device__ __forceinline__ void decode(int base0, int kb, int i, int my_pl, int& same_pixel, int& bb) const {
-        if (big) { same_pixel = 1; bb = 32 * kb + i; }
-        else { const int s = base0 + i; same_pixel = ((s >> lg) == my_pl); bb = s & (Sp - 1); }
-    }
 };
 
 template <int NW>   // key blocks per query: Sp / 32 (1 when Sp <= 32)
@@ -175,16 +155,6 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnArgs a) {
 
 
 // ------------------------------------------------------------------------------------------ backward
-struct AttnBwdArgs {
-    const float* qkv;    // [N,192]
-    const float* ctx;    // [N,64]
-    const float* dctx;   // [N,64]
-    float* dqkv;         // [N,192]
-    int S, Sp, HW;
-    float p_drop;
-    unsigned long long seed;
-};
-
 constexpr int RLD = 36;      // row-major per-head tiles: 32 dims + 4 pad
 constexpr int TLD = 132;     // transposed per-head tiles: 128 slots + 4 pad
 
@@ -393,8 +363,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnBwdArgs a) {
     }
 }
 
+// Slots per pixel: the next power of two (128 must be a multiple of it: a workgroup tile holds whole pixels).
 int padded_S(int S) {
-    if (S >= 32) return (S + 31) / 32 * 32;
     int sp = 1;
     while (sp < S) sp *= 2;
     return sp;
@@ -414,10 +384,10 @@ extern "C" int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, f
     const int PPW = 128 / a.Sp;
     const int ntiles = (HW + PPW - 1) / PPW;
     const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), block(256);
+    if (ksr_prec() == KSR_BF16) return ksr_attn_bf16_fwd_launch(a, a.Sp <= 32 ? 1 : a.Sp / 32, grid.x, stream);
     switch (a.Sp <= 32 ? 1 : a.Sp / 32) {
         case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, 0, stream, a); break;
         case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL(attn_fwd_kernel<3>, grid, block, 0, stream, a); break;
         default: hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, block, 0, stream, a); break;
     }
     KSR_LAUNCH_CHECK("batch_attn_fwd");
@@ -435,6 +405,7 @@ extern "C" int ksr_batch_attn_bwd(const float* qkv, const float* ctx, const floa
     const int PPW = 128 / a.Sp;
     const int ntiles = (HW + PPW - 1) / PPW;
     const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), block(256);
+    if (ksr_prec() == KSR_BF16) return ksr_attn_bf16_bwd_launch(a, a.Sp <= 32 ? 1 : a.Sp / 32, grid.x, stream);
     switch (a.Sp <= 32 ? 1 : a.Sp / 32) {
 #define KSR_ATTN_BWD(NWV)                                                                       \
     do {                                                                                        \
@@ -443,7 +414,6 @@ extern "C" int ksr_batch_attn_bwd(const float* qkv, const float* ctx, const floa
     } while (0)
         case 1: KSR_ATTN_BWD(1); break;
         case 2: KSR_ATTN_BWD(2); break;
-        case 3: KSR_ATTN_BWD(3); break;
         default: KSR_ATTN_BWD(4); break;
     }
 #undef KSR_ATTN_BWD

@@ -1,0 +1,440 @@
+// Batch-axis attention with bf16 MFMA operands (v_mfma_f32_32x32x16_bf16, fp32 accumulation): the bf16-mode
+// variants of the kernels in ksr_attn.hip.  Same slot scheme (slot = pl*Sp + b, a wave owns 32 slots, the
+// query sits on the MFMA column axis, the accumulator tile of one product is the B operand of the next) and
+// the same fp32 softmax / dropout arithmetic; only the four (forward) / ten (backward) products per key block
+// are rounded to bf16.  A 16-deep MFMA step pairs k-slot j of lane half g with
+//   dims   16*s + 8*g + j                          for products over the 32 dims of a head, and
+//   slots  16*s + 8*(j>>2) + 4*g + (j&3)           for products over the 32 slots of a block
+// (the second is the order in which an accumulator tile holds its rows), so LDS rows are read with one
+// 16-byte access per step and transposed tiles with two 8-byte accesses.
+// Rows of qkv / ctx are fetched with lane-linear 16-byte accesses (16 lanes per 256-byte row) and
+// redistributed through a wave-private LDS tile.
+#include "ksr_attn.h"
+
+namespace {
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int KLH = 72;      // forward K rows: 64 dims + 8 pad (bf16)
+constexpr int VLH = 136;     // transposed tiles: 128 slots + 8 pad (bf16)
+constexpr int RLH = 40;      // backward per-head rows: 32 dims + 8 pad (bf16)
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// Row (token) of every slot of this wave, or -1: slot = 32*wave + row.
+struct RowMap {
+    int Sp, lg, big, S, HW, wv, pl_w, b0_w, tile, PPW;
+    __device__ __forceinline__ long operator()(int row) const {
+        int pl, b;
+        if (big) { pl = pl_w; b = b0_w + row; }
+        else { const int s = wv * 32 + row; pl = s >> lg; b = s & (Sp - 1); }
+        const int p = tile * PPW + pl;
+        return (b < S && p < HW) ? (long)b * HW + p : -1;
+    }
+};
+
+// Lane-linear fetch of 32 rows x 64 channels (channels c0.. of a tensor with ld floats per row).
+__device__ __forceinline__ void fetch_rows(const float* __restrict__ base, const RowMap& rm, int ld, int c0, int lane,
+                                           float4 (&v)[8]) {
+    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long n = rm(4 * i + r4);
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n >= 0) v[i] = *reinterpret_cast<const float4*>(base + n * ld + c0 + c4);
+    }
+}
+
+// Fetched tile -> this lane's operand form: x[X][s][j] = channel 32*X + 16*s + 8*g + j of row (lane & 31).
+__device__ __forceinline__ void finish_split(float* __restrict__ xb, int lane, const float4 (&v)[8], float (&x)[2][2][8]) {
+    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+    ksr_wave_fence();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(xb + (4 * i + r4) * KSR_XPOSE_LD + c4) = v[i];
+    ksr_wave_fence();
+    const float* rp = xb + (lane & 31) * KSR_XPOSE_LD + 8 * (lane >> 5);
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float4 t0 = *reinterpret_cast<const float4*>(rp + 32 * X + 16 * s);
+            const float4 t1 = *reinterpret_cast<const float4*>(rp + 32 * X + 16 * s + 4);
+            x[X][s][0] = t0.x; x[X][s][1] = t0.y; x[X][s][2] = t0.z; x[X][s][3] = t0.w;
+            x[X][s][4] = t1.x; x[X][s][5] = t1.y; x[X][s][6] = t1.z; x[X][s][7] = t1.w;
+        }
+}
+
+__device__ __forceinline__ void pack_split(const float (&x)[2][2][8], float mul, bf16x8 (&p)[2][2]) {
+#pragma unroll
+    for (int X = 0; X < 2; ++X)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[X][s][j] = (__bf16)(x[X][s][j] * mul);
+}
+
+// acc[row = slot of block][col = lane] += sum over the 32 dims of rows[(rbase + slot)][dim] * x[dim]
+__device__ __forceinline__ void rows_times_x(const __bf16* __restrict__ rows, int ld, int rbase, int coff, int tok, int g,
+                                             const bf16x8 (&x)[2], f32x16& acc) {
+    const __bf16* rp = rows + (rbase + tok) * ld + coff + 8 * g;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) acc = mfma16(*reinterpret_cast<const bf16x8*>(rp + 16 * s), x[s], acc);
+}
+
+// acc[row = dim][col = lane] += sum over the 32 slots of a block of tr[dim][cbase + slot] * y[slot], y an
+// accumulator tile (register r of lane half g <-> slot (r&3) + 8(r>>2) + 4g)
+__device__ __forceinline__ void tr_times_acc(const __bf16* __restrict__ tr, int cbase, int tok, int g, const f32x16& y,
+                                             f32x16& acc) {
+    const __bf16* tp = tr + tok * VLH + cbase + 4 * g;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tp + 16 * s);
+        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tp + 16 * s + 8);
+        bf16x8 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) b[j] = (__bf16)y[8 * s + j];
+        acc = mfma16(a, b, acc);
+    }
+}
+
+// Accumulator tile (rows = 32 dims of one head) -> 32-float-wide LDS tile -> rows of a tensor, channels c0..c0+31
+__device__ __forceinline__ void store_dims32(float* __restrict__ xb, float* __restrict__ base, const RowMap& rm, int ld,
+                                             int c0, int lane, const f32x16& acc, float mul) {
+    const int tok = lane & 31, g = lane >> 5;
+    ksr_wave_fence();
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4*>(xb + tok * KSR_XPOSE16_LD + 8 * q + 4 * g) =
+            make_float4(acc[4 * q] * mul, acc[4 * q + 1] * mul, acc[4 * q + 2] * mul, acc[4 * q + 3] * mul);
+    ksr_wave_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+        const float4 t = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE16_LD + c4);
+        const long n = rm(row);
+        if (n >= 0) *reinterpret_cast<float4*>(base + n * ld + c0 + c4) = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+struct __attribute__((aligned(16))) FwdSmem {
+    __bf16 k[128 * KLH];
+    __bf16 vt[64 * VLH];
+    float xpose[4 * KSR_XPOSE_FLOATS];
+};
+
+template <int NW>
+__global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
+    __shared__ FwdSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, g = lane >> 5;
+    const int S = a.S, Sp = a.Sp, HW = a.HW;
+    const int PPW = 128 / Sp;
+    const int ntiles = (HW + PPW - 1) / PPW;
+    const int slot = wv * 32 + tok;
+    const int pl = slot / Sp, b = slot - pl * Sp;
+    const float scale = 0.17677669529663687f;
+    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+    const bool drop = a.p_drop > 0.f;
+    const int kbase0 = (Sp >= 32) ? pl * Sp : wv * 32;
+    int lg = 0;
+    while ((1 << lg) < Sp) ++lg;
+    const SlotMap smap{Sp, lg, Sp >= 32};
+    float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const RowMap rm{Sp, lg, Sp >= 32, S, HW, wv, (wv * 32) / Sp, (wv * 32) % Sp, tile, PPW};
+        const int p = tile * PPW + pl;
+        const bool live = (b < S) && (p < HW);
+        const long n = live ? ((long)b * HW + p) : 0;
+
+        bf16x8 qb[2][2];
+        {
+            float4 fq[8], fk[8], fv[8];
+            fetch_rows(a.qkv, rm, 192, 0, lane, fq);
+            fetch_rows(a.qkv, rm, 192, 64, lane, fk);
+            fetch_rows(a.qkv, rm, 192, 128, lane, fv);
+            float x[2][2][8];
+            finish_split(xb, lane, fq, x);
+            pack_split(x, scale, qb);
+            __syncthreads();                        // previous tile's readers of k / vt are done
+            finish_split(xb, lane, fk, x);
+#pragma unroll
+            for (int X = 0; X < 2; ++X)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 w;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w[j] = (__bf16)x[X][s][j];
+                    *reinterpret_cast<bf16x8*>(&sm.k[slot * KLH + 32 * X + 16 * s + 8 * g]) = w;
+                }
+            finish_split(xb, lane, fv, x);
+#pragma unroll
+            for (int X = 0; X < 2; ++X)
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) sm.vt[(32 * X + 16 * s + 8 * g + j) * VLH + slot] = (__bf16)x[X][s][j];
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int X = 0; X < 2; ++X) {
+            // ---- scores^T = K q^T, masked softmax (rows split over the lane pair) ----
+            f32x16 sc[NW];
+            float m = -INFINITY;
+            const unsigned dbase = drop ? ksr_attn_drop_base(a.seed, (unsigned long long)n, X) : 0u;
+#pragma unroll
+            for (int kb = 0; kb < NW; ++kb) {
+                sc[kb] = zero16();
+                rows_times_x(sm.k, KLH, kbase0 + 32 * kb, 32 * X, tok, g, qb[X], sc[kb]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int same, kbb;
+                    smap.decode(kbase0, kb, key_of_reg(r, g), pl, same, kbb);
+                    sc[kb][r] = (same && (kbb < S)) ? sc[kb][r] : -INFINITY;
+                    m = fmaxf(m, sc[kb][r]);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float pj = expf(sc[kb][r] - m);
+                    l += pj;
+                    if (drop) {
+                        int same, kbb;
+                        smap.decode(kbase0, kb, key_of_reg(r, g), pl, same, kbb);
+                        pj = ksr_attn_keep(dbase, kbb, keep) ? pj * inv_keep : 0.f;
+                    }
+                    sc[kb][r] = pj;
+                }
+            const float inv_l = 1.f / ksr_pair_sum(l);
+            // ---- ctx^T = V^T P^T ----
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int kb = 0; kb < NW; ++kb) tr_times_acc(sm.vt + 32 * X * VLH, kbase0 + 32 * kb, tok, g, sc[kb], acc);
+            store_dims32(xb, a.ctx, rm, 64, 32 * X, lane, acc, inv_l);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+struct __attribute__((aligned(16))) BwdSmem {
+    __bf16 rowA[128 * RLH];   // phase A: K rows  | phase B: Q rows (scaled)
+    __bf16 rowB[128 * RLH];   // phase A: V rows  | phase B: dO rows
+    __bf16 trA[32 * VLH];     // phase A: K^T     | phase B: Q^T (scaled)
+    __bf16 trB[32 * VLH];     //                  | phase B: dO^T
+    float stat[128 * 4];      // per query slot: m, 1/l, D, dropout base (bits)
+    float xpose[4 * KSR_XPOSE_FLOATS];
+};
+
+__device__ __forceinline__ void put_rows(__bf16* __restrict__ rows, int slot, int g, const bf16x8 (&x)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(&rows[slot * RLH + 16 * s + 8 * g]) = x[s];
+}
+__device__ __forceinline__ void put_tr(__bf16* __restrict__ tr, int slot, int g, const bf16x8 (&x)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tr[(16 * s + 8 * g + j) * VLH + slot] = x[s][j];
+}
+
+template <int NW, bool DROP>
+__global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
+    __shared__ BwdSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, g = lane >> 5;
+    const int S = a.S, Sp = a.Sp, HW = a.HW;
+    const int PPW = 128 / Sp;
+    const int ntiles = (HW + PPW - 1) / PPW;
+    const int slot = wv * 32 + tok;
+    const int pl = slot / Sp, b = slot - pl * Sp;
+    const float scale = 0.17677669529663687f;
+    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+    const int base0 = (Sp >= 32) ? pl * Sp : wv * 32;
+    int lg = 0;
+    while ((1 << lg) < Sp) ++lg;
+    const SlotMap smap{Sp, lg, Sp >= 32};
+    float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const RowMap rm{Sp, lg, Sp >= 32, S, HW, wv, (wv * 32) / Sp, (wv * 32) % Sp, tile, PPW};
+        const int p = tile * PPW + pl;
+        const bool live = (b < S) && (p < HW);
+        const long n = live ? ((long)b * HW + p) : 0;
+
+        // operands of this lane's token in MFMA form, both heads; D = rowsum(dO * O) per head (fp32)
+        bf16x8 qb[2][2], kb_[2][2], vb[2][2], dob[2][2];
+        float D[2];
+        {
+            float4 f0[8], f1[8], f2[8];
+            float x[2][2][8];
+            fetch_rows(a.qkv, rm, 192, 0, lane, f0);
+            fetch_rows(a.qkv, rm, 192, 64, lane, f1);
+            fetch_rows(a.qkv, rm, 192, 128, lane, f2);
+            finish_split(xb, lane, f0, x); pack_split(x, scale, qb);
+            finish_split(xb, lane, f1, x); pack_split(x, 1.f, kb_);
+            finish_split(xb, lane, f2, x); pack_split(x, 1.f, vb);
+            fetch_rows(a.dctx, rm, 64, 0, lane, f0);
+            fetch_rows(a.ctx, rm, 64, 0, lane, f1);
+            float o[2][2][8];
+            finish_split(xb, lane, f0, x); pack_split(x, 1.f, dob);
+            finish_split(xb, lane, f1, o);
+#pragma unroll
+            for (int X = 0; X < 2; ++X) {
+                float d = 0.f;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d += x[X][s][j] * o[X][s][j];
+                D[X] = ksr_pair_sum(d);
+            }
+        }
+
+#pragma unroll 1
+        for (int X = 0; X < 2; ++X) {
+            // this head's operands (selected by value: the loop is not unrolled, to bound register pressure)
+            bf16x8 qx[2], kx[2], vx[2], dox[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                qx[s] = X ? qb[1][s] : qb[0][s];
+                kx[s] = X ? kb_[1][s] : kb_[0][s];
+                vx[s] = X ? vb[1][s] : vb[0][s];
+                dox[s] = X ? dob[1][s] : dob[0][s];
+            }
+            const float DX = X ? D[1] : D[0];
+            // ---------------- phase A: this lane is a query; LDS holds K rows, V rows, K^T ----------------
+            __syncthreads();
+            put_rows(sm.rowA, slot, g, kx);
+            put_rows(sm.rowB, slot, g, vx);
+            put_tr(sm.trA, slot, g, kx);
+            __syncthreads();
+            float m = -INFINITY, inv_l;
+            const unsigned dbase = DROP ? ksr_attn_drop_base(a.seed, (unsigned long long)n, X) : 0u;
+            {
+                f32x16 st[NW];
+#pragma unroll
+                for (int kb = 0; kb < NW; ++kb) {
+                    st[kb] = zero16();
+                    rows_times_x(sm.rowA, RLH, base0 + 32 * kb, 0, tok, g, qx, st[kb]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int same, kbb;
+                        smap.decode(base0, kb, key_of_reg(r, g), pl, same, kbb);
+                        st[kb][r] = (same && (kbb < S)) ? st[kb][r] : -INFINITY;
+                        m = fmaxf(m, st[kb][r]);
+                    }
+                }
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float l = 0.f;
+#pragma unroll
+                for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { st[kb][r] = expf(st[kb][r] - m); l += st[kb][r]; }
+                inv_l = 1.f / ksr_pair_sum(l);
+                f32x16 dq = zero16();
+#pragma unroll
+                for (int kb = 0; kb < NW; ++kb) {
+                    f32x16 dp = zero16();
+                    rows_times_x(sm.rowB, RLH, base0 + 32 * kb, 0, tok, g, dox, dp);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float dpr = dp[r];
+                        if (DROP) {
+                            int same, kbb;
+                            smap.decode(base0, kb, key_of_reg(r, g), pl, same, kbb);
+                            dpr = ksr_attn_keep(dbase, kbb, keep) ? dpr * inv_keep : 0.f;
+                        }
+                        dp[r] = st[kb][r] * inv_l * (dpr - DX) * scale;      // dS (scaled for dq)
+                    }
+                    tr_times_acc(sm.trA, base0 + 32 * kb, tok, g, dp, dq);
+                }
+                store_dims32(xb, a.dqkv, rm, 192, 32 * X, lane, dq, 1.f);
+            }
+            // ---------------- phase B: this lane is a key; LDS holds Q rows, dO rows, Q^T, dO^T, stats ----------------
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            put_rows(sm.rowA, slot, g, qx);
+            put_rows(sm.rowB, slot, g, dox);
+            put_tr(sm.trA, slot, g, qx);
+            put_tr(sm.trB, slot, g, dox);
+            if (g == 0) *reinterpret_cast<f32x4*>(&sm.stat[slot * 4]) = f32x4{m, inv_l, DX, __uint_as_float(dbase)};
+            __syncthreads();
+            {
+                f32x16 dk = zero16(), dv = zero16();
+#pragma unroll
+                for (int qblk = 0; qblk < NW; ++qblk) {
+                    f32x16 sq = zero16(), dp = zero16();
+                    rows_times_x(sm.rowA, RLH, base0 + 32 * qblk, 0, tok, g, kx, sq);
+                    rows_times_x(sm.rowB, RLH, base0 + 32 * qblk, 0, tok, g, vx, dp);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int qs = base0 + 32 * qblk + key_of_reg(r, g);      // query slot
+                        int same, qbb;
+                        smap.decode(base0, qblk, key_of_reg(r, g), pl, same, qbb);
+                        const bool ok = same && (qbb < S) && (p < HW);
+                        const f32x4 stt = *reinterpret_cast<const f32x4*>(&sm.stat[qs * 4]);
+                        const float pij = ok ? expf(sq[r] - stt[0]) * stt[1] : 0.f;
+                        float pt = pij, dpr = dp[r];
+                        if (DROP) {
+                            const bool kept = ksr_attn_keep(__float_as_uint(stt[3]), b, keep);
+                            pt = kept ? pij * inv_keep : 0.f;
+                            dpr = kept ? dpr * inv_keep : 0.f;
+                        }
+                        sq[r] = pij * (dpr - stt[2]);    // dS
+                        dp[r] = pt;                       // probabilities after dropout
+                    }
+                    tr_times_acc(sm.trA, base0 + 32 * qblk, tok, g, sq, dk);
+                    tr_times_acc(sm.trB, base0 + 32 * qblk, tok, g, dp, dv);
+                }
+                store_dims32(xb, a.dqkv, rm, 192, 64 + 32 * X, lane, dk, 1.f);
+                store_dims32(xb, a.dqkv, rm, 192, 128 + 32 * X, lane, dv, 1.f);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int ksr_attn_bf16_fwd_launch(const AttnArgs& a, int nw, unsigned grid, hipStream_t stream) {
+    const dim3 g(grid), block(256);
+    switch (nw) {
+        case 1: hipLaunchKernelGGL(attn_fwd_bf16_kernel<1>, g, block, 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, g, block, 0, stream, a); break;
+        default: hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, g, block, 0, stream, a); break;
+    }
+    KSR_LAUNCH_CHECK("batch_attn_fwd(bf16)");
+    return KSR_OK;
+}
+
+int ksr_attn_bf16_bwd_launch(const AttnBwdArgs& a, int nw, unsigned grid, hipStream_t stream) {
+    const dim3 g(grid), block(256);
+    const bool drop = a.p_drop > 0.f;
+#define KSR_ATTN_BWD(NWV)                                                                          \
+    do {                                                                                           \
+        if (drop) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NWV, true>), g, block, 0, stream, a);   \
+        else hipLaunchKernelGGL((attn_bwd_bf16_kernel<NWV, false>), g, block, 0, stream, a);       \
+    } while (0)
+    switch (nw) {
+        case 1: KSR_ATTN_BWD(1); break;
+        case 2: KSR_ATTN_BWD(2); break;
+        default: KSR_ATTN_BWD(4); break;
+    }
+#undef KSR_ATTN_BWD
+    KSR_LAUNCH_CHECK("batch_attn_bwd(bf16)");
+    return KSR_OK;
+}

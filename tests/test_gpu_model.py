@@ -255,7 +255,7 @@ def test_mfma_attention_split_layer_vs_oracle(S, HW):
     assert_fwd(out2, out, atol=2e-5)
 
 
-@pytest.mark.parametrize("S,HW", [(3, 41), (8, 20), (20, 9), (32, 6), (64, 5), (100, 3)])
+@pytest.mark.parametrize("S,HW", [(3, 41), (8, 20), (20, 9), (32, 6), (64, 5), (80, 4), (100, 3)])
 @pytest.mark.parametrize("p_drop", [0.0, 0.3])
 def test_mfma_attention_matches_valu_attention(S, HW, p_drop):
     """Forward and backward MFMA attention kernels against the VALU kernels (same dropout masks), and the
@@ -308,3 +308,32 @@ def test_bf16_mfma_mode_golden(r, G, k):
     m.precision = "fp32"
     with torch.no_grad():
         assert_fwd(m.eval()(t(g["x"]).cuda()), t(g["y"]), atol=2e-5)
+
+
+@pytest.mark.parametrize("S,HW,p_drop", [(3, 50, 0.0), (8, 40, 0.1), (32, 9, 0.0), (64, 130, 0.1), (100, 7, 0.1), (128, 5, 0.0)])
+def test_bf16_attention_matches_fp32_attention(S, HW, p_drop):
+    """bf16-operand attention kernels against the fp32 ones on the same inputs and dropout masks.  Stated
+    tolerance (bf16 operands, fp32 softmax and accumulation): rel-L2 <= 2e-2 forward and backward."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(7 * S + HW)
+    N = S * HW
+    qkv = torch.randn(N, 192, device="cuda")
+    dctx = torch.randn(N, 64, device="cuda")
+    L = lib()
+    res = {}
+    try:
+        for prec in ("fp32", "bf16"):
+            engine.set_precision(prec)
+            ctx = torch.full((N, 64), float("nan"), device="cuda")
+            dqkv = torch.full((N, 192), float("nan"), device="cuda")
+            check(L.ksr_batch_attn_fwd(ptr(qkv), ptr(ctx), c_int(S), c_int(HW), c_float(p_drop), c_uint64(5), stream()), "fwd")
+            check(L.ksr_batch_attn_bwd(ptr(qkv), ptr(ctx), ptr(dctx), ptr(dqkv), c_int(S), c_int(HW), c_float(p_drop),
+                                       c_uint64(5), stream()), "bwd")
+            res[prec] = (ctx.cpu(), dqkv.cpu())
+    finally:
+        engine.set_precision("fp32")
+    assert bool(torch.isfinite(res["bf16"][0]).all()) and bool(torch.isfinite(res["bf16"][1]).all())
+    assert rel_l2(res["bf16"][0], res["fp32"][0]) <= 2e-2
+    for c0, name in ((0, "dq"), (64, "dk"), (128, "dv")):
+        assert rel_l2(res["bf16"][1][:, c0:c0 + 64], res["fp32"][1][:, c0:c0 + 64]) <= 2e-2, name
