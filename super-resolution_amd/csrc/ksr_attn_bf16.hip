@@ -23,6 +23,9 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
+// exp(x) for x <= 0 (or -inf) as one v_exp_f32: the arguments are differences to the row maximum
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
             for (int kb = 0; kb < NW; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pj = expf(sc[kb][r] - m);
+                    float pj = fast_exp(sc[kb][r] - m);
                     l += pj;
                     if (drop) {
                         int same, kbb;
@@ -344,7 +347,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < NW; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { st[kb][r] = expf(st[kb][r] - m); l += st[kb][r]; }
+                    for (int r = 0; r < 16; ++r) { st[kb][r] = fast_exp(st[kb][r] - m); l += st[kb][r]; }
                 inv_l = 1.f / ksr_pair_sum(l);
                 f32x16 dq = zero16();
 #pragma unroll
@@ -388,7 +391,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                         smap.decode(base0, qblk, key_of_reg(r, g), pl, same, qbb);
                         const bool ok = same && (qbb < S) && (p < HW);
                         const f32x4 stt = *reinterpret_cast<const f32x4*>(&sm.stat[qs * 4]);
-                        const float pij = ok ? expf(sq[r] - stt[0]) * stt[1] : 0.f;
+                        const float pij = ok ? fast_exp(sq[r] - stt[0]) * stt[1] : 0.f;
                         float pt = pij, dpr = dp[r];
                         if (DROP) {
                             const bool kept = ksr_attn_keep(__float_as_uint(stt[3]), b, keep);

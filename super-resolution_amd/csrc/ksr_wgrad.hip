@@ -198,22 +198,31 @@ struct RedArgs {
 };
 
 __global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
-    // 16 outputs x 16 slab groups per workgroup; group partials are combined in a fixed order
-    __shared__ float part[16][17];
-    const int o = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const int idx = blockIdx.x * 16 + o;
+    // 32 outputs x 8 slab groups per workgroup (lanes = consecutive outputs: 128-byte rows of the slabs); every
+    // thread keeps 4 independent partial sums; all partials are combined in a fixed order
+    __shared__ float part[8][33];
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + o;
     const int total = a.J * a.K + (a.bias ? a.tail_len : 0);
     const bool is_bias = idx >= a.J * a.K;
     const float* slab = a.slab + (long)blockIdx.y * a.G * a.stride + (is_bias ? a.tail_off + idx - a.J * a.K : idx);
-    float s = 0.f;
-    if (idx < total)
-        for (int g = grp; g < a.G; g += 16) s += slab[(long)g * a.stride];
-    part[grp][o] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < total) {
+        int g = grp;
+        for (; g + 24 < a.G; g += 32) {
+            s0 += slab[(long)g * a.stride];
+            s1 += slab[(long)(g + 8) * a.stride];
+            s2 += slab[(long)(g + 16) * a.stride];
+            s3 += slab[(long)(g + 24) * a.stride];
+        }
+        for (; g < a.G; g += 8) s0 += slab[(long)g * a.stride];
+    }
+    part[grp][o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp != 0 || idx >= total) return;
-    s = 0.f;
+    float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += part[r][o];
+    for (int r = 0; r < 8; ++r) s += part[r][o];
     int j, k;
     if (is_bias) { j = idx - a.J * a.K; k = 0; }
     else { j = idx / a.K; k = idx - j * a.K; }
@@ -411,7 +420,7 @@ int launch_reduce(const float* slab, int G, int J, int K, long stride, float* ou
     if (tail_off < 0) { tail_off = J * K; tail_len = J; }
     RedArgs r{slab, G, J, K, stride, out, sj, sk, bias, kan_O, kan_Kc, kan_nbh, tail_off, tail_len, out_bstride};
     const int total = J * K + (bias ? tail_len : 0);
-    hipLaunchKernelGGL(reduce_kernel, dim3((total + 15) / 16, nb), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(reduce_kernel, dim3((total + 31) / 32, nb), dim3(256), 0, s, r);
     KSR_LAUNCH_CHECK("reduce");
     return KSR_OK;
 }
