@@ -141,10 +141,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "bf16"), choices=["fp32", "bf16"],
-                    help="MFMA operand precision of the training workload: bf16 operands / fp32 accumulate and "
-                         "storage (BASELINE configs[2] is the bf16 training configuration) or exact fp32; "
-                         "inference is always fp32")
+    ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "bf16"), choices=["fp32", "bf16", "bf16s"],
+                    help="precision mode of the training workload: bf16 = bf16 MFMA operands / fp32 accumulate and "
+                         "storage, bf16s = also bf16 storage of the activations between kernels (BASELINE configs[2] is "
+                         "the bf16 training configuration), fp32 = exact; inference is always fp32")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,8 +183,10 @@ def main():
         x = torch.rand(B, 3, H, W, device=dev)
         tgt = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
         ts = TrainStep(model, world_size=world, rank=rank)
-        wl = (f"x4 SR training step, {args.precision} MFMA operands / fp32 accumulate and storage (fwd + bwd + RCCL "
-              "gradient all-reduce + Adam), 64 patches of 128x128 per GPU (BASELINE configs[2], per-rank batch), dropout live")
+        mode = {"fp32": "exact fp32", "bf16": "bf16 MFMA operands / fp32 accumulate and storage",
+                "bf16s": "bf16 MFMA operands and activation storage / fp32 accumulate"}[args.precision]
+        wl = (f"x4 SR training step, {mode} (fwd + bwd + RCCL gradient all-reduce + Adam), 64 patches of 128x128 per "
+              "GPU (BASELINE configs[2], per-rank batch), dropout live")
 
         def step():
             return ts.step(x, tgt)
@@ -227,7 +229,7 @@ def main():
         dom = max(totals, key=totals.get)
         avg_ms = sum(prof[dom]) / len(prof[dom])
         P = 16 * (5 + 3 + 2)
-        bf16 = args.workload == "train" and args.precision == "bf16"
+        bf16 = args.workload == "train" and args.precision != "fp32"
         models = kernel_models(B, P, bf16)
         kmodel = models.get(dom)
         npx = B * H * W
@@ -279,7 +281,7 @@ def main():
             "metric": "output megapixels/sec", "value": round(value, 3), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if (args.workload == "train" and args.precision == "bf16") else "f32",
+            "dtype": "bf16" if (args.workload == "train" and args.precision != "fp32") else "f32",
             "data": "synthetic", "config": {"workload": wl, "upscale": 4, "grid_size": 5, "spline_order": 3,
                                             "per_gpu_batch": B, "lr_patch": [H, W]},
             "roofline": roofline, "cpu_baseline": cpu, "inference": inference}))

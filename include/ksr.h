@@ -29,11 +29,19 @@ typedef struct ihipStream_t* ksr_stream_t; /* == hipStream_t */
 int ksr_version(void);
 const char* ksr_last_error(void);
 
-/* MFMA operand precision of every 1x1-conv / linear GEMM kernel below: 0 = exact fp32 (the mode in which
- * parity with the reference's fp32 results is stated), 1 = bf16 operands with fp32 accumulation (the
- * reference has no such mode; separately stated tolerance).  HBM storage, the spline basis, LayerNorm,
- * softmax, the attention products and the weight-gradient reductions stay fp32 in both modes.
- * Process-wide, read at launch time. */
+/* Precision mode of the kernels below (process-wide, read at launch time):
+ *   0  exact fp32 MFMA, fp32 storage: the mode in which parity with the reference's fp32 results is stated;
+ *   1  bf16 MFMA operands with fp32 accumulation (1x1 convs / linears, attention products, weight gradients),
+ *      fp32 storage (the reference has no such mode; separately stated tolerance);
+ *   2  as 1, and every [N, C] activation / activation-gradient tensor exchanged between the kernels of the
+ *      hyper-encoder path is STORED AS bf16: in this mode the `float*` parameters that carry such tensors
+ *      point to bf16 buffers of the same shape.  Images, outputs, per-pixel scalars (v, rstd, dpre),
+ *      parameters, parameter gradients and workspaces stay fp32.  The KAN-cell, bilinear, loss, optimiser and
+ *      channel-attention entry points have no mode-2 variant (fp32 tensors only).
+ * The spline basis, LayerNorm, softmax and all accumulation are fp32 in every mode.
+ * out_f32_copy / in_f32_copy arguments: the one tensor whose bf16 rounding matters (the sigmoid output that
+ * enters the first transformer layer's residual + LayerNorm: values 0.5 +- 1e-3 at initialisation) can be kept
+ * as an additional fp32 copy; NULL = not used. */
 int ksr_set_precision(int prec);
 int ksr_get_precision(void);
 
@@ -95,7 +103,8 @@ int ksr_dwrelu_pw_fwd(const float* in, const float* dw_w, const float* dw_b, con
  * gate = depthwise3x3(t[:, 64:]) ; out = sigmoid(fn_2(value * gate))  (unet_blocks.py:269-275,
  * gazetr.py:104,107).  save_gate [N,64] optional = the gate (after the depthwise conv). */
 int ksr_gate_pw_fwd(const float* t_in, const float* gate_w, const float* gate_b, const float* w,
-                    const float* bias, float* out, float* save_gate, int B, int H, int W, ksr_stream_t stream);
+                    const float* bias, float* out, float* save_gate, float* out_f32_copy, int B, int H, int W,
+                    ksr_stream_t stream);
 
 /* One TransformerEncoderLayer (conv_sep_kan/gazetr.py:53-66) applied the way GazeTR applies it
  * (gazetr.py:110-115): nn.MultiheadAttention(E=64, 2 heads, batch_first=True) on a tensor arranged
@@ -108,7 +117,8 @@ int ksr_gate_pw_fwd(const float* t_in, const float* gate_w, const float* gate_b,
  *   hmid [N,32], xhat2 [N,64], rstd2 [N], xhat_final [N,64], rstd_final [N].
  *   p_drop > 0 enables the four dropout sites (counter-based generator keyed by seed). S <= 128. */
 int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* const* params, float* const* saves, int S,
-                           int HW, float eps, float p_drop, uint64_t seed, ksr_stream_t stream);
+                           int HW, float eps, float p_drop, uint64_t seed, const float* in_f32_copy,
+                           ksr_stream_t stream);
 
 /* The same layer as three kernels, used for large local batches: ksr_pointwise_fwd(n_out = 192) computes
  * qkv [N,192] = in_proj(x); ksr_batch_attn_fwd runs the 2-head softmax attention over the S images of every
@@ -118,7 +128,7 @@ int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, float p_drop
                        ksr_stream_t stream);
 int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, float* out, const float* const* params,
                                 float* const* saves, int64_t N, float eps, float p_drop, uint64_t seed,
-                                ksr_stream_t stream);
+                                const float* in_f32_copy, ksr_stream_t stream);
 
 /* feed (1x1 conv 64 -> P, gazetr.py:117) + ConvSepKanCell (conv_sep_kan_cells.py:136-156) + PixelShuffle
  * (conv_sep_kan.py:38) fused; the [N,P] coefficient tensor is never written.  in_dim = 1, out_dim =

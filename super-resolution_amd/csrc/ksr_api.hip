@@ -15,13 +15,14 @@ extern "C" const char* ksr_last_error(void) { return g_err; }
 
 extern "C" int ksr_version(void) { return 100; }
 
-// MFMA operand precision of the GEMM kernels (0 = exact fp32, 1 = bf16 operands / fp32 accumulate).
+// Precision mode: 0 = exact fp32, 1 = bf16 MFMA operands / fp32 accumulate and storage, 2 = as 1 with the
+// activation and gradient tensors between kernels stored as bf16.
 // Process-wide, read at launch time; the caller sets it before a forward/backward sequence.
 static int g_prec = 0;
 int ksr_prec() { return g_prec; }
 
 extern "C" int ksr_set_precision(int prec) {
-    KSR_CHECK_ARG(prec == 0 || prec == 1, "set_precision: 0 (fp32) or 1 (bf16 MFMA operands)");
+    KSR_CHECK_ARG(prec >= 0 && prec <= 2, "set_precision: 0 (fp32), 1 (bf16 MFMA operands) or 2 (bf16 operands and activation storage)");
     g_prec = prec;
     return KSR_OK;
 }

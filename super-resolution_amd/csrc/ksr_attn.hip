@@ -384,7 +384,7 @@ extern "C" int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, f
     const int PPW = 128 / a.Sp;
     const int ntiles = (HW + PPW - 1) / PPW;
     const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), block(256);
-    if (ksr_prec() == KSR_BF16) return ksr_attn_bf16_fwd_launch(a, a.Sp <= 32 ? 1 : a.Sp / 32, grid.x, stream);
+    if (ksr_prec() != KSR_F32) return ksr_attn_bf16_fwd_launch(a, a.Sp <= 32 ? 1 : a.Sp / 32, grid.x, stream);
     switch (a.Sp <= 32 ? 1 : a.Sp / 32) {
         case 1: hipLaunchKernelGGL(attn_fwd_kernel<1>, grid, block, 0, stream, a); break;
         case 2: hipLaunchKernelGGL(attn_fwd_kernel<2>, grid, block, 0, stream, a); break;
@@ -405,7 +405,7 @@ extern "C" int ksr_batch_attn_bwd(const float* qkv, const float* ctx, const floa
     const int PPW = 128 / a.Sp;
     const int ntiles = (HW + PPW - 1) / PPW;
     const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), block(256);
-    if (ksr_prec() == KSR_BF16) return ksr_attn_bf16_bwd_launch(a, a.Sp <= 32 ? 1 : a.Sp / 32, grid.x, stream);
+    if (ksr_prec() != KSR_F32) return ksr_attn_bf16_bwd_launch(a, a.Sp <= 32 ? 1 : a.Sp / 32, grid.x, stream);
     switch (a.Sp <= 32 ? 1 : a.Sp / 32) {
 #define KSR_ATTN_BWD(NWV)                                                                       \
     do {                                                                                        \

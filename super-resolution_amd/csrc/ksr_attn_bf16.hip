@@ -45,24 +45,34 @@ struct RowMap {
     }
 };
 
-// Lane-linear fetch of 32 rows x 64 channels (channels c0.. of a tensor with ld floats per row).
-__device__ __forceinline__ void fetch_rows(const float* __restrict__ base, const RowMap& rm, int ld, int c0, int lane,
-                                           float4 (&v)[8]) {
-    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+// Lane-linear fetch of 32 rows x 64 channels (channels c0.. of a tensor with ld elements per row, stored as T).
+template <class T>
+__device__ __forceinline__ void fetch_rows(const void* __restrict__ base, const RowMap& rm, int ld, int c0, int lane,
+                                           KsrTile<T>& t) {
+    if constexpr (sizeof(T) == 4) {
+        const int r4 = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const long n = rm(4 * i + r4);
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (n >= 0) v[i] = *reinterpret_cast<const float4*>(base + n * ld + c0 + c4);
+        for (int i = 0; i < 8; ++i) {
+            const long n = rm(4 * i + r4);
+            t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n >= 0) t.v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + n * ld + c0 + c4);
+        }
+    } else {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long n = rm(8 * i + r8);
+            t.v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (n >= 0) t.v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + n * ld + c0 + c8);
+        }
     }
 }
 
 // Fetched tile -> this lane's operand form: x[X][s][j] = channel 32*X + 16*s + 8*g + j of row (lane & 31).
-__device__ __forceinline__ void finish_split(float* __restrict__ xb, int lane, const float4 (&v)[8], float (&x)[2][2][8]) {
-    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+template <class T>
+__device__ __forceinline__ void finish_split(float* __restrict__ xb, int lane, const KsrTile<T>& t, float (&x)[2][2][8]) {
     ksr_wave_fence();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(xb + (4 * i + r4) * KSR_XPOSE_LD + c4) = v[i];
+    ksr_co_to_lds<T>(xb, lane, t);
     ksr_wave_fence();
     const float* rp = xb + (lane & 31) * KSR_XPOSE_LD + 8 * (lane >> 5);
 #pragma unroll
@@ -112,7 +122,8 @@ __device__ __forceinline__ void tr_times_acc(const __bf16* __restrict__ tr, int 
 }
 
 // Accumulator tile (rows = 32 dims of one head) -> 32-float-wide LDS tile -> rows of a tensor, channels c0..c0+31
-__device__ __forceinline__ void store_dims32(float* __restrict__ xb, float* __restrict__ base, const RowMap& rm, int ld,
+template <class T>
+__device__ __forceinline__ void store_dims32(float* __restrict__ xb, void* __restrict__ base, const RowMap& rm, int ld,
                                              int c0, int lane, const f32x16& acc, float mul) {
     const int tok = lane & 31, g = lane >> 5;
     ksr_wave_fence();
@@ -121,12 +132,24 @@ __device__ __forceinline__ void store_dims32(float* __restrict__ xb, float* __re
         *reinterpret_cast<float4*>(xb + tok * KSR_XPOSE16_LD + 8 * q + 4 * g) =
             make_float4(acc[4 * q] * mul, acc[4 * q + 1] * mul, acc[4 * q + 2] * mul, acc[4 * q + 3] * mul);
     ksr_wave_fence();
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
-        const float4 t = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE16_LD + c4);
-        const long n = rm(row);
-        if (n >= 0) *reinterpret_cast<float4*>(base + n * ld + c0 + c4) = t;
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            const float4 t = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE16_LD + c4);
+            const long n = rm(row);
+            if (n >= 0) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + n * ld + c0 + c4) = t;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 2, c8 = (idx & 3) * 8;
+            const float* sp = xb + row * KSR_XPOSE16_LD + c8;
+            const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const long n = rm(row);
+            if (n >= 0) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + n * ld + c0 + c8) = ksr_pack8(x);
+        }
     }
 }
 
@@ -137,7 +160,7 @@ struct __attribute__((aligned(16))) FwdSmem {
     float xpose[4 * KSR_XPOSE_FLOATS];
 };
 
-template <int NW>
+template <int NW, class ST>
 __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
     __shared__ FwdSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -164,15 +187,15 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
 
         bf16x8 qb[2][2];
         {
-            float4 fq[8], fk[8], fv[8];
-            fetch_rows(a.qkv, rm, 192, 0, lane, fq);
-            fetch_rows(a.qkv, rm, 192, 64, lane, fk);
-            fetch_rows(a.qkv, rm, 192, 128, lane, fv);
+            KsrTile<ST> fq, fk, fv;
+            fetch_rows<ST>(a.qkv, rm, 192, 0, lane, fq);
+            fetch_rows<ST>(a.qkv, rm, 192, 64, lane, fk);
+            fetch_rows<ST>(a.qkv, rm, 192, 128, lane, fv);
             float x[2][2][8];
-            finish_split(xb, lane, fq, x);
+            finish_split<ST>(xb, lane, fq, x);
             pack_split(x, scale, qb);
             __syncthreads();                        // previous tile's readers of k / vt are done
-            finish_split(xb, lane, fk, x);
+            finish_split<ST>(xb, lane, fk, x);
 #pragma unroll
             for (int X = 0; X < 2; ++X)
 #pragma unroll
@@ -182,7 +205,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
                     for (int j = 0; j < 8; ++j) w[j] = (__bf16)x[X][s][j];
                     *reinterpret_cast<bf16x8*>(&sm.k[slot * KLH + 32 * X + 16 * s + 8 * g]) = w;
                 }
-            finish_split(xb, lane, fv, x);
+            finish_split<ST>(xb, lane, fv, x);
 #pragma unroll
             for (int X = 0; X < 2; ++X)
 #pragma unroll
@@ -230,7 +253,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
             f32x16 acc = zero16();
 #pragma unroll
             for (int kb = 0; kb < NW; ++kb) tr_times_acc(sm.vt + 32 * X * VLH, kbase0 + 32 * kb, tok, g, sc[kb], acc);
-            store_dims32(xb, a.ctx, rm, 64, 32 * X, lane, acc, inv_l);
+            store_dims32<ST>(xb, a.ctx, rm, 64, 32 * X, lane, acc, inv_l);
         }
     }
 }
@@ -256,7 +279,7 @@ __device__ __forceinline__ void put_tr(__bf16* __restrict__ tr, int slot, int g,
         for (int j = 0; j < 8; ++j) tr[(16 * s + 8 * g + j) * VLH + slot] = x[s][j];
 }
 
-template <int NW, bool DROP>
+template <int NW, bool DROP, class ST>
 __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
     __shared__ BwdSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -284,19 +307,19 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
         bf16x8 qb[2][2], kb_[2][2], vb[2][2], dob[2][2];
         float D[2];
         {
-            float4 f0[8], f1[8], f2[8];
+            KsrTile<ST> f0, f1, f2;
             float x[2][2][8];
-            fetch_rows(a.qkv, rm, 192, 0, lane, f0);
-            fetch_rows(a.qkv, rm, 192, 64, lane, f1);
-            fetch_rows(a.qkv, rm, 192, 128, lane, f2);
-            finish_split(xb, lane, f0, x); pack_split(x, scale, qb);
-            finish_split(xb, lane, f1, x); pack_split(x, 1.f, kb_);
-            finish_split(xb, lane, f2, x); pack_split(x, 1.f, vb);
-            fetch_rows(a.dctx, rm, 64, 0, lane, f0);
-            fetch_rows(a.ctx, rm, 64, 0, lane, f1);
+            fetch_rows<ST>(a.qkv, rm, 192, 0, lane, f0);
+            fetch_rows<ST>(a.qkv, rm, 192, 64, lane, f1);
+            fetch_rows<ST>(a.qkv, rm, 192, 128, lane, f2);
+            finish_split<ST>(xb, lane, f0, x); pack_split(x, scale, qb);
+            finish_split<ST>(xb, lane, f1, x); pack_split(x, 1.f, kb_);
+            finish_split<ST>(xb, lane, f2, x); pack_split(x, 1.f, vb);
+            fetch_rows<ST>(a.dctx, rm, 64, 0, lane, f0);
+            fetch_rows<ST>(a.ctx, rm, 64, 0, lane, f1);
             float o[2][2][8];
-            finish_split(xb, lane, f0, x); pack_split(x, 1.f, dob);
-            finish_split(xb, lane, f1, o);
+            finish_split<ST>(xb, lane, f0, x); pack_split(x, 1.f, dob);
+            finish_split<ST>(xb, lane, f1, o);
 #pragma unroll
             for (int X = 0; X < 2; ++X) {
                 float d = 0.f;
@@ -366,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                     }
                     tr_times_acc(sm.trA, base0 + 32 * kb, tok, g, dp, dq);
                 }
-                store_dims32(xb, a.dqkv, rm, 192, 32 * X, lane, dq, 1.f);
+                store_dims32<ST>(xb, a.dqkv, rm, 192, 32 * X, lane, dq, 1.f);
             }
             // ---------------- phase B: this lane is a key; LDS holds Q rows, dO rows, Q^T, dO^T, stats ----------------
             __builtin_amdgcn_sched_barrier(0);
@@ -404,8 +427,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                     tr_times_acc(sm.trA, base0 + 32 * qblk, tok, g, sq, dk);
                     tr_times_acc(sm.trB, base0 + 32 * qblk, tok, g, dp, dv);
                 }
-                store_dims32(xb, a.dqkv, rm, 192, 64 + 32 * X, lane, dk, 1.f);
-                store_dims32(xb, a.dqkv, rm, 192, 128 + 32 * X, lane, dv, 1.f);
+                store_dims32<ST>(xb, a.dqkv, rm, 192, 64 + 32 * X, lane, dk, 1.f);
+                store_dims32<ST>(xb, a.dqkv, rm, 192, 128 + 32 * X, lane, dv, 1.f);
             }
         }
     }
@@ -415,11 +438,18 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
 
 int ksr_attn_bf16_fwd_launch(const AttnArgs& a, int nw, unsigned grid, hipStream_t stream) {
     const dim3 g(grid), block(256);
+    const bool bs = ksr_prec() == KSR_BF16S;
+#define KSR_ATTN_FWD(NWV)                                                                               \
+    do {                                                                                                \
+        if (bs) hipLaunchKernelGGL((attn_fwd_bf16_kernel<NWV, __bf16>), g, block, 0, stream, a);        \
+        else hipLaunchKernelGGL((attn_fwd_bf16_kernel<NWV, float>), g, block, 0, stream, a);            \
+    } while (0)
     switch (nw) {
-        case 1: hipLaunchKernelGGL(attn_fwd_bf16_kernel<1>, g, block, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL(attn_fwd_bf16_kernel<2>, g, block, 0, stream, a); break;
-        default: hipLaunchKernelGGL(attn_fwd_bf16_kernel<4>, g, block, 0, stream, a); break;
+        case 1: KSR_ATTN_FWD(1); break;
+        case 2: KSR_ATTN_FWD(2); break;
+        default: KSR_ATTN_FWD(4); break;
     }
+#undef KSR_ATTN_FWD
     KSR_LAUNCH_CHECK("batch_attn_fwd(bf16)");
     return KSR_OK;
 }
@@ -427,10 +457,16 @@ int ksr_attn_bf16_fwd_launch(const AttnArgs& a, int nw, unsigned grid, hipStream
 int ksr_attn_bf16_bwd_launch(const AttnBwdArgs& a, int nw, unsigned grid, hipStream_t stream) {
     const dim3 g(grid), block(256);
     const bool drop = a.p_drop > 0.f;
-#define KSR_ATTN_BWD(NWV)                                                                          \
-    do {                                                                                           \
-        if (drop) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NWV, true>), g, block, 0, stream, a);   \
-        else hipLaunchKernelGGL((attn_bwd_bf16_kernel<NWV, false>), g, block, 0, stream, a);       \
+    const bool bs = ksr_prec() == KSR_BF16S;
+#define KSR_ATTN_BWD(NWV)                                                                                          \
+    do {                                                                                                           \
+        if (bs) {                                                                                                  \
+            if (drop) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NWV, true, __bf16>), g, block, 0, stream, a);       \
+            else hipLaunchKernelGGL((attn_bwd_bf16_kernel<NWV, false, __bf16>), g, block, 0, stream, a);           \
+        } else {                                                                                                   \
+            if (drop) hipLaunchKernelGGL((attn_bwd_bf16_kernel<NWV, true, float>), g, block, 0, stream, a);        \
+            else hipLaunchKernelGGL((attn_bwd_bf16_kernel<NWV, false, float>), g, block, 0, stream, a);            \
+        }                                                                                                          \
     } while (0)
     switch (nw) {
         case 1: KSR_ATTN_BWD(1); break;

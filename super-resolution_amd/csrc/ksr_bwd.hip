@@ -30,7 +30,7 @@ struct BwdArgs {
 
 template <int PREC, int KIN, int BPRO>
 struct __attribute__((aligned(16))) BwdSmem {
-    float frag[2 * (KIN / 2) * 64 / (PREC == KSR_BF16 ? 2 : 1)];
+    float frag[2 * (KIN / 2) * 64 / (PREC != KSR_F32 ? 2 : 1)];
     float dww[BPRO == BPRO_PLAIN ? 4 : 9 * 64];
     float p2w[64];
     float halo[BPRO == BPRO_PLAIN ? 4 : HALO_FLOATS];
@@ -42,6 +42,7 @@ static_assert(4 * KSR_XPOSE_FLOATS <= HALO_FLOATS, "transposers must fit in the 
 template <int PREC, int KIN, int BPRO, int BEPI>
 __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     constexpr int KH = KIN / 2;
+    using ST = typename KsrStore<PREC>::T;
     __shared__ BwdSmem<PREC, KIN, BPRO> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             n0w = (long)b * HW + (long)y * a.W + x0;
             nvalid = (y < a.H) ? ((a.W - x0) < 32 ? a.W - x0 : 32) : 0;
             __syncthreads();
-            ksr_stage_halo(sm.halo, a.halo_src, 64, 0, b, y0, x0, a.H, a.W, tid);
+            ksr_stage_halo<ST>(sm.halo, a.halo_src, 64, 0, b, y0, x0, a.H, a.W, tid);
             __syncthreads();
         } else {
             n = tile * 128 + wv * 32 + tok;
@@ -86,18 +87,18 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         constexpr bool PRE_R = BPRO == BPRO_PLAIN && (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD);
         constexpr bool PRE_E1 = BPRO == BPRO_PLAIN && (BEPI == BEPI_RELUMASK || BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD || BEPI == BEPI_GATE);
         constexpr bool PRE_E2 = BPRO == BPRO_PLAIN && BEPI == BEPI_GATE;
-        float4 pf_r[PRE_R ? 8 : 1], pf_e1[PRE_E1 ? 8 : 1], pf_e2[PRE_E2 ? 8 : 1];
+        KsrTile<ST> pf_r, pf_e1, pf_e2;
         if (BPRO == BPRO_PLAIN) {
-            float4 f[KIN / 64][8];
+            KsrTile<ST> f[KIN / 64];
 #pragma unroll
-            for (int grp = 0; grp < KIN / 64; ++grp) ksr_co_fetch(a.dz, n0w, nvalid, a.dz_ld, 64 * grp, lane, f[grp]);
-            if constexpr (PRE_R) ksr_co_fetch(a.resid, n0w, nvalid, 64, 0, lane, pf_r);
-            if constexpr (PRE_E1) ksr_co_fetch(a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, pf_e1);
-            if constexpr (PRE_E2) ksr_co_fetch(a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, pf_e2);
+            for (int grp = 0; grp < KIN / 64; ++grp) ksr_co_fetch<ST>(a.dz, n0w, nvalid, a.dz_ld, 64 * grp, lane, f[grp]);
+            if constexpr (PRE_R) ksr_co_fetch<ST>(a.resid, n0w, nvalid, 64, 0, lane, pf_r);
+            if constexpr (PRE_E1) ksr_co_fetch<ST>(a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, pf_e1);
+            if constexpr (PRE_E2) ksr_co_fetch<ST>(a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, pf_e2);
 #pragma unroll
             for (int grp = 0; grp < KIN / 64; ++grp) {
                 float t[32];
-                ksr_co_finish(xb, lane, f[grp], t);
+                ksr_co_finish<ST>(xb, lane, f[grp], t);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) dz[32 * grp + i] = t[i];
             }
@@ -109,10 +110,10 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             __syncthreads();       // every wave is done with the halo tile: it now serves as the transposers
             if (BPRO == BPRO_CONVT_G) {
                 float mk[32], t[32];
-                ksr_load32_co(xb, a.mask_src, n0w, nvalid, a.mask_ld, a.mask_c0, lane, mk);
+                ksr_load32_co<ST>(xb, a.mask_src, n0w, nvalid, a.mask_ld, a.mask_c0, lane, mk);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) g[i] = mk[i] > 0.f ? g[i] : 0.f;
-                ksr_load32_co(xb, a.dz, n0w, nvalid, a.dz_ld, 0, lane, t);
+                ksr_load32_co<ST>(xb, a.dz, n0w, nvalid, a.dz_ld, 0, lane, t);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) { dz[i] = t[i]; dz[32 + i] = g[i]; }
             } else {
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             float t[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) t[i] = dz[(BPRO == BPRO_CONVT_G ? 32 : 0) + i];
-            ksr_store32_co(xb, a.dz_store, n0w, nvalid, a.dz_store_ld, a.dz_store_c0, lane, t);
+            ksr_store32_co<ST>(xb, a.dz_store, n0w, nvalid, a.dz_store_ld, a.dz_store_c0, lane, t);
             __builtin_amdgcn_sched_barrier(0);
         }
         float dA[32];
@@ -140,37 +141,37 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
 
         if (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD) {
             float r[32];
-            if constexpr (PRE_R) ksr_co_finish(xb, lane, pf_r, r);
-            else ksr_load32_co(xb, a.resid, n0w, nvalid, 64, 0, lane, r);
+            if constexpr (PRE_R) ksr_co_finish<ST>(xb, lane, pf_r, r);
+            else ksr_load32_co<ST>(xb, a.resid, n0w, nvalid, 64, 0, lane, r);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] += r[i];
         }
         if (BEPI == BEPI_RELUMASK) {
             float e[32];
-            if constexpr (PRE_E1) ksr_co_finish(xb, lane, pf_e1, e);
-            else ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
+            if constexpr (PRE_E1) ksr_co_finish<ST>(xb, lane, pf_e1, e);
+            else ksr_load32_co<ST>(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] = e[i] > 0.f ? dA[i] : 0.f;
         }
         if (BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD) {
             float e[32];
-            if constexpr (PRE_E1) ksr_co_finish(xb, lane, pf_e1, e);
-            else ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
+            if constexpr (PRE_E1) ksr_co_finish<ST>(xb, lane, pf_e1, e);
+            else ksr_load32_co<ST>(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] = dA[i] * e[i] * (1.f - e[i]);
         }
         if (BEPI == BEPI_GATE) {
             float gte[32], val[32], o2[32];
-            if constexpr (PRE_E1) ksr_co_finish(xb, lane, pf_e1, gte);
-            else ksr_load32_co(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, gte);
-            if constexpr (PRE_E2) ksr_co_finish(xb, lane, pf_e2, val);
-            else ksr_load32_co(xb, a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, val);
+            if constexpr (PRE_E1) ksr_co_finish<ST>(xb, lane, pf_e1, gte);
+            else ksr_load32_co<ST>(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, gte);
+            if constexpr (PRE_E2) ksr_co_finish<ST>(xb, lane, pf_e2, val);
+            else ksr_load32_co<ST>(xb, a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, val);
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 o2[i] = dA[i] * val[i];
                 dA[i] = val[i] > 0.f ? dA[i] * gte[i] : 0.f;
             }
-            ksr_store32_co(xb, a.out2, n0w, nvalid, 64, 0, lane, o2);
+            ksr_store32_co<ST>(xb, a.out2, n0w, nvalid, 64, 0, lane, o2);
         }
         if (BEPI == BEPI_STEM) {
             float s = 0.f;
@@ -179,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             s = ksr_pair_sum(s);
             if (live && h == 0) a.dpre[n] = a.v[n] > 0.f ? s : 0.f;
         }
-        ksr_store32_co(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
+        ksr_store32_co<ST>(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
     }
 }
 
@@ -196,7 +197,10 @@ int launch_dgrad_p(const BwdArgs& a, hipStream_t s) {
 
 template <int KIN, int BPRO, int BEPI>
 int launch_dgrad(const BwdArgs& a, hipStream_t s) {
-    return ksr_prec() == KSR_BF16 ? launch_dgrad_p<KSR_BF16, KIN, BPRO, BEPI>(a, s) : launch_dgrad_p<KSR_F32, KIN, BPRO, BEPI>(a, s);
+#define KSR_CALL(P) return launch_dgrad_p<P, KIN, BPRO, BEPI>(a, s)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
+    return KSR_OK;
 }
 
 int dims_ok(int B, int H, int W, const char* who) {

@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
         const long n = live ? (long)b * HW + (long)y * a.W + x : 0;
         for (int gi = 0; gi < a.groups; ++gi) {
             __syncthreads();
-            ksr_stage_halo(halo, a.in, a.ld, 64 * gi, b, y0, x0, a.H, a.W, tid);
+            ksr_stage_halo<float>(halo, a.in, a.ld, 64 * gi, b, y0, x0, a.H, a.W, tid);
             __syncthreads();
             float g[32];
 #pragma unroll
@@ -123,6 +123,7 @@ int launch_apply_p(const ApArgs& a, int B, hipStream_t s) {
 
 template <int KH, int NB, bool TRANS>
 int launch_apply(const ApArgs& a, int B, hipStream_t s) {
+    KSR_UNSUPPORTED(ksr_prec() == KSR_BF16S, "chan_apply: the channel-attention kernels have no bf16-storage variant");
     return ksr_prec() == KSR_BF16 ? launch_apply_p<KSR_BF16, KH, NB, TRANS>(a, B, s) : launch_apply_p<KSR_F32, KH, NB, TRANS>(a, B, s);
 }
 

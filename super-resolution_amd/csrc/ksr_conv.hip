@@ -30,13 +30,14 @@ struct ConvArgs {
     const float* p2b;
     float* out;           // NHWC [N, NOUT]
     float* save;          // training: STEM v [N]; DWRELU operand [N,64]; GATE gate G [N,64]; else null
+    float* out32;         // optional fp32 copy of the output (whatever the storage mode), else null
     int B, H, W;
 };
 
 
 template <int PREC, int PRO, int NB>
 struct __attribute__((aligned(16))) ConvSmem {
-    float frag[NB * 32 * 64 / (PREC == KSR_BF16 ? 2 : 1)];
+    float frag[NB * 32 * 64 / (PREC != KSR_F32 ? 2 : 1)];
     float biasfrag[NB * 32];
     float dww[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? 9 * 64 : 16];
     float dwb[64];
@@ -59,6 +60,7 @@ __device__ __forceinline__ float apply_act(float v) {
 template <int PREC, int PRO, int NOUT, int ACT>
 __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
     constexpr int NB = NOUT / 32;   // 16-register blocks per lane half (NOUT/2 outputs per half)
+    using ST = typename KsrStore<PREC>::T;
     __shared__ ConvSmem<PREC, PRO, NB> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             // ---- stage the halo tile (rows y0-1..y0+4, cols x0-1..x0+32, 64 channels) ----
             const int c0 = (PRO == PRO_GATE) ? 64 : 0;
             __syncthreads();   // previous tile's readers are done
-            ksr_stage_halo(sm.halo, a.in, a.in_ld, c0, b, y0, x0, a.H, a.W, tid);
+            ksr_stage_halo<ST>(sm.halo, a.in, a.in_ld, c0, b, y0, x0, a.H, a.W, tid);
             __syncthreads();
         } else {
             n = tile * 128 + wv * 32 + tok;
@@ -113,7 +115,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
         else nvalid = (N - n0w) < 32 ? (int)(N - n0w > 0 ? N - n0w : 0) : 32;
         float op[32];
         if (PRO == PRO_PLAIN) {
-            ksr_load32_co(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, op);
+            ksr_load32_co<ST>(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, op);
         } else if (PRO == PRO_STEM) {
             const float w1 = a.p1[0], b1 = a.p1b[0];
             const float* Y = a.in + (long)b * a.img_bstride;
@@ -141,11 +143,11 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             if (PRO == PRO_DWRELU) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) op[i] = g[i] > 0.f ? g[i] : 0.f;
-                if (a.save) ksr_store32_co(xb, a.save, n0w, nvalid, 64, 0, lane, op);
+                if (a.save) ksr_store32_co<ST>(xb, a.save, n0w, nvalid, 64, 0, lane, op);
             } else {
-                if (a.save) ksr_store32_co(xb, a.save, n0w, nvalid, 64, 0, lane, g);
+                if (a.save) ksr_store32_co<ST>(xb, a.save, n0w, nvalid, 64, 0, lane, g);
                 float val[32];
-                ksr_load32_co(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, val);
+                ksr_load32_co<ST>(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, val);
 #pragma unroll
                 for (int i = 0; i < 32; ++i) op[i] = val[i] * g[i];
             }
@@ -162,7 +164,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
                 o[q] = apply_act<ACT>(acc[2 * grp][q]);
                 o[16 + q] = apply_act<ACT>(acc[2 * grp + 1][q]);
             }
-            ksr_store32_co(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            ksr_store32_co<ST>(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            if (a.out32) ksr_store32_co<float>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
         }
     }
 }
@@ -181,7 +184,10 @@ int launch_conv_p(const ConvArgs& a, hipStream_t s) {
 
 template <int PRO, int NOUT, int ACT>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
-    return ksr_prec() == KSR_BF16 ? launch_conv_p<KSR_BF16, PRO, NOUT, ACT>(a, s) : launch_conv_p<KSR_F32, PRO, NOUT, ACT>(a, s);
+#define KSR_CALL(P) return launch_conv_p<P, PRO, NOUT, ACT>(a, s)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
+    return KSR_OK;
 }
 
 int check_dims(int B, int H, int W, const char* who) {
@@ -231,12 +237,12 @@ extern "C" int ksr_dwrelu_pw_fwd(const float* in, const float* dw_w, const float
 }
 
 extern "C" int ksr_gate_pw_fwd(const float* t_in, const float* gate_w, const float* gate_b, const float* w,
-                               const float* bias, float* out, float* save_gate, int B, int H, int W,
+                               const float* bias, float* out, float* save_gate, float* out_f32_copy, int B, int H, int W,
                                hipStream_t stream) {
     KSR_CHECK_ARG(t_in && gate_w && gate_b && w && bias && out, "gate_pw_fwd: null pointer");
     if (int rc = check_dims(B, H, W, "gate_pw_fwd")) return rc;
     ConvArgs a{};
     a.in = t_in; a.in_ld = 128; a.dw_w = gate_w; a.dw_b = gate_b; a.wt = w; a.bias = bias; a.out = out;
-    a.save = save_gate; a.B = B; a.H = H; a.W = W;
+    a.save = save_gate; a.out32 = out_f32_copy; a.B = B; a.H = H; a.W = W;
     return launch_conv<PRO_GATE, 64, ACT_SIGMOID>(a, stream);
 }

@@ -9,19 +9,36 @@
 constexpr int HALO_W = 34, HALO_H = 6, HALO_LD = 68;   // 4 x 32 pixel tile + 1 pixel rim; 64 ch + 4 pad
 constexpr int HALO_FLOATS = HALO_H * HALO_W * HALO_LD;
 
-// Load channels [c0, c0+64) of the (6 x 34) pixel window whose interior starts at (y0, x0) of image b.
-// src is NHWC with `ld` channels per pixel; pixels outside the image are zero.  All 256 threads call.
-__device__ __forceinline__ void ksr_stage_halo(float* __restrict__ halo, const float* __restrict__ src, int ld,
+// Load channels [c0, c0+64) of the (6 x 34) pixel window whose interior starts at (y0, x0) of image b into an
+// fp32 LDS tile.  src is NHWC with `ld` channels per pixel, stored as T; pixels outside the image are zero.
+// All 256 threads call.
+template <class T>
+__device__ __forceinline__ void ksr_stage_halo(float* __restrict__ halo, const void* __restrict__ src, int ld,
                                                int c0, int b, int y0, int x0, int H, int W, int tid) {
     const long HW = (long)H * W;
-    for (int c = tid; c < HALO_H * HALO_W * 16; c += 256) {
-        const int q = c & 15, pix = c >> 4;
-        const int hx = pix % HALO_W, hy = pix / HALO_W;
-        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-            v = *reinterpret_cast<const float4*>(src + ((long)b * HW + (long)gy * W + gx) * ld + c0 + 4 * q);
-        *reinterpret_cast<float4*>(&halo[pix * HALO_LD + 4 * q]) = v;
+    if constexpr (sizeof(T) == 4) {
+        for (int c = tid; c < HALO_H * HALO_W * 16; c += 256) {
+            const int q = c & 15, pix = c >> 4;
+            const int hx = pix % HALO_W, hy = pix / HALO_W;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + ((long)b * HW + (long)gy * W + gx) * ld + c0 + 4 * q);
+            *reinterpret_cast<float4*>(&halo[pix * HALO_LD + 4 * q]) = v;
+        }
+    } else {
+        for (int c = tid; c < HALO_H * HALO_W * 8; c += 256) {
+            const int q = c & 7, pix = c >> 3;
+            const int hx = pix % HALO_W, hy = pix / HALO_W;
+            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            uint4 w = make_uint4(0u, 0u, 0u, 0u);
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
+                w = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(src) + ((long)b * HW + (long)gy * W + gx) * ld + c0 + 8 * q);
+            float x[8];
+            ksr_unpack8(w, x);
+            *reinterpret_cast<float4*>(&halo[pix * HALO_LD + 8 * q]) = make_float4(x[0], x[1], x[2], x[3]);
+            *reinterpret_cast<float4*>(&halo[pix * HALO_LD + 8 * q + 4]) = make_float4(x[4], x[5], x[6], x[7]);
+        }
     }
 }
 

@@ -66,6 +66,7 @@ template <int PREC, int R, int KC, int KORD>
 __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKnots kn) {
     using C = FeedCfg<R, KC>;
     constexpr int NB = C::NB;
+    using ST = typename KsrStore<PREC>::T;
     __shared__ FeedSmem<NB> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -84,7 +85,7 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
         const int y = hw / a.W, x = hw % a.W;
 
         float f[32];
-        if (live) ksr_load32(a.feat + n * 64 + 32 * h, f);
+        if (live) ksr_loadn<ST, 32>(a.feat, n * 64 + 32 * h, f);
         else {
 #pragma unroll
             for (int i = 0; i < 32; ++i) f[i] = 0.f;
@@ -136,8 +137,9 @@ int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
     const long N = (long)a.B * a.H * a.W;
     const long ntiles = (N + 127) / 128;
     const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);
-    if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((feed_kan_fwd_kernel<KSR_BF16, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
-    else hipLaunchKernelGGL((feed_kan_fwd_kernel<KSR_F32, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
+#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_fwd_kernel<P, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
     KSR_LAUNCH_CHECK("feed_kan_fwd");
     return KSR_OK;
 }
@@ -154,6 +156,7 @@ template <int PREC, int R, int KC, int KORD>
 __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKnots kn) {
     using C = FeedCfg<R, KC>;
     constexpr int NB = C::NB, KH = NB * 16;
+    using ST = typename KsrStore<PREC>::T;
     __shared__ FeedBwdSmem<NB> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -211,18 +214,14 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
                 dp[e] = 0.f;
             }
         }
-        if (live) {
-            float4* gp4 = reinterpret_cast<float4*>(a.gparam + (n * 2 + h) * KH);
-#pragma unroll
-            for (int q = 0; q < KH / 4; ++q) gp4[q] = make_float4(dp[4 * q], dp[4 * q + 1], dp[4 * q + 2], dp[4 * q + 3]);
-        }
+        if (live) ksr_storen<ST, KH>(a.gparam, (n * 2 + h) * KH, dp);
         f32x16 acc[2];
         ksr_wave_gemm<PREC, KH, 2>(sm.frag, nullptr, dp, acc, lane);
         if (live) {
             float df[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { df[i] = acc[0][i]; df[16 + i] = acc[1][i]; }
-            ksr_store32(a.gfeat + n * 64 + 32 * h, df);
+            ksr_storen<ST, 32>(a.gfeat, n * 64 + 32 * h, df);
         }
     }
 }
@@ -232,8 +231,9 @@ int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
     const long N = (long)a.B * a.H * a.W;
     const long ntiles = (N + 127) / 128;
     const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
-    if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((feed_kan_bwd_kernel<KSR_BF16, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
-    else hipLaunchKernelGGL((feed_kan_bwd_kernel<KSR_F32, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn);
+#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_bwd_kernel<P, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
     KSR_LAUNCH_CHECK("feed_kan_bwd");
     return KSR_OK;
 }

@@ -23,9 +23,18 @@
 
 // MFMA operand precision of ksr_wave_gemm: exact fp32 (v_mfma_f32_32x32x2_f32) or bf16 operands with fp32
 // accumulation (v_mfma_f32_32x32x16_bf16, 16x the rate).  Storage in HBM and all other arithmetic stay fp32.
-enum { KSR_F32 = 0, KSR_BF16 = 1 };
+enum { KSR_F32 = 0, KSR_BF16 = 1, KSR_BF16S = 2 };   // KSR_BF16S: bf16 MFMA operands AND bf16 activation storage
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 int ksr_prec();   // process-wide setting (ksr_set_precision)
+// Runs CALL(PREC) for the current mode; CALL is a macro taking the mode constant.
+#define KSR_DISPATCH_PREC(CALL)                                   \
+    do {                                                          \
+        switch (ksr_prec()) {                                     \
+            case KSR_BF16S: CALL(KSR_BF16S); break;               \
+            case KSR_BF16: CALL(KSR_BF16); break;                 \
+            default: CALL(KSR_F32); break;                        \
+        }                                                         \
+    } while (0)
 
 // D row of a 32x32 MFMA block held by (lane half h, register q): (q&3) + 8*(q>>2) + 4*h.
 // Inverse: for A-operand row rho, the result lands on half (rho>>2)&1, register (rho&3)+4*(rho>>3).
@@ -74,7 +83,7 @@ __device__ __forceinline__ void ksr_stage_weights(float* __restrict__ frag, floa
     __bf16* frag16 = reinterpret_cast<__bf16*>(frag);
     for (int idx = tid; idx < total; idx += nthreads) {
         // fp32: idx = ((blk*(KH/4) + s/4)*64 + lane)*4 + s%4 ; bf16: ((blk*(KH/8) + s/8)*64 + lane)*8 + s%8
-        constexpr int G = (PREC == KSR_BF16) ? 8 : 4;
+        constexpr int G = (PREC != KSR_F32) ? 8 : 4;
         const int s_lo = idx % G;
         const int lane = (idx / G) & 63;
         const int rest = idx / (G * 64);
@@ -85,7 +94,7 @@ __device__ __forceinline__ void ksr_stage_weights(float* __restrict__ frag, floa
         const int i = im(hh, s);
         float v = 0.f;
         if (o >= 0 && i >= 0) v = TRANS ? W[(long)i * ldw + o] : W[(long)o * ldw + i];
-        if (PREC == KSR_BF16) frag16[idx] = (__bf16)v;
+        if (PREC != KSR_F32) frag16[idx] = (__bf16)v;
         else frag[idx] = v;
     }
     if (biasfrag) {
@@ -117,7 +126,7 @@ __device__ __forceinline__ void ksr_wave_gemm(const float* __restrict__ frag, co
             for (int q = 0; q < 16; ++q) acc[blk][q] = 0.f;
         }
     }
-    if (PREC == KSR_BF16) {
+    if (PREC != KSR_F32) {
         // activations -> bf16 once; one 16-byte LDS read (8 bf16 of weights) per MFMA
         bf16x8 xb[KH / 8];
 #pragma unroll
@@ -162,42 +171,68 @@ __device__ __forceinline__ void ksr_wave_gemm(const float* __restrict__ frag, co
     }
 }
 
-// ---- HL loads / stores of one token's half (32 channels, 128 contiguous bytes) ----------------
-__device__ __forceinline__ void ksr_load32(const float* __restrict__ p, float* __restrict__ x) {
-    const float4* p4 = reinterpret_cast<const float4*>(p);
+// ---- storage type of the [N, C] activation / gradient tensors exchanged between kernels -------------
+// fp32 in modes KSR_F32 and KSR_BF16, bf16 in mode KSR_BF16S.  The C ABI keeps `float*` parameters for these
+// tensors in every mode; the kernels reinterpret them according to their PREC template argument.
+template <int PREC> struct KsrStore { typedef float T; };
+template <> struct KsrStore<KSR_BF16S> { typedef __bf16 T; };
+
+__device__ __forceinline__ void ksr_unpack8(const uint4& w, float* __restrict__ x) {   // 8 bf16 -> 8 floats
+    x[0] = __uint_as_float(w.x << 16); x[1] = __uint_as_float(w.x & 0xffff0000u);
+    x[2] = __uint_as_float(w.y << 16); x[3] = __uint_as_float(w.y & 0xffff0000u);
+    x[4] = __uint_as_float(w.z << 16); x[5] = __uint_as_float(w.z & 0xffff0000u);
+    x[6] = __uint_as_float(w.w << 16); x[7] = __uint_as_float(w.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 ksr_pack8(const float* __restrict__ x) {               // 8 floats -> 8 bf16 (RNE)
+    bf16x8 v;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float4 v = p4[q];
-        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)x[j];
+    return *reinterpret_cast<const uint4*>(&v);
+}
+
+// ---- lane-private loads / stores of N contiguous channels (N = 32: one token's half) --------------
+template <class T, int N>
+__device__ __forceinline__ void ksr_loadn(const void* __restrict__ base, long off, float* __restrict__ x) {
+    if constexpr (sizeof(T) == 4) {
+        const float4* p4 = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) {
+            const float4 v = p4[q];
+            x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        }
+    } else {
+        const uint4* p4 = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + off);
+#pragma unroll
+        for (int q = 0; q < N / 8; ++q) ksr_unpack8(p4[q], x + 8 * q);
     }
 }
-__device__ __forceinline__ void ksr_store32(float* __restrict__ p, const float* __restrict__ x) {
-    float4* p4 = reinterpret_cast<float4*>(p);
+template <class T, int N>
+__device__ __forceinline__ void ksr_storen(void* __restrict__ base, long off, const float* __restrict__ x) {
+    if constexpr (sizeof(T) == 4) {
+        float4* p4 = reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + off);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) p4[q] = make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
-}
-__device__ __forceinline__ void ksr_load16(const float* __restrict__ p, float* __restrict__ x) {
-    const float4* p4 = reinterpret_cast<const float4*>(p);
+        for (int q = 0; q < N / 4; ++q) p4[q] = make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    } else {
+        uint4* p4 = reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + off);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 v = p4[q];
-        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+        for (int q = 0; q < N / 8; ++q) p4[q] = ksr_pack8(x + 8 * q);
     }
 }
-__device__ __forceinline__ void ksr_store16(float* __restrict__ p, const float* __restrict__ x) {
-    float4* p4 = reinterpret_cast<float4*>(p);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) p4[q] = make_float4(x[4 * q + 0], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
-}
+// fp32 shorthands (pointer already at the lane's first element)
+__device__ __forceinline__ void ksr_load32(const float* __restrict__ p, float* __restrict__ x) { ksr_loadn<float, 32>(p, 0, x); }
+__device__ __forceinline__ void ksr_store32(float* __restrict__ p, const float* __restrict__ x) { ksr_storen<float, 32>(p, 0, x); }
+__device__ __forceinline__ void ksr_load16(const float* __restrict__ p, float* __restrict__ x) { ksr_loadn<float, 16>(p, 0, x); }
+__device__ __forceinline__ void ksr_store16(float* __restrict__ p, const float* __restrict__ x) { ksr_storen<float, 16>(p, 0, x); }
 
 // ---- coalesced HL loads / stores through a wave-private LDS transposer --------------------------
 // A lane moving its own 128 contiguous bytes with eight 16-byte accesses makes every access of the wave
 // touch 64 different cache lines; such streams top out near 3.5 TB/s on MI355X where lane-linear 16-byte
 // accesses reach 5+ TB/s.  These helpers move a wave's tile (32 consecutive rows x 64 channels) with
-// lane-linear accesses (16 lanes cover one row's 256 bytes) and transpose to / from the half layout in a
-// wave-private LDS buffer of KSR_XPOSE_FLOATS floats (rows padded to 68 floats: conflict-free both ways).
-// Only the owning wave touches its buffer and LDS operations of one wave complete in order, so no
-// workgroup barrier is needed; the compiler barriers keep the phases in program order.
+// lane-linear accesses (16 lanes cover one fp32 row's 256 bytes, 8 lanes a bf16 row's 128 bytes) and
+// transpose to / from the half layout in a wave-private fp32 LDS buffer of KSR_XPOSE_FLOATS floats (rows
+// padded to 68 floats: conflict-free both ways).  Only the owning wave touches its buffer and LDS
+// operations of one wave complete in order, so no workgroup barrier is needed; the compiler barriers keep
+// the phases in program order.
 constexpr int KSR_XPOSE_LD = 68;
 constexpr int KSR_XPOSE_FLOATS = 32 * KSR_XPOSE_LD;
 
@@ -207,89 +242,166 @@ __device__ __forceinline__ void ksr_wave_fence() {
     asm volatile("" ::: "memory");
 }
 
-// Two-phase form of ksr_load32_co: ksr_co_fetch only issues the global loads (several tiles can be in
-// flight), ksr_co_finish transposes one fetched tile into the half layout.
-__device__ __forceinline__ void ksr_co_fetch(const float* __restrict__ base, long n0, int nvalid, int ld, int c0,
-                                             int lane, float4 (&v)[8]) {
-    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+// registers of one fetched 32 x 64 tile
+template <class T> struct KsrTile { float4 v[8]; };
+template <> struct KsrTile<__bf16> { uint4 v[4]; };
+
+// Phase 1: issue the global loads of rows [n0, n0+32) (nvalid real rows, the rest read as 0), channels
+// [c0, c0+64) of a tensor with ld elements per row.  Several tiles can be in flight.
+template <class T>
+__device__ __forceinline__ void ksr_co_fetch(const void* __restrict__ base, long n0, int nvalid, int ld, int c0, int lane,
+                                             KsrTile<T>& t) {
+    if constexpr (sizeof(T) == 4) {
+        const int r4 = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + r4;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nvalid) v[i] = *reinterpret_cast<const float4*>(base + (n0 + row) * ld + c0 + c4);
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + r4;
+            t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nvalid) t.v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * ld + c0 + c4);
+        }
+    } else {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + r8;
+            t.v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < nvalid) t.v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * ld + c0 + c8);
+        }
     }
 }
-__device__ __forceinline__ void ksr_co_finish(float* __restrict__ xb, int lane, const float4 (&v)[8], float (&x)[32]) {
-    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
-    ksr_wave_fence();
+// fetched tile -> fp32 LDS tile [32][KSR_XPOSE_LD] (caller fences)
+template <class T>
+__device__ __forceinline__ void ksr_co_to_lds(float* __restrict__ xb, int lane, const KsrTile<T>& t) {
+    if constexpr (sizeof(T) == 4) {
+        const int r4 = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(xb + (4 * i + r4) * KSR_XPOSE_LD + c4) = v[i];
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(xb + (4 * i + r4) * KSR_XPOSE_LD + c4) = t.v[i];
+    } else {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float x[8];
+            ksr_unpack8(t.v[i], x);
+            float* d = xb + (8 * i + r8) * KSR_XPOSE_LD + c8;
+            *reinterpret_cast<float4*>(d) = make_float4(x[0], x[1], x[2], x[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(x[4], x[5], x[6], x[7]);
+        }
+    }
+}
+// Phase 2: transpose one fetched tile into the half layout (this lane: row lane&31, channels 32*(lane>>5)..+31).
+template <class T>
+__device__ __forceinline__ void ksr_co_finish(float* __restrict__ xb, int lane, const KsrTile<T>& t, float (&x)[32]) {
+    ksr_wave_fence();
+    ksr_co_to_lds<T>(xb, lane, t);
     ksr_wave_fence();
     const float* rp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
-        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+        const float4 v = *reinterpret_cast<const float4*>(rp + 4 * q);
+        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
 }
-
-// x <- rows [n0, n0+32) (nvalid real rows, the rest read as 0), channels [c0, c0+64) of a tensor with ld floats
-// per row, in half layout (this lane: row n0 + (lane&31), channels 32*(lane>>5) ..+31).
-__device__ __forceinline__ void ksr_load32_co(float* __restrict__ xb, const float* __restrict__ base, long n0,
-                                              int nvalid, int ld, int c0, int lane, float (&x)[32]) {
-    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
-    float4 v[8];
+template <class T>
+__device__ __forceinline__ void ksr_load32_co(float* __restrict__ xb, const void* __restrict__ base, long n0, int nvalid,
+                                              int ld, int c0, int lane, float (&x)[32]) {
+    KsrTile<T> t;
+    ksr_co_fetch<T>(base, n0, nvalid, ld, c0, lane, t);
+    ksr_co_finish<T>(xb, lane, t, x);
+}
+// fp32 LDS tile -> rows [n0, n0 + nvalid) of the tensor (caller has written the tile and fenced)
+template <class T>
+__device__ __forceinline__ void ksr_co_from_lds(const float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
+                                                int ld, int c0, int lane) {
+    if constexpr (sizeof(T) == 4) {
+        const int r4 = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + r4;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nvalid) v[i] = *reinterpret_cast<const float4*>(base + (n0 + row) * ld + c0 + c4);
-    }
-    ksr_wave_fence();
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + r4;
+            const float4 v = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE_LD + c4);
+            if (row < nvalid) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4) = v;
+        }
+    } else {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(xb + (4 * i + r4) * KSR_XPOSE_LD + c4) = v[i];
-    ksr_wave_fence();
-    const float* rp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
-        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + r8;
+            const float* sp = xb + row * KSR_XPOSE_LD + c8;
+            const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (row < nvalid) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8) = ksr_pack8(x);
+        }
     }
 }
-
-// The reverse: x (half layout) -> rows [n0, n0 + nvalid).
-__device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, float* __restrict__ base, long n0, int nvalid,
+// The reverse of ksr_load32_co: x (half layout) -> rows [n0, n0 + nvalid).
+template <class T>
+__device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                int ld, int c0, int lane, const float (&x)[32]) {
     float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
     ksr_wave_fence();
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     ksr_wave_fence();
-    const int r4 = lane >> 4, c4 = (lane & 15) * 4;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 4 * i + r4;
-        const float4 t = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE_LD + c4);
-        if (row < nvalid) *reinterpret_cast<float4*>(base + (n0 + row) * ld + c0 + c4) = t;
-    }
+    ksr_co_from_lds<T>(xb, base, n0, nvalid, ld, c0, lane);
 }
 
 // 32-channel rows (lane half h holds channels 16h .. 16h+15): same scheme with rows padded to 36 floats.
 constexpr int KSR_XPOSE16_LD = 36;
-__device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const float* __restrict__ base, long n0,
-                                              int nvalid, int lane, float (&x)[16]) {
-    float4 v[4];
+// fp32 LDS tile [32][36] <-> rows of a tensor with ld elements per row, channels c0 .. c0+31
+template <class T>
+__device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
+                                                  int ld, int c0, int lane) {
+    if constexpr (sizeof(T) == 4) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
-        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < nvalid) v[i] = *reinterpret_cast<const float4*>(base + (n0 + row) * 32 + c4);
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE16_LD + c4);
+            if (row < nvalid) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4) = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 2, c8 = (idx & 3) * 8;
+            const float* sp = xb + row * KSR_XPOSE16_LD + c8;
+            const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
+            const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (row < nvalid) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8) = ksr_pack8(x);
+        }
     }
+}
+template <class T>
+__device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const void* __restrict__ base, long n0, int nvalid,
+                                              int lane, float (&x)[16]) {
     ksr_wave_fence();
+    if constexpr (sizeof(T) == 4) {
+        float4 v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
-        *reinterpret_cast<float4*>(xb + row * KSR_XPOSE16_LD + c4) = v[i];
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nvalid) v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * 32 + c4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            *reinterpret_cast<float4*>(xb + row * KSR_XPOSE16_LD + c4) = v[i];
+        }
+    } else {
+        uint4 v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 2, c8 = (idx & 3) * 8;
+            v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < nvalid) v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * 32 + c8);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 2, c8 = (idx & 3) * 8;
+            float f[8];
+            ksr_unpack8(v[i], f);
+            float* d = xb + row * KSR_XPOSE16_LD + c8;
+            *reinterpret_cast<float4*>(d) = make_float4(f[0], f[1], f[2], f[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
+        }
     }
     ksr_wave_fence();
     const float* rp = xb + (lane & 31) * KSR_XPOSE16_LD + 16 * (lane >> 5);
@@ -299,19 +411,15 @@ __device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const floa
         x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
     }
 }
-__device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, float* __restrict__ base, long n0, int nvalid,
+template <class T>
+__device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                int lane, const float (&x)[16]) {
     float* wp = xb + (lane & 31) * KSR_XPOSE16_LD + 16 * (lane >> 5);
     ksr_wave_fence();
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     ksr_wave_fence();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
-        const float4 t = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE16_LD + c4);
-        if (row < nvalid) *reinterpret_cast<float4*>(base + (n0 + row) * 32 + c4) = t;
-    }
+    ksr_co16_from_lds<T>(xb, base, n0, nvalid, 32, 0, lane);
 }
 
 // Sum of v over the two lanes that share a token (lanes l and l^32).

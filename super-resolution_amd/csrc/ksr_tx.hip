@@ -27,6 +27,7 @@ struct TxArgs {
     // s1 [N,64], hmid [N,32], xhat2 [N,64], rstd2 [N]
     float *sv_qkv, *sv_ctx, *sv_xhat1, *sv_rstd1, *sv_s1, *sv_hmid, *sv_xhat2, *sv_rstd2;
     float *sv_xhatf, *sv_rstdf;   // final LayerNorm (only with nf_w)
+    const float* in32;            // optional fp32 copy of `in` (read instead of it, whatever the storage mode)
     int S, HW;
     float eps;
     float p_drop;                 // 0 in eval mode
@@ -63,6 +64,7 @@ __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* 
 // exchange buffer in LDS (4x the occupancy).
 template <int PREC, bool TRAIN, bool POST>
 __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs a) {
+    using ST = typename KsrStore<PREC>::T;
     __shared__ TxSmem<POST> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -98,13 +100,18 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
         const int nvalid = POST ? (((long)S * HW - n0w) < 32 ? (int)((long)S * HW - n0w > 0 ? (long)S * HW - n0w : 0) : 32) : 0;
         float* xb = sm.xpose + (POST ? wv * KSR_XPOSE_FLOATS : 0);
         auto st32 = [&](float* base, const float (&v)[32]) {
-            if (POST) ksr_store32_co(xb, base, n0w, nvalid, 64, 0, lane, v);
-            else if (live) ksr_store32(base + n * 64 + 32 * h, v);
+            if (POST) ksr_store32_co<ST>(xb, base, n0w, nvalid, 64, 0, lane, v);
+            else if (live) ksr_storen<ST, 32>(base, n * 64 + 32 * h, v);
         };
 
         float s0[32];
-        if (POST) ksr_load32_co(xb, a.in, n0w, nvalid, 64, 0, lane, s0);
-        else if (live) ksr_load32(a.in + n * 64 + 32 * h, s0);
+        if (POST) {
+            if (a.in32) ksr_load32_co<float>(xb, a.in32, n0w, nvalid, 64, 0, lane, s0);
+            else ksr_load32_co<ST>(xb, a.in, n0w, nvalid, 64, 0, lane, s0);
+        } else if (live) {
+            if (a.in32) ksr_loadn<float, 32>(a.in32, n * 64 + 32 * h, s0);
+            else ksr_loadn<ST, 32>(a.in, n * 64 + 32 * h, s0);
+        }
         else {
 #pragma unroll
             for (int i = 0; i < 32; ++i) s0[i] = 0.f;
@@ -112,7 +119,7 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
 
         float ctx[32];
         if (POST) {
-            ksr_load32_co(xb, a.ctx_in, n0w, nvalid, 64, 0, lane, ctx);
+            ksr_load32_co<ST>(xb, a.ctx_in, n0w, nvalid, 64, 0, lane, ctx);
         } else {
         // ---- QKV projection -------------------------------------------------------------
         float q[32];
@@ -127,9 +134,9 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
                 kvr[32 + i] = acc[4][i]; kvr[48 + i] = acc[5][i];
             }
             if (TRAIN && a.sv_qkv && live) {
-                ksr_store32(a.sv_qkv + n * 192 + 32 * h, q);
-                ksr_store32(a.sv_qkv + n * 192 + 64 + 32 * h, kvr);
-                ksr_store32(a.sv_qkv + n * 192 + 128 + 32 * h, kvr + 32);
+                ksr_storen<ST, 32>(a.sv_qkv, n * 192 + 32 * h, q);
+                ksr_storen<ST, 32>(a.sv_qkv, n * 192 + 64 + 32 * h, kvr);
+                ksr_storen<ST, 32>(a.sv_qkv, n * 192 + 128 + 32 * h, kvr + 32);
             }
             __syncthreads();                          // previous tile's K/V readers are done
             float* dst = &sm.kv[slot * KV_LD + 64 * h];
@@ -176,7 +183,7 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
             const float inv_l = 1.f / l;
 #pragma unroll
             for (int i = 0; i < 32; ++i) ctx[i] *= inv_l;
-            if (TRAIN && a.sv_ctx && live) ksr_store32(a.sv_ctx + n * 64 + 32 * h, ctx);
+            if (TRAIN && a.sv_ctx && live) ksr_storen<ST, 32>(a.sv_ctx, n * 64 + 32 * h, ctx);
         }
 
         }
@@ -218,8 +225,8 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
                     hm[i] = ksr_uniform(a.seed, 2u, (unsigned long long)n * 32 + 16 * h + i) < keep ? hm[i] * inv_keep : 0.f;
             }
             if (TRAIN && a.sv_hmid) {
-                if (POST) ksr_store16_co(xb, a.sv_hmid, n0w, nvalid, lane, hm);
-                else if (live) ksr_store16(a.sv_hmid + n * 32 + 16 * h, hm);
+                if (POST) ksr_store16_co<ST>(xb, a.sv_hmid, n0w, nvalid, lane, hm);
+                else if (live) ksr_storen<ST, 16>(a.sv_hmid, n * 32 + 16 * h, hm);
             }
             f32x16 acc2[2];
             ksr_wave_gemm<PREC, 16, 2>(sm.f_l2, sm.b_l2, hm, acc2, lane);
@@ -260,14 +267,15 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
 }  // namespace
 
 extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* const* params, float* const* saves,
-                                      int S, int HW, float eps, float p_drop, uint64_t seed, hipStream_t stream) {
+                                      int S, int HW, float eps, float p_drop, uint64_t seed, const float* in_f32_copy,
+                                      hipStream_t stream) {
     KSR_CHECK_ARG(in && out && params, "batch_tx_layer_fwd: null pointer");
     KSR_CHECK_ARG(S > 0 && HW > 0, "batch_tx_layer_fwd: non-positive dimension");
     KSR_UNSUPPORTED(S > 128, "batch_tx_layer_fwd: local batch %d > 128 not supported", S);
     KSR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "batch_tx_layer_fwd: dropout p must be in [0,1)");
     for (int i = 0; i < 12; ++i) KSR_CHECK_ARG(params[i] != nullptr, "batch_tx_layer_fwd: params[%d] is null", i);
     TxArgs a{};
-    a.in = in; a.out = out;
+    a.in = in; a.in32 = in_f32_copy; a.out = out;
     a.in_w = params[0]; a.in_b = params[1]; a.out_w = params[2]; a.out_b = params[3];
     a.l1_w = params[4]; a.l1_b = params[5]; a.l2_w = params[6]; a.l2_b = params[7];
     a.n1_w = params[8]; a.n1_b = params[9]; a.n2_w = params[10]; a.n2_b = params[11];
@@ -281,8 +289,14 @@ extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* 
     const int PPW = 128 / S;
     const int ntiles = (HW + PPW - 1) / PPW;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    if (saves || p_drop > 0.f) { if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_BF16, true, false>), dim3(grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32, true, false>), dim3(grid), dim3(256), 0, stream, a); }
-    else { if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_BF16, false, false>), dim3(grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32, false, false>), dim3(grid), dim3(256), 0, stream, a); }
+    const bool train = saves || p_drop > 0.f;
+#define KSR_CALL(P)                                                                                                   \
+    do {                                                                                                              \
+        if (train) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, true, false>), dim3(grid), dim3(256), 0, stream, a);    \
+        else hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, false>), dim3(grid), dim3(256), 0, stream, a);         \
+    } while (0)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
     KSR_LAUNCH_CHECK("batch_tx_layer_fwd");
     return KSR_OK;
 }
@@ -291,12 +305,12 @@ extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* 
 // (ksr_batch_attn_fwd).  params as ksr_batch_tx_layer_fwd (entries 0, 1 unused); saves[0], saves[1] unused.
 extern "C" int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, float* out, const float* const* params,
                                            float* const* saves, int64_t N, float eps, float p_drop, uint64_t seed,
-                                           hipStream_t stream) {
+                                           const float* in_f32_copy, hipStream_t stream) {
     KSR_CHECK_ARG(in && ctx && out && params && N > 0, "batch_tx_layer_post_fwd: bad argument");
     KSR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "batch_tx_layer_post_fwd: dropout p must be in [0,1)");
     for (int i = 2; i < 12; ++i) KSR_CHECK_ARG(params[i] != nullptr, "batch_tx_layer_post_fwd: params[%d] is null", i);
     TxArgs a{};
-    a.in = in; a.ctx_in = ctx; a.out = out;
+    a.in = in; a.in32 = in_f32_copy; a.ctx_in = ctx; a.out = out;
     a.out_w = params[2]; a.out_b = params[3];
     a.l1_w = params[4]; a.l1_b = params[5]; a.l2_w = params[6]; a.l2_b = params[7];
     a.n1_w = params[8]; a.n1_b = params[9]; a.n2_w = params[10]; a.n2_b = params[11];
@@ -309,8 +323,14 @@ extern "C" int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, fl
     a.S = 1; a.HW = (int)N; a.eps = eps; a.p_drop = p_drop; a.seed = seed;
     const long ntiles = (N + 127) / 128;
     const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
-    if (saves || p_drop > 0.f) { if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_BF16, true, true>), dim3(grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32, true, true>), dim3(grid), dim3(256), 0, stream, a); }
-    else { if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_BF16, false, true>), dim3(grid), dim3(256), 0, stream, a); else hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32, false, true>), dim3(grid), dim3(256), 0, stream, a); }
+    const bool train = saves || p_drop > 0.f;
+#define KSR_CALL(P)                                                                                                   \
+    do {                                                                                                              \
+        if (train) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, true, true>), dim3(grid), dim3(256), 0, stream, a);     \
+        else hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, true>), dim3(grid), dim3(256), 0, stream, a);          \
+    } while (0)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
     KSR_LAUNCH_CHECK("batch_tx_layer_post_fwd");
     return KSR_OK;
 }

@@ -46,6 +46,7 @@ __device__ __forceinline__ void ln_bwd(const float (&dy)[32], const float* __res
 
 template <int PREC>
 __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
+    using ST = typename KsrStore<PREC>::T;
     __shared__ TxBwdTokSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -70,18 +71,18 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
 
         float g[32], xh[32];
-        ksr_load32_co(xb, a.dy, n0w, nvalid, 64, 0, lane, g);
+        ksr_load32_co<ST>(xb, a.dy, n0w, nvalid, 64, 0, lane, g);
         if (a.nf_w) {
             float t[32];
-            ksr_load32_co(xb, a.xhatf, n0w, nvalid, 64, 0, lane, xh);
+            ksr_load32_co<ST>(xb, a.xhatf, n0w, nvalid, 64, 0, lane, xh);
             ln_bwd(g, sm.ln[0], h, xh, a.rstdf[n], t);
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = t[i];
-            ksr_store32_co(xb, a.ds2, n0w, nvalid, 64, 0, lane, g);
+            ksr_store32_co<ST>(xb, a.ds2, n0w, nvalid, 64, 0, lane, g);
         }
         // LayerNorm 2
         float du2[32];
-        ksr_load32_co(xb, a.xhat2, n0w, nvalid, 64, 0, lane, xh);
+        ksr_load32_co<ST>(xb, a.xhat2, n0w, nvalid, 64, 0, lane, xh);
         ln_bwd(g, sm.ln[1], h, xh, a.rstd2[n], du2);
         // MLP
         float dm[32];
@@ -89,16 +90,16 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         for (int i = 0; i < 32; ++i)
             dm[i] = drop ? (ksr_uniform(a.seed, 3u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du2[i] * inv_keep : 0.f)
                          : du2[i];
-        ksr_store32_co(xb, a.dm, n0w, nvalid, 64, 0, lane, dm);
+        ksr_store32_co<ST>(xb, a.dm, n0w, nvalid, 64, 0, lane, dm);
         float dpre[16];
         {
             f32x16 acc[1];
             ksr_wave_gemm<PREC, 32, 1>(sm.f_l2t, nullptr, dm, acc, lane);
             float hm[16];
-            ksr_load16_co(xb, a.hmid, n0w, nvalid, lane, hm);
+            ksr_load16_co<ST>(xb, a.hmid, n0w, nvalid, lane, hm);
 #pragma unroll
             for (int i = 0; i < 16; ++i) dpre[i] = hm[i] > 0.f ? (drop ? acc[0][i] * inv_keep : acc[0][i]) : 0.f;
-            ksr_store16_co(xb, a.dpre, n0w, nvalid, lane, dpre);
+            ksr_store16_co<ST>(xb, a.dpre, n0w, nvalid, lane, dpre);
         }
         float ds1[32];
         {
@@ -106,26 +107,26 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
             ksr_wave_gemm<PREC, 16, 2>(sm.f_l1t, nullptr, dpre, acc, lane);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ds1[i] = du2[i] + acc[0][i]; ds1[16 + i] = du2[16 + i] + acc[1][i]; }
-            ksr_store32_co(xb, a.ds1, n0w, nvalid, 64, 0, lane, ds1);
+            ksr_store32_co<ST>(xb, a.ds1, n0w, nvalid, 64, 0, lane, ds1);
         }
         // LayerNorm 1
         float du1[32];
-        ksr_load32_co(xb, a.xhat1, n0w, nvalid, 64, 0, lane, xh);
+        ksr_load32_co<ST>(xb, a.xhat1, n0w, nvalid, 64, 0, lane, xh);
         ln_bwd(ds1, sm.ln[2], h, xh, a.rstd1[n], du1);
-        ksr_store32_co(xb, a.du1, n0w, nvalid, 64, 0, lane, du1);
+        ksr_store32_co<ST>(xb, a.du1, n0w, nvalid, 64, 0, lane, du1);
         float da[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i)
             da[i] = drop ? (ksr_uniform(a.seed, 1u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du1[i] * inv_keep : 0.f)
                          : du1[i];
-        if (drop) ksr_store32_co(xb, a.da, n0w, nvalid, 64, 0, lane, da);
+        if (drop) ksr_store32_co<ST>(xb, a.da, n0w, nvalid, 64, 0, lane, da);
         {
             f32x16 acc[2];
             ksr_wave_gemm<PREC, 32, 2>(sm.f_outt, nullptr, da, acc, lane);
             float dc[32];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { dc[i] = acc[0][i]; dc[16 + i] = acc[1][i]; }
-            ksr_store32_co(xb, a.dctx, n0w, nvalid, 64, 0, lane, dc);
+            ksr_store32_co<ST>(xb, a.dctx, n0w, nvalid, 64, 0, lane, dc);
         }
     }
 }
@@ -143,6 +144,7 @@ struct TxBwdAttnArgs {
 
 constexpr int XLD = 140;     // floats per slot in the exchange buffer (2 x 68 + 4 pad)
 
+template <class ST>   // storage type of qkv / ctx / dctx / dqkv
 __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
     __shared__ __attribute__((aligned(16))) float xb[128 * XLD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -167,17 +169,17 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
         float m = -INFINITY, l = 0.f, D = 0.f;
         {
             float kv[32];
-            ksr_load32(a.qkv + n * 192 + 64 + 32 * h, kv);
+            ksr_loadn<ST, 32>(a.qkv, n * 192 + 64 + 32 * h, kv);
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(mine + 4 * c) = f32x4{kv[4 * c], kv[4 * c + 1], kv[4 * c + 2], kv[4 * c + 3]};
-            ksr_load32(a.qkv + n * 192 + 128 + 32 * h, kv);
+            ksr_loadn<ST, 32>(a.qkv, n * 192 + 128 + 32 * h, kv);
 #pragma unroll
             for (int c = 0; c < 8; ++c) *reinterpret_cast<f32x4*>(mine + 32 + 4 * c) = f32x4{kv[4 * c], kv[4 * c + 1], kv[4 * c + 2], kv[4 * c + 3]};
-            ksr_load32(a.qkv + n * 192 + 32 * h, q);
-            ksr_load32(a.dctx + n * 64 + 32 * h, dO);
+            ksr_loadn<ST, 32>(a.qkv, n * 192 + 32 * h, q);
+            ksr_loadn<ST, 32>(a.dctx, n * 64 + 32 * h, dO);
             float o[32];
-            ksr_load32(a.ctx + n * 64 + 32 * h, o);
+            ksr_loadn<ST, 32>(a.ctx, n * 64 + 32 * h, o);
 #pragma unroll
             for (int i = 0; i < 32; ++i) { q[i] *= scale; D += dO[i] * o[i]; }
         }
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
                 dq[4 * c + 2] += dS * kk[c][2]; dq[4 * c + 3] += dS * kk[c][3];
             }
         }
-        if (live) ksr_store32(a.dqkv + n * 192 + 32 * h, dq);
+        if (live) ksr_storen<ST, 32>(a.dqkv, n * 192 + 32 * h, dq);
 
         // ---- phase B: this lane is a KEY.  exchange buffer holds q*scale | dO | m, 1/l, D ----
         __syncthreads();
@@ -231,8 +233,8 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
         }
         *reinterpret_cast<f32x4*>(mine + 64) = f32x4{m, inv_l, D, 0.f};
         float kj[32], vj[32], dk[32], dv[32];
-        ksr_load32(a.qkv + n * 192 + 64 + 32 * h, kj);
-        ksr_load32(a.qkv + n * 192 + 128 + 32 * h, vj);
+        ksr_loadn<ST, 32>(a.qkv, n * 192 + 64 + 32 * h, kj);
+        ksr_loadn<ST, 32>(a.qkv, n * 192 + 128 + 32 * h, vj);
 #pragma unroll
         for (int i = 0; i < 32; ++i) { dk[i] = 0.f; dv[i] = 0.f; }
         __syncthreads();
@@ -267,8 +269,8 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
             }
         }
         if (live) {
-            ksr_store32(a.dqkv + n * 192 + 64 + 32 * h, dk);
-            ksr_store32(a.dqkv + n * 192 + 128 + 32 * h, dv);
+            ksr_storen<ST, 32>(a.dqkv, n * 192 + 64 + 32 * h, dk);
+            ksr_storen<ST, 32>(a.dqkv, n * 192 + 128 + 32 * h, dv);
         }
     }
 }
@@ -295,8 +297,9 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     KSR_CHECK_ARG(!(p_drop > 0.f) || a.da, "batch_tx_layer_bwd_token: dropout needs the da output");
     a.N = (long)N; a.p_drop = p_drop; a.seed = seed;
     const long ntiles = (N + 127) / 128;
-    if (ksr_prec() == KSR_BF16) hipLaunchKernelGGL(tx_bwd_token_kernel<KSR_BF16>, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(tx_bwd_token_kernel<KSR_F32>, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a);
+#define KSR_CALL(P) hipLaunchKernelGGL(tx_bwd_token_kernel<P>, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token");
     return KSR_OK;
 }
@@ -308,7 +311,8 @@ extern "C" int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, c
     TxBwdAttnArgs a{qkv, ctx, dctx, dqkv, S, HW, p_drop, seed};
     const int PPW = 128 / S;
     const int ntiles = (HW + PPW - 1) / PPW;
-    hipLaunchKernelGGL(tx_bwd_attn_kernel, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, stream, a);
+    if (ksr_prec() == KSR_BF16S) hipLaunchKernelGGL(tx_bwd_attn_kernel<__bf16>, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(tx_bwd_attn_kernel<float>, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_attn");
     return KSR_OK;
 }

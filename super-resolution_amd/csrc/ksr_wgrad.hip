@@ -35,14 +35,17 @@ struct WgArgs {
 // LDS read, fp32 accumulation; 16 pixels per instruction); the bias / square sums stay exact fp32.
 template <int PREC, int WG_T, int NP, bool HAS2>   // pixels per staged chunk; dz blocks per wave; a2 present
 __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float wlds[];
+    using T = typename KsrStore<PREC>::T;          // storage type of dz / a1 / a2 (staged as stored)
+    constexpr int EPP = 16 / sizeof(T);            // elements per 16-byte piece
+    extern __shared__ __attribute__((aligned(16))) float wlds_raw[];
+    T* wlds = reinterpret_cast<T*>(wlds_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kk = lane >> 5;
     const int NJB = a.J / 32, NKB = a.K / 32;
     const int kb = wv % NKB, jb0 = wv / NKB, jbs = 4 / NKB;
-    const int RL = a.Jv + a.K + (HAS2 ? a.K : 0);      // floats per staged row
-    const int RL4 = RL / 4;
+    const int RL = a.Jv + a.K + (HAS2 ? a.K : 0);      // elements per staged row
+    const int RL4 = RL / EPP;                           // 16-byte pieces per row
     const unsigned inv = (unsigned)((0x100000000ULL + RL4 - 1) / RL4);
     const int nvec = WG_T * RL4;                        // 16-byte pieces per chunk
     const int npass = (nvec + 255) / 256;
@@ -74,42 +77,42 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     const int nchunks = n1 > n0 ? (int)((n1 - n0 + WG_T - 1) / WG_T) : 0;
 
     auto issue = [&](int c) {
-        float* dstbuf = wlds + (c & 1) * (WG_T * RL);
+        T* dstbuf = wlds + (c & 1) * (WG_T * RL);
         const long t0 = n0 + (long)c * WG_T;
         for (int i = 0; i < npass; ++i) {
             const unsigned f = (unsigned)(i * 256 + tid);
             if ((int)f >= nvec) break;                  // ragged last pass: the remaining lanes stage nothing
             const unsigned trow = __umulhi(f, inv);
-            const int q = (int)(f - trow * RL4) * 4;
+            const int q = (int)(f - trow * RL4) * EPP;
             long tokn = t0 + trow;
             if (tokn >= n1) tokn = n1 - 1;
-            const float* s_dz = a.dz + tokn * a.dz_ld + a.dz_c0 + q;
-            const float* s_a1 = a.a1 + tokn * a.a1_ld + a.a1_c0 + (q - a.Jv);
-            const float* src = q < a.Jv ? s_dz : s_a1;
+            const T* s_dz = reinterpret_cast<const T*>(a.dz) + tokn * a.dz_ld + a.dz_c0 + q;
+            const T* s_a1 = reinterpret_cast<const T*>(a.a1) + tokn * a.a1_ld + a.a1_c0 + (q - a.Jv);
+            const T* src = q < a.Jv ? s_dz : s_a1;
             if (HAS2) {
-                const float* s_a2 = a.a2 + tokn * a.a2_ld + a.a2_c0 + (q - a.Jv - a.K);
+                const T* s_a2 = reinterpret_cast<const T*>(a.a2) + tokn * a.a2_ld + a.a2_c0 + (q - a.Jv - a.K);
                 src = q < a.Jv + a.K ? src : s_a2;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dstbuf + (i * 256 + wv * 64) * 4),
+                                             (__attribute__((address_space(3))) void*)(dstbuf + (i * 256 + wv * 64) * EPP),
                                              16, 0, 0);
         }
     };
 
-    constexpr bool BF = PREC == KSR_BF16;
+    constexpr bool BF = PREC != KSR_F32;
     constexpr int UG = BF ? 8 : 4;       // operand registers per group: fp32 4 pixel pairs, bf16 one 16-pixel step
     constexpr int NG = WG_T / 2 / UG;
     static_assert(NG % 2 == 0, "operand groups are consumed in pairs");
-    auto load_group = [&](const float* buf, int g, float (&bv)[UG], float (&av)[UG][NP]) {
+    auto load_group = [&](const T* buf, int g, float (&bv)[UG], float (&av)[UG][NP]) {
 #pragma unroll
         for (int i = 0; i < UG; ++i) {
             // pixel of register i: fp32 MFMA k = 2*pair + kk; bf16 MFMA k = 8*kk + i within the 16-pixel step
             const int px = BF ? 16 * g + 8 * kk + i : 2 * (g * UG + i) + kk;
-            const float* row = buf + px * RL;
-            bv[i] = row[boff];
-            if (HAS2) bv[i] *= row[boff + a.K];
+            const T* row = buf + px * RL;
+            bv[i] = (float)row[boff];
+            if (HAS2) bv[i] *= (float)row[boff + a.K];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) av[i][p] = row[joff[p]];
+            for (int p = 0; p < NP; ++p) av[i][p] = (float)row[joff[p]];
         }
     };
 
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     for (int c = 0; c < nchunks; ++c) {
         __syncthreads();                 // chunk c has landed (vmcnt(0) + barrier); buffer (c+1)&1 is free
         if (c + 1 < nchunks) issue(c + 1);
-        const float* buf = wlds + (c & 1) * (WG_T * RL);
+        const T* buf = wlds + (c & 1) * (WG_T * RL);
         const long t0 = n0 + (long)c * WG_T;
         const int nvalid = (n1 - t0 < WG_T) ? (int)(n1 - t0) : WG_T;
         float bvA[UG], avA[UG][NP], bvB[UG], avB[UG][NP];
@@ -243,6 +246,17 @@ struct ColArgs {
     long N;
 };
 
+template <class T>
+__device__ __forceinline__ float4 ld4(const void* base, long off) {
+    if constexpr (sizeof(T) == 4) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + off);
+    else {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(base) + off);
+        return make_float4(__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                           __uint_as_float(w.y & 0xffff0000u));
+    }
+}
+
+template <class T>   // storage type of a (and of b unless it is the per-pixel fp32 scalar)
 __global__ void __launch_bounds__(256) colreduce_kernel(ColArgs a) {
     __shared__ float red[2][16][64];
     const int c4 = (threadIdx.x & 15) * 4, rg = threadIdx.x >> 4;     // 16 row groups x 16 channel quads
@@ -257,9 +271,9 @@ __global__ void __launch_bounds__(256) colreduce_kernel(ColArgs a) {
             const long nn = n + 16 * u;
             const bool ok = nn < n1;
             const long nc = ok ? nn : n;
-            av[u] = *reinterpret_cast<const float4*>(a.a + nc * a.a_ld + a.a_c0 + c4);
+            av[u] = ld4<T>(a.a, nc * a.a_ld + a.a_c0 + c4);
             if (a.b_scalar) { const float s = a.b[nc]; bv[u] = make_float4(s, s, s, s); }
-            else bv[u] = *reinterpret_cast<const float4*>(a.b + nc * 64 + c4);
+            else bv[u] = ld4<T>(a.b, nc * 64 + c4);
             if (!ok) av[u] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -288,6 +302,7 @@ struct DwgArgs {
     int B, H, W;
 };
 
+template <class T>   // storage type of in and ds
 __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
     __shared__ __attribute__((aligned(16))) float halo[HALO_FLOATS];
     __shared__ float red[10][4][64];
@@ -307,15 +322,15 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
         const int y = y0 + row;
         const int yc = y < a.H ? y : a.H - 1;
         const int xmax = (a.W - x0) < 32 ? (a.W - x0) : 32;
-        const float* dsp = a.ds + ((long)b * HW + (long)yc * a.W + x0) * a.ds_ld + a.ds_c0 + c;
+        const T* dsp = reinterpret_cast<const T*>(a.ds) + ((long)b * HW + (long)yc * a.W + x0) * a.ds_ld + a.ds_c0 + c;
         float dv[32];
 #pragma unroll
         for (int col = 0; col < 32; ++col) {
             const int cc = col < xmax ? col : xmax - 1;
-            dv[col] = dsp[(long)cc * a.ds_ld];
+            dv[col] = (float)dsp[(long)cc * a.ds_ld];
         }
         __syncthreads();
-        ksr_stage_halo(halo, a.in, a.in_ld, a.in_c0, b, y0, x0, a.H, a.W, tid);
+        ksr_stage_halo<T>(halo, a.in, a.in_ld, a.in_c0, b, y0, x0, a.H, a.W, tid);
         __syncthreads();
         {
 #pragma unroll
@@ -441,8 +456,10 @@ int launch_wgrad_inst_p(const WgArgs& a, size_t lds_bytes, dim3 grid, hipStream_
 
 template <int T, int NP, bool HAS2>
 int launch_wgrad_inst(const WgArgs& a, size_t lds_bytes, dim3 grid, hipStream_t stream) {
-    return ksr_prec() == KSR_BF16 ? launch_wgrad_inst_p<KSR_BF16, T, NP, HAS2>(a, lds_bytes, grid, stream)
-                                  : launch_wgrad_inst_p<KSR_F32, T, NP, HAS2>(a, lds_bytes, grid, stream);
+#define KSR_CALL(P) return launch_wgrad_inst_p<P, T, NP, HAS2>(a, lds_bytes, grid, stream)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
+    return KSR_OK;
 }
 
 int launch_wgrad_kernel(const WgArgs& a, int per_wave, int T, size_t lds_bytes, unsigned g, unsigned nb, hipStream_t stream) {
@@ -466,9 +483,11 @@ int launch_wgrad_kernel(const WgArgs& a, int per_wave, int T, size_t lds_bytes, 
 // Chunk length and LDS bytes for staged rows of RL floats: 64 pixels while two buffers stay within 64 KiB
 // (more bytes in flight per workgroup) and a wave owns at most 3 row blocks (register budget), else 32.
 void wgrad_shape(int RL, int per_wave, int* T, size_t* lds_bytes) {
-    *T = (2 * 64 * RL * (int)sizeof(float) <= 64 * 1024 && per_wave <= 3) ? 64 : 32;
-    *lds_bytes = (size_t)2 * *T * RL * sizeof(float);
+    const int esz = ksr_prec() == KSR_BF16S ? 2 : 4;       // bytes per stored element
+    *T = (2 * 64 * RL * esz <= 64 * 1024 && per_wave <= 3) ? 64 : 32;
+    *lds_bytes = (size_t)2 * *T * RL * esz;
 }
+int wgrad_align() { return ksr_prec() == KSR_BF16S ? 8 : 4; }   // elements per 16-byte piece
 
 // Workgroups per batch entry of a batched Gram product (nb entries of `tokens` pixels, Jp = J rounded up to 32).
 long gram_grid(int Jp, int K, int nb, long tokens) {
@@ -496,8 +515,9 @@ extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const flo
     KSR_CHECK_ARG(N > 0, "wgrad: N must be positive");
     const int NKB = K / 32, per_wave = (J / 32 + (4 / NKB) - 1) / (4 / NKB);
     KSR_UNSUPPORTED(per_wave > WG_MAXP, "wgrad: J=%d too large", J);
-    KSR_CHECK_ARG(dz_ld % 4 == 0 && dz_c0 % 4 == 0 && a1_ld % 4 == 0 && a1_c0 % 4 == 0 && a2_ld % 4 == 0 && a2_c0 % 4 == 0,
-                  "wgrad: leading dimensions and channel offsets must be multiples of 4");
+    const int al = wgrad_align();
+    KSR_CHECK_ARG(dz_ld % al == 0 && dz_c0 % al == 0 && a1_ld % al == 0 && a1_c0 % al == 0 && a2_ld % al == 0 && a2_c0 % al == 0,
+                  "wgrad: leading dimensions and channel offsets must be multiples of %d", al);
     WgArgs a{dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, a2, a2_ld, a2_c0, slab, (long)N, J, 0, (long)J * K + J};
     int T; size_t lds_bytes;
     wgrad_shape(J + K + (a2 ? K : 0), per_wave, &T, &lds_bytes);
@@ -531,8 +551,9 @@ extern "C" int ksr_gram_batched(const float* dz, int dz_ld, int dz_c0, int J, co
     KSR_CHECK_ARG(J > 0 && J % 4 == 0 && (K == 32 || K == 64), "gram_batched: J must be a multiple of 4 and K 32 or 64");
     KSR_CHECK_ARG(tokens_per_entry > 0 && nb > 0 && nb <= 65535, "gram_batched: bad batch");
     KSR_CHECK_ARG(!want_sq || (J % 32 == 0 && tail), "gram_batched: sums of squares need J % 32 == 0 and a tail buffer");
-    KSR_CHECK_ARG(dz_ld % 4 == 0 && dz_c0 % 4 == 0 && a1_ld % 4 == 0 && a1_c0 % 4 == 0,
-                  "gram_batched: leading dimensions and channel offsets must be multiples of 4");
+    const int al = wgrad_align();
+    KSR_CHECK_ARG(J % al == 0 && dz_ld % al == 0 && dz_c0 % al == 0 && a1_ld % al == 0 && a1_c0 % al == 0,
+                  "gram_batched: J, leading dimensions and channel offsets must be multiples of %d", al);
     const int Jp = (J + 31) / 32 * 32;
     const int NKB = K / 32, per_wave = (Jp / 32 + (4 / NKB) - 1) / (4 / NKB);
     KSR_UNSUPPORTED(per_wave > WG_MAXP, "gram_batched: J=%d too large", J);
@@ -556,7 +577,8 @@ extern "C" int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b,
     ColArgs c{a, a_ld, a_c0, b, b_is_per_pixel_scalar, slab, (long)N};
     long g = (N + 255) / 256;
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(colreduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, c);
+    if (ksr_prec() == KSR_BF16S) hipLaunchKernelGGL(colreduce_kernel<__bf16>, dim3((unsigned)g), dim3(256), 0, stream, c);
+    else hipLaunchKernelGGL(colreduce_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, c);
     KSR_LAUNCH_CHECK("colreduce");
     return launch_reduce(slab, (int)g, 2, 64, 128, out, out_row_stride, 1, nullptr, 0, 0, 0, stream);
 }
@@ -568,7 +590,8 @@ extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const flo
     DwgArgs d{in, in_ld, in_c0, ds, ds_ld, ds_c0, slab, B, H, W};
     long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
     const long g = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL(dwgrad_kernel, dim3((unsigned)g), dim3(256), 0, stream, d);
+    if (ksr_prec() == KSR_BF16S) hipLaunchKernelGGL(dwgrad_kernel<__bf16>, dim3((unsigned)g), dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL(dwgrad_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, d);
     KSR_LAUNCH_CHECK("dwconv_wgrad");
     // slab rows: tap t (J = 9) x channel (K = 64) then the bias row handled as a 10th row via two calls
     if (int rc = launch_reduce(slab, (int)g, 9, 64, 640, dW, 1, 9, nullptr, 0, 0, 0, stream)) return rc;

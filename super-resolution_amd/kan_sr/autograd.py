@@ -38,6 +38,10 @@ class _Ws:
     def new(self, *shape):
         return torch.empty(*shape, device=self.dev, dtype=torch.float32)
 
+    def act(self, *shape):
+        """[N, C] activation-gradient tensor in the storage type of the current precision mode."""
+        return torch.empty(*shape, device=self.dev, dtype=engine.act_dtype())
+
     def grad(self, name, *shape):
         if self.arena is None:
             return self.new(*shape)
@@ -95,9 +99,9 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     params = [nf_w, p[q + "norm2.weight"], p[q + "norm1.weight"], p[q + "linear2.weight"], p[q + "linear1.weight"],
               p[q + "self_attn.out_proj.weight"]]
     saved = [sv["xhatf"], sv["rstdf"], sv["xhat2"], sv["rstd2"], sv["hmid"], sv["xhat1"], sv["rstd1"]]
-    ds2 = ws.new(N, 64) if last else None
-    dm, dpre, ds1, du1, dctx = ws.new(N, 64), ws.new(N, 32), ws.new(N, 64), ws.new(N, 64), ws.new(N, 64)
-    da = ws.new(N, 64) if p_drop > 0 else None
+    ds2 = ws.act(N, 64) if last else None
+    dm, dpre, ds1, du1, dctx = ws.act(N, 64), ws.act(N, 32), ws.act(N, 64), ws.act(N, 64), ws.act(N, 64)
+    da = ws.act(N, 64) if p_drop > 0 else None
     lseed = (seed * 4 + li) & 0xFFFFFFFFFFFFFFFF
     check(L.ksr_batch_tx_layer_bwd_token(ptr(dy), _ptr_array(params), _ptr_array(saved),
                                          _ptr_array([ds2, dm, dpre, ds1, du1, da, dctx]), c_int64(N),
@@ -126,14 +130,14 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     _wgrad(ws, da, 64, 0, 64, sv["ctx"], 64, 0, 64, N, gw, gb)
     grads[q + "self_attn.out_proj.weight"], grads[q + "self_attn.out_proj.bias"] = gw, gb
     # attention
-    dqkv = ws.new(N, 192)
+    dqkv = ws.act(N, 192)
     attn_bwd = L.ksr_batch_attn_bwd if g.B > engine.SPLIT_ATTENTION_ABOVE else L.ksr_batch_tx_layer_bwd_attn
     check(attn_bwd(ptr(sv["qkv"]), ptr(sv["ctx"]), ptr(dctx), ptr(dqkv), c_int(g.B), c_int(g.H * g.W), c_float(p_drop),
                    c_uint64(lseed), stream()), "attention backward")
     gw, gb = ws.grad(q + "self_attn.in_proj_weight", 192, 64), ws.grad(q + "self_attn.in_proj_bias", 192)
     _wgrad(ws, dqkv, 192, 0, 192, sv["in"], 64, 0, 64, N, gw, gb)
     grads[q + "self_attn.in_proj_weight"], grads[q + "self_attn.in_proj_bias"] = gw, gb
-    dsin = ws.new(N, 64)
+    dsin = ws.act(N, 64)
     check(L.ksr_in_proj_bwd(ptr(dqkv), ptr(p[q + "self_attn.in_proj_weight"]), ptr(du1), ptr(y_in_sigmoid), ptr(dsin),
                             *_dims(g), stream()), "ksr_in_proj_bwd")
     return dsin
@@ -145,8 +149,8 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
     L = lib()
     N = g.N
     q = pre + name + "."
-    dt = ws.new(N, 128)
-    dgate = ws.new(N, 64)
+    dt = ws.act(N, 128)
+    dgate = ws.act(N, 64)
     check(L.ksr_gate_pw_bwd(ptr(dz), ptr(p[q + "fn_2.weight"]), ptr(gate_saved), ptr(t), ptr(dt), ptr(dgate),
                             *_dims(g), stream()), "ksr_gate_pw_bwd")
     gw, gb = ws.grad(q + "fn_2.weight", 64, 64, 1, 1), ws.grad(q + "fn_2.bias", 64)
@@ -154,7 +158,7 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
     grads[q + "fn_2.weight"], grads[q + "fn_2.bias"] = gw, gb
     grads[q + "gate.weight"], grads[q + "gate.bias"] = _dwconv_wgrad(ws, t, 128, 64, dgate, g, q + "gate.weight",
                                                                    q + "gate.bias")
-    dx = ws.new(N, 64)
+    dx = ws.act(N, 64)
     if stem_saves is None:
         check(L.ksr_fn1_bwd(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(t), ptr(p[q + "fn_1.0.weight"]), ptr(dx),
                             c_int(0), ptr(None), ptr(None), ptr(None), *_dims(g), stream()), "ksr_fn1_bwd")
@@ -212,8 +216,8 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
     grads: Dict[str, torch.Tensor] = {}
     # ---- feed + KAN ----
     lane_len = int(L.ksr_feed_kan_lane_len(c_int(g.r), c_int(g.n_coef)))
-    gfeat = ws.new(N, 64)
-    gparam = ws.new(N, 2 * lane_len)
+    gfeat = ws.act(N, 64)
+    gparam = ws.act(N, 2 * lane_len)
     check(L.ksr_feed_kan_bwd(ptr(gout), c_int64(gout_batch_stride), ptr(x),
                              c_int64(3 * g.H * g.W), ptr(p[pre + "feed.weight"]), ptr(save_us), ptr(gfeat), ptr(gparam),
                              *_dims(g), c_int(g.r), c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k),
@@ -241,7 +245,7 @@ def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, t
     dx4 = _gated_backward(ws, dz6, "ffn4", p, pre, g, sv["t5"], sv["g6"], grads, sv["x4"])
     # ---- ffn3 ----
     q = pre + "ffn3."
-    ds4 = ws.new(N, 64)
+    ds4 = ws.act(N, 64)
     check(L.ksr_pw2_bwd(ptr(dx4), ptr(p[q + "pointwise2.weight"]), ptr(sv["a4"]), ptr(ds4), *_dims(g), stream()),
           "ksr_pw2_bwd")
     gw, gb = ws.grad(q + "pointwise2.weight", 64, 64, 1, 1), ws.grad(q + "pointwise2.bias", 64)
@@ -249,7 +253,7 @@ def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, t
     grads[q + "pointwise2.weight"], grads[q + "pointwise2.bias"] = gw, gb
     grads[q + "depthwise.weight"], grads[q + "depthwise.bias"] = _dwconv_wgrad(ws, sv["t3"], 64, 0, ds4, g,
                                                                              q + "depthwise.weight", q + "depthwise.bias")
-    dt3, dz2 = ws.new(N, 64), ws.new(N, 64)
+    dt3, dz2 = ws.act(N, 64), ws.act(N, 64)
     check(L.ksr_pw1_bwd(ptr(ds4), ptr(p[q + "depthwise.weight"]), ptr(p[q + "pointwise1.weight"]), ptr(sv["x3"]),
                         ptr(dt3), ptr(dz2), *_dims(g), stream()), "ksr_pw1_bwd")
     gw, gb = ws.grad(q + "pointwise1.weight", 64, 64, 1, 1), ws.grad(q + "pointwise1.bias", 64)

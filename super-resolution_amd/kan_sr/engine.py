@@ -55,15 +55,26 @@ def _dims(g: Geometry):
     return c_int(g.B), c_int(g.H), c_int(g.W)
 
 
-PRECISIONS = {"fp32": 0, "bf16": 1}
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16s": 2}
+_current_precision = "fp32"
 
 
 def set_precision(name: str) -> None:
-    """MFMA operand precision of the GEMM kernels for the calls that follow: "fp32" (exact, the parity mode)
-    or "bf16" (bf16 operands, fp32 accumulate; storage and everything else stay fp32).  Process-wide."""
+    """Precision mode of the kernels for the calls that follow (process-wide):
+    "fp32"  exact fp32 MFMA, fp32 storage (the parity mode);
+    "bf16"  bf16 MFMA operands, fp32 accumulation, fp32 storage;
+    "bf16s" as "bf16", and the [N, C] activation / gradient tensors between kernels are stored as bf16
+            (the image, the output, per-pixel scalars, parameters and their gradients stay fp32)."""
+    global _current_precision
     if name not in PRECISIONS:
         raise KsrError(f"precision must be one of {sorted(PRECISIONS)}, got {name!r}")
     check(lib().ksr_set_precision(c_int(PRECISIONS[name])), "ksr_set_precision")
+    _current_precision = name
+
+
+def act_dtype() -> torch.dtype:
+    """Storage type of the activation tensors in the current precision mode."""
+    return torch.bfloat16 if _current_precision == "bf16s" else torch.float32
 
 
 def new_seed() -> int:
@@ -78,10 +89,12 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
     L = lib()
     dev = x.device
     N = g.N
-    new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+    adt = act_dtype()
+    new = lambda *shape: torch.empty(*shape, device=dev, dtype=adt)                  # activations [N, C]
+    new32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)      # per-pixel scalars
     keep = saves is not None
     t2 = new(N, 128)
-    v = new(N) if keep else None
+    v = new32(N) if keep else None
     check(L.ksr_stem_fwd(ptr(x), c_int64(3 * g.H * g.W), ptr(p[pre + "ffn1.pointwise1.weight"]),
                          ptr(p[pre + "ffn1.pointwise1.bias"]), ptr(p[pre + "ffn1.depthwise.weight"]),
                          ptr(p[pre + "ffn1.depthwise.bias"]), ptr(p[pre + "ffn1.pointwise2.weight"]),
@@ -90,7 +103,7 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
     x3 = new(N, 64)
     g2 = new(N, 64) if keep else None
     check(L.ksr_gate_pw_fwd(ptr(t2), ptr(p[pre + "ffn2.gate.weight"]), ptr(p[pre + "ffn2.gate.bias"]),
-                            ptr(p[pre + "ffn2.fn_2.weight"]), ptr(p[pre + "ffn2.fn_2.bias"]), ptr(x3), ptr(g2),
+                            ptr(p[pre + "ffn2.fn_2.weight"]), ptr(p[pre + "ffn2.fn_2.bias"]), ptr(x3), ptr(g2), ptr(None),
                             *_dims(g), stream()), "ksr_gate_pw_fwd")
     t3 = new(N, 64)
     check(L.ksr_pointwise_fwd(ptr(x3), ptr(p[pre + "ffn3.pointwise1.weight"]), ptr(p[pre + "ffn3.pointwise1.bias"]),
@@ -104,9 +117,12 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
     check(L.ksr_pointwise_fwd(ptr(x4), ptr(p[pre + "ffn4.fn_1.0.weight"]), ptr(p[pre + "ffn4.fn_1.0.bias"]),
                               ptr(t5), c_int(128), c_int(1), *_dims(g), stream()), "ksr_pointwise_fwd")
     x6 = new(N, 64)
+    # bf16 storage: the first transformer layer's residual + LayerNorm reads an fp32 copy of x6 (sigmoid outputs
+    # sit at 0.5 +- 1e-3 at initialisation, below bf16 resolution)
+    x6_f32 = new32(N, 64) if adt != torch.float32 else None
     g6 = new(N, 64) if keep else None
     check(L.ksr_gate_pw_fwd(ptr(t5), ptr(p[pre + "ffn4.gate.weight"]), ptr(p[pre + "ffn4.gate.bias"]),
-                            ptr(p[pre + "ffn4.fn_2.weight"]), ptr(p[pre + "ffn4.fn_2.bias"]), ptr(x6), ptr(g6),
+                            ptr(p[pre + "ffn4.fn_2.weight"]), ptr(p[pre + "ffn4.fn_2.bias"]), ptr(x6), ptr(g6), ptr(x6_f32),
                             *_dims(g), stream()), "ksr_gate_pw_fwd")
     if keep:
         saves.update(v=v, t2=t2, g2=g2, x3=x3, t3=t3, a4=a4, x4=x4, t5=t5, g6=g6, x6=x6)
@@ -119,13 +135,14 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
         out = new(N, 64)
         sv = None
         if keep:
-            sv = dict(qkv=new(N, 192), ctx=new(N, 64), xhat1=new(N, 64), rstd1=new(N), s1=new(N, 64),
-                      hmid=new(N, 32), xhat2=new(N, 64), rstd2=new(N),
-                      xhatf=new(N, 64) if last else None, rstdf=new(N) if last else None)
+            sv = dict(qkv=new(N, 192), ctx=new(N, 64), xhat1=new(N, 64), rstd1=new32(N), s1=new(N, 64),
+                      hmid=new(N, 32), xhat2=new(N, 64), rstd2=new32(N),
+                      xhatf=new(N, 64) if last else None, rstdf=new32(N) if last else None)
             sv["in"] = s
             saves[f"tx{li}"] = sv
         names = ("qkv", "ctx", "xhat1", "rstd1", "s1", "hmid", "xhat2", "rstd2", "xhatf", "rstdf")
         lseed = c_uint64((seed * 4 + li) & 0xFFFFFFFFFFFFFFFF)
+        s_f32 = x6_f32 if li == 0 else None
         if g.B > SPLIT_ATTENTION_ABOVE:
             # large local batch: QKV projection, MFMA attention and the rest of the layer as three kernels
             qkv = sv["qkv"] if keep else new(N, 192)
@@ -136,12 +153,12 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
                                        stream()), "ksr_batch_attn_fwd")
             sv_arr = _ptr_array([None, None] + [sv[k] for k in names[2:]]) if keep else None
             check(L.ksr_batch_tx_layer_post_fwd(ptr(s), ptr(ctx), ptr(out), _ptr_array(plist), sv_arr, c_int64(N),
-                                                c_float(LN_EPS), c_float(p_drop), lseed, stream()),
+                                                c_float(LN_EPS), c_float(p_drop), lseed, ptr(s_f32), stream()),
                   "ksr_batch_tx_layer_post_fwd")
         else:
             sv_arr = _ptr_array([sv[k] for k in names]) if keep else None
             check(L.ksr_batch_tx_layer_fwd(ptr(s), ptr(out), _ptr_array(plist), sv_arr, c_int(g.B),
-                                           c_int(g.H * g.W), c_float(LN_EPS), c_float(p_drop), lseed, stream()),
+                                           c_int(g.H * g.W), c_float(LN_EPS), c_float(p_drop), lseed, ptr(s_f32), stream()),
                   "ksr_batch_tx_layer_fwd")
         s = out
     if keep:

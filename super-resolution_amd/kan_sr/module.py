@@ -155,6 +155,8 @@ class ConvSepKan(nn.Module):
     def _forward_attention(self, x, p, pre, g, p_drop, seed, needs_grad):
         """Encoder trunk -> channel attention head -> KAN + pixel shuffle + chroma."""
         from .ops import kan_head
+        if self.precision == "bf16s":
+            raise KsrError("the channel-attention head has no bf16-storage kernels: use precision 'fp32' or 'bf16'")
         head = self.layers[-1].encoder.encoder.feed
         head.precision = self.precision
         with torch.set_grad_enabled(needs_grad):

@@ -76,7 +76,7 @@ def test_batch_tx_layer_vs_oracle(S):
     out = torch.empty_like(sin)
     plist = [pc[pre + n] for n in engine.TX_PARAM_NAMES] + [None, None]
     check(lib().ksr_batch_tx_layer_fwd(ptr(sin), ptr(out), engine._ptr_array(plist), None, c_int(S), c_int(HW),
-                                       c_float(1e-5), c_float(0.0), c_uint64(0), stream()), "tx")
+                                       c_float(1e-5), c_float(0.0), c_uint64(0), None, stream()), "tx")
     assert_fwd(out.permute(1, 0, 2), ref, atol=2e-5)
 
 
@@ -246,12 +246,12 @@ def test_mfma_attention_split_layer_vs_oracle(S, HW):
                               c_int(1), stream()), "qkv")
     check(L.ksr_batch_attn_fwd(ptr(qkv), ptr(ctx), c_int(S), c_int(HW), c_float(0.0), c_uint64(0), stream()), "attn")
     check(L.ksr_batch_tx_layer_post_fwd(ptr(sin), ptr(ctx), ptr(out), engine._ptr_array(plist), None, c_int64(N),
-                                        c_float(1e-5), c_float(0.0), c_uint64(0), stream()), "post")
+                                        c_float(1e-5), c_float(0.0), c_uint64(0), None, stream()), "post")
     assert_fwd(out.permute(1, 0, 2), ref, atol=2e-5)
     # the fused kernel gives the same answer
     out2 = torch.empty_like(sin)
     check(L.ksr_batch_tx_layer_fwd(ptr(sin), ptr(out2), engine._ptr_array(plist), None, c_int(S), c_int(HW),
-                                   c_float(1e-5), c_float(0.0), c_uint64(0), stream()), "tx")
+                                   c_float(1e-5), c_float(0.0), c_uint64(0), None, stream()), "tx")
     assert_fwd(out2, out, atol=2e-5)
 
 
@@ -286,14 +286,18 @@ def test_mfma_attention_matches_valu_attention(S, HW, p_drop):
         assert rel_l2(d1.cpu(), ref) <= 1e-5
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16s"])
 @pytest.mark.parametrize("r,G,k", [(2, 5, 3), (4, 5, 3), (4, 16, 3)])
-def test_bf16_mfma_mode_golden(r, G, k):
-    """bf16 MFMA operands / fp32 accumulate (a build-side mode the reference does not have).  Stated tolerance:
+def test_bf16_mfma_mode_golden(r, G, k, precision):
+    """bf16 MFMA operands / fp32 accumulate, with fp32 ("bf16") or bf16 ("bf16s") storage of the activations
+    between kernels (build-side modes the reference does not have).  Stated tolerance:
     forward rel-L2 <= 2e-2 on the Y plane; every parameter gradient of >= 64 elements cosine >= 0.999 and
     rel-L2 <= 5e-2; the four stem tensors of 1 or 9 elements (sums of ~1e5 cancelling terms, |g| ~ 1e-5)
-    cosine >= 0.99 and rel-L2 <= 0.3."""
+    cosine >= 0.99 and rel-L2 <= 0.3.  With bf16 storage, on this 512-pixel input (rounding noise averages over
+    few pixels): cosine >= 0.98 and rel-L2 <= 0.2 (0.5 for the stem tensors); test_bf16_storage_large_batch pins
+    the mode at a realistic pixel count."""
     g, m = _load_model_golden(r, G, k)
-    m.precision = "bf16"
+    m.precision = precision
     y = m(t(g["x"]).cuda())
     assert rel_l2(y[:, 0].detach().cpu(), t(g["y"])[:, 0]) <= 2e-2
     assert_fwd(y[:, 1:], t(g["y"])[:, 1:])           # chroma does not go through a GEMM
@@ -302,16 +306,21 @@ def test_bf16_mfma_mode_golden(r, G, k):
         got, ref = prm.grad.cpu().flatten().double(), t(g["g." + n]).flatten().double()
         cos = float((got * ref).sum() / (got.norm() * ref.norm()).clamp_min(1e-30))
         big = got.numel() >= 64
-        assert cos >= (0.999 if big else 0.99), f"{n}: cos {cos:.5f}"
-        assert rel_l2(got, ref) <= (5e-2 if big else 0.3), f"{n}: rel-L2 {rel_l2(got, ref):.3e}"
+        if precision == "bf16s":
+            cos_min, rel_max = (0.98, 0.2) if big else (0.98, 0.5)
+        else:
+            cos_min, rel_max = (0.999, 5e-2) if big else (0.99, 0.3)
+        assert cos >= cos_min, f"{n}: cos {cos:.5f}"
+        assert rel_l2(got, ref) <= rel_max, f"{n}: rel-L2 {rel_l2(got, ref):.3e}"
     # and fp32 mode is restored by the next fp32 module call
     m.precision = "fp32"
     with torch.no_grad():
         assert_fwd(m.eval()(t(g["x"]).cuda()), t(g["y"]), atol=2e-5)
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
 @pytest.mark.parametrize("S,HW,p_drop", [(3, 50, 0.0), (8, 40, 0.1), (32, 9, 0.0), (64, 130, 0.1), (100, 7, 0.1), (128, 5, 0.0)])
-def test_bf16_attention_matches_fp32_attention(S, HW, p_drop):
+def test_bf16_attention_matches_fp32_attention(S, HW, p_drop, storage):
     """bf16-operand attention kernels against the fp32 ones on the same inputs and dropout masks.  Stated
     tolerance (bf16 operands, fp32 softmax and accumulation): rel-L2 <= 2e-2 forward and backward."""
     from kan_sr import engine
@@ -322,18 +331,55 @@ def test_bf16_attention_matches_fp32_attention(S, HW, p_drop):
     dctx = torch.randn(N, 64, device="cuda")
     L = lib()
     res = {}
+    lowp = "bf16s" if storage == "bf16" else "bf16"
+    if storage == "bf16":       # the fp32 run sees the same (bf16-representable) inputs
+        qkv, dctx = qkv.bfloat16().float(), dctx.bfloat16().float()
     try:
-        for prec in ("fp32", "bf16"):
+        for prec in ("fp32", lowp):
             engine.set_precision(prec)
-            ctx = torch.full((N, 64), float("nan"), device="cuda")
-            dqkv = torch.full((N, 192), float("nan"), device="cuda")
-            check(L.ksr_batch_attn_fwd(ptr(qkv), ptr(ctx), c_int(S), c_int(HW), c_float(p_drop), c_uint64(5), stream()), "fwd")
-            check(L.ksr_batch_attn_bwd(ptr(qkv), ptr(ctx), ptr(dctx), ptr(dqkv), c_int(S), c_int(HW), c_float(p_drop),
+            dt = engine.act_dtype()
+            ctx = torch.full((N, 64), float("nan"), device="cuda", dtype=dt)
+            dqkv = torch.full((N, 192), float("nan"), device="cuda", dtype=dt)
+            q_in, d_in = qkv.to(dt), dctx.to(dt)
+            check(L.ksr_batch_attn_fwd(ptr(q_in), ptr(ctx), c_int(S), c_int(HW), c_float(p_drop), c_uint64(5), stream()), "fwd")
+            check(L.ksr_batch_attn_bwd(ptr(q_in), ptr(ctx), ptr(d_in), ptr(dqkv), c_int(S), c_int(HW), c_float(p_drop),
                                        c_uint64(5), stream()), "bwd")
-            res[prec] = (ctx.cpu(), dqkv.cpu())
+            res["fp32" if prec == "fp32" else "bf16"] = (ctx.float().cpu(), dqkv.float().cpu())
     finally:
         engine.set_precision("fp32")
     assert bool(torch.isfinite(res["bf16"][0]).all()) and bool(torch.isfinite(res["bf16"][1]).all())
     assert rel_l2(res["bf16"][0], res["fp32"][0]) <= 2e-2
     for c0, name in ((0, "dq"), (64, "dk"), (128, "dv")):
         assert rel_l2(res["bf16"][1][:, c0:c0 + 64], res["fp32"][1][:, c0:c0 + 64]) <= 2e-2, name
+
+
+def test_bf16_storage_large_batch():
+    """bf16 activation storage against the exact fp32 mode of the same kernels at 32 768 pixels (8 x 64 x 64), eval
+    mode.  Stated tolerance: forward rel-L2 <= 1e-2; gradients of tensors with >= 64 elements cosine >= 0.999 and
+    rel-L2 <= 5e-2."""
+    from kan_sr.module import ConvSepKan
+    from kan_sr.init import init_like_training_setup
+    torch.manual_seed(3)
+    m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4).eval()
+    init_like_training_setup(m, 0)
+    m = m.cuda()
+    x = torch.rand(8, 3, 64, 64, device="cuda")
+    gy = torch.randn(8, 3, 256, 256, device="cuda")
+    res = {}
+    for prec in ("fp32", "bf16s"):
+        m.precision = prec
+        m.zero_grad(set_to_none=True)
+        y = m(x)
+        y.backward(gy)
+        res[prec] = (y.detach().cpu(), {n: p.grad.detach().cpu().double().flatten() for n, p in m.named_parameters()})
+    m.precision = "fp32"
+    assert rel_l2(res["bf16s"][0][:, 0], res["fp32"][0][:, 0]) <= 1e-2
+    worst = []
+    for n, ref in res["fp32"][1].items():
+        got = res["bf16s"][1][n]
+        if got.numel() < 64:
+            continue
+        cos = float((got * ref).sum() / (got.norm() * ref.norm()).clamp_min(1e-30))
+        worst.append((cos, rel_l2(got, ref), n))
+    bad = [w for w in worst if w[0] < 0.999 or w[1] > 5e-2]
+    assert not bad, bad
