@@ -29,7 +29,7 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
-def kernel_models(S: int, P: int, bf16: bool):
+def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
     """Per entry point: (bound, algorithmic flops per LR pixel per step, algorithmic HBM bytes per LR pixel per
     step, MFMA peak in TFLOP/s) summed over that entry point's launches in one training step.
     Flops: 2*Cin*Cout per 1x1 conv / linear, 2*9 per depthwise output; attention: 2 products of 64 flops per
@@ -37,12 +37,13 @@ def kernel_models(S: int, P: int, bf16: bool):
     must read + write once (fp32 storage).  The GEMM kernels are priced against the MFMA peak of their operand
     type (bf16 mode: dense bf16 peak); the attention products and, in fp32 mode, everything else run on fp32 MFMA."""
     pk = PEAK_MFMA_BF16_TFLOPS if bf16 else PEAK_MFMA_F32_TFLOPS
-    f32 = PEAK_MFMA_F32_TFLOPS
+    f32 = pk                       # the attention products follow the operand mode as well
+    k = act_bytes / 4.0            # byte counts below are written for fp32 activations
     wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64 + 64 * 64 + 192 * 64) + (64 * 64 + 128 * 64) + 2 * 64 * 64 + 64 * 64
     wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64) + (64 + 64) + (192 + 64)) + (64 * 3 + 128 + 64)
                     + 2 * (64 + 64) + 64 * 3)
     lin_post = 2 * (64 * 64 + 64 * 32 + 32 * 64)
-    return {
+    models = {
         # forward
         "ksr_stem_fwd": ("hbm", 2 * 64 * 128 + 150, 4 + 512 + 4, pk),
         "ksr_gate_pw_fwd": ("hbm", 2 * (2 * 64 * 64 + 2 * 9 * 64 + 64), 2 * (512 + 256 + 256), pk),
@@ -67,15 +68,24 @@ def kernel_models(S: int, P: int, bf16: bool):
         "ksr_colreduce": ("hbm", 0, 5 * 512 + 2 * 260, pk),
         "ksr_dwconv_wgrad": ("hbm", 3 * 2 * 10 * 64, 3 * 512, pk),
     }
+    # activation bytes scale with the storage type; the image-side tensors of these entry points stay fp32
+    fixed = {"ksr_stem_fwd": 8, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_feed_kan_bwd": 64 + 4 + 128, "ksr_bilinear_up": 8 + 8 * 16,
+             "ksr_gate_pw_fwd": 256 if act_bytes != 4 else 0, "ksr_batch_tx_layer_post_fwd": 128 if act_bytes != 4 else 0}
+    out = {}
+    for name, (bound, fl, by, peak) in models.items():
+        fx = fixed.get(name, 0)
+        base = by - fx if name not in ("ksr_gate_pw_fwd", "ksr_batch_tx_layer_post_fwd") else by
+        out[name] = (bound, fl, base * k + fx, peak)
+    return out
 
 
-# entry point -> device kernel of the default (bf16 training, S = 64) workload, for looking up the HBM bytes per
+# entry point -> device kernel of the default (bf16s training, S = 64) workload, for looking up the HBM bytes per
 # launch measured with the rocprofv3 PMC passes (profiles/pmc_hbm_bytes_per_launch.json)
 ENTRY_KERNEL = {
-    "ksr_batch_attn_bwd": "attn_bwd_kernel<2, true>", "ksr_batch_attn_fwd": "attn_fwd_kernel<2>",
-    "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<1>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<1, true, true>",
-    "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<1, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<1, 4, 8, 3>",
-    "ksr_gate_pw_fwd": "conv_fwd_kernel<1, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<1, 64, 0, 3>",
+    "ksr_batch_attn_bwd": "attn_bwd_bf16_kernel<2, true, __bf16>", "ksr_batch_attn_fwd": "attn_fwd_bf16_kernel<2, __bf16>",
+    "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<2>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<2, true, true>",
+    "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<2, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<2, 4, 8, 3>",
+    "ksr_gate_pw_fwd": "conv_fwd_kernel<2, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<2, 64, 0, 3>",
 }
 
 
@@ -141,7 +151,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "bf16"), choices=["fp32", "bf16", "bf16s"],
+    ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "bf16s"), choices=["fp32", "bf16", "bf16s"],
                     help="precision mode of the training workload: bf16 = bf16 MFMA operands / fp32 accumulate and "
                          "storage, bf16s = also bf16 storage of the activations between kernels (BASELINE configs[2] is "
                          "the bf16 training configuration), fp32 = exact; inference is always fp32")
@@ -230,7 +240,7 @@ def main():
         avg_ms = sum(prof[dom]) / len(prof[dom])
         P = 16 * (5 + 3 + 2)
         bf16 = args.workload == "train" and args.precision != "fp32"
-        models = kernel_models(B, P, bf16)
+        models = kernel_models(B, P, bf16, 2 if (args.workload == "train" and args.precision == "bf16s") else 4)
         kmodel = models.get(dom)
         npx = B * H * W
         roofline = {"kernel": dom, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
@@ -246,9 +256,9 @@ def main():
 
         if kmodel is not None:
             roofline.update(price(dom))
-        if bf16 and B == 64:
+        if args.workload == "train" and args.precision == "bf16s" and B == 64:
             roofline["traffic"] = measured_traffic(dom)
-            roofline["traffic_source"] = "profiles/r01_train_b64_bf16_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
+            roofline["traffic_source"] = "profiles/r01_train_b64_bf16s_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
             roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
         roofline["avg_launch_ms"] = round(avg_ms, 4)
         roofline["launches_per_step"] = len(prof[dom]) // nlaunch

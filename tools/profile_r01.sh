@@ -1,9 +1,9 @@
 #!/bin/bash
 # rocprofv3 passes over the default bench (run on the GPU box from the repo root): kernel trace + stats, then
-# one PMC pass each for FETCH_SIZE and WRITE_SIZE.  Summaries land under gpurun_out/prof_r01/.
+# one PMC pass each for FETCH_SIZE and WRITE_SIZE.  Summaries land under gpurun_out/prof_r01s/.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/prof_r01
+OUT=$R/gpurun_out/prof_r01s
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.log || exit 1
