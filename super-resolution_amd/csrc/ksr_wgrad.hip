@@ -123,6 +123,93 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
         const T* buf = wlds + (c & 1) * (WG_T * RL);
         const long t0 = n0 + (long)c * WG_T;
         const int nvalid = (n1 - t0 < WG_T) ? (int)(n1 - t0) : WG_T;
+        if constexpr (PREC == KSR_BF16S) {
+            // bf16 rows in LDS: a 16-pixel MFMA operand (8 consecutive pixels of one channel per lane) is two
+            // ds_read_b64_tr_b16 (each 16-lane group reads a 4-pixel x 16-channel block transposed); no conversion.
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            const int li = lane & 15;
+            const int lane_off = (8 * kk + (li >> 2)) * RL + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+            const int bbase = a.Jv + 32 * kb;
+            auto tr = [&](const T* ptr) -> uint2 {
+                const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+                return *reinterpret_cast<const uint2*>(&v);
+            };
+            auto ld_step = [&](int g, uint2 (&bq)[HAS2 ? 4 : 2], uint2 (&aq)[NP][2]) {
+                const T* base = buf + 16 * g * RL + lane_off;
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    bq[r] = tr(base + 4 * r * RL + bbase);
+                    if (HAS2) bq[2 + r] = tr(base + 4 * r * RL + bbase + a.K);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) aq[p][r] = tr(base + 4 * r * RL + (joff[p] - col));
+                }
+            };
+            auto unpack = [](const uint2 (&q)[2], float (&x)[8]) {
+                x[0] = __uint_as_float(q[0].x << 16); x[1] = __uint_as_float(q[0].x & 0xffff0000u);
+                x[2] = __uint_as_float(q[0].y << 16); x[3] = __uint_as_float(q[0].y & 0xffff0000u);
+                x[4] = __uint_as_float(q[1].x << 16); x[5] = __uint_as_float(q[1].x & 0xffff0000u);
+                x[6] = __uint_as_float(q[1].y << 16); x[7] = __uint_as_float(q[1].y & 0xffff0000u);
+            };
+            auto use_step = [&](int g, const uint2 (&bq)[HAS2 ? 4 : 2], const uint2 (&aq)[NP][2]) {
+                const bool ragged = nvalid < WG_T;                 // wave-uniform: only a range's last chunk
+                // pixels of this lane's 8 operand elements: 16g + 8kk + e; zero the ones past the range
+                unsigned m[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+                if (ragged) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const int px = 16 * g + 8 * kk + 2 * d;
+                        m[d] = (px < nvalid ? 0x0000ffffu : 0u) | (px + 1 < nvalid ? 0xffff0000u : 0u);
+                    }
+                }
+                uint4 bw = make_uint4(bq[0].x & m[0], bq[0].y & m[1], bq[1].x & m[2], bq[1].y & m[3]);
+                if (HAS2) {
+                    float x1[8], x2[8];
+                    const uint2 q1[2] = {make_uint2(bw.x, bw.y), make_uint2(bw.z, bw.w)};
+                    const uint2 q2[2] = {bq[2], bq[3]};
+                    unpack(q1, x1); unpack(q2, x2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x1[e] *= x2[e];
+                    bw = ksr_pack8(x1);
+                }
+                if (a.sq) {
+                    float x[8];
+                    const uint2 q1[2] = {make_uint2(bw.x, bw.y), make_uint2(bw.z, bw.w)};
+                    unpack(q1, x);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) sqb += x[e] * x[e];
+                }
+                const bf16x8 bpk = *reinterpret_cast<const bf16x8*>(&bw);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const unsigned jm = jmask[p] != 0.f ? 0xffffffffu : 0u;
+                    const uint4 aw = make_uint4(aq[p][0].x & m[0] & jm, aq[p][0].y & m[1] & jm, aq[p][1].x & m[2] & jm,
+                                                aq[p][1].y & m[3] & jm);
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&aw), bpk, acc[p], 0, 0, 0);
+                    if (kb == 0) {                                   // wave-uniform: bias (and square) sums of dz
+                        float x[8];
+                        const uint2 q1[2] = {make_uint2(aw.x, aw.y), make_uint2(aw.z, aw.w)};
+                        unpack(q1, x);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { bsum[p] += x[e]; sqa[p] += x[e] * x[e]; }
+                    }
+                }
+            };
+            constexpr int NS = WG_T / 16;                            // 16-pixel steps per chunk (2 or 4)
+            uint2 bqA[HAS2 ? 4 : 2], aqA[NP][2], bqB[HAS2 ? 4 : 2], aqB[NP][2];
+            ld_step(0, bqA, aqA);
+#pragma unroll 1
+            for (int g = 0; g < NS; g += 2) {
+                ld_step(g + 1, bqB, aqB);
+                __builtin_amdgcn_sched_barrier(0);
+                use_step(g, bqA, aqA);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < NS) ld_step(g + 2, bqA, aqA);
+                __builtin_amdgcn_sched_barrier(0);
+                use_step(g + 1, bqB, aqB);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            continue;
+        }
         float bvA[UG], avA[UG][NP], bvB[UG], avB[UG][NP];
         auto consume = [&](int g, const float (&bv)[UG], const float (&av)[UG][NP]) {
             bf16x8 bpk, apk[NP];
