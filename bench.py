@@ -82,7 +82,8 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
 # entry point -> device kernel of the default (bf16s training, S = 64) workload, for looking up the HBM bytes per
 # launch measured with the rocprofv3 PMC passes (profiles/pmc_hbm_bytes_per_launch.json)
 ENTRY_KERNEL = {
-    "ksr_batch_attn_bwd": "attn_bwd_bf16_kernel<2, true, __bf16>", "ksr_batch_attn_fwd": "attn_fwd_bf16_kernel<2, __bf16>",
+    "ksr_batch_attn_bwd": "_ZN12_GLOBAL__N_120attn_bwd_bf16_kernelILi2ELb1EDF16bEEv11AttnBwdArgs",
+    "ksr_batch_attn_fwd": "_ZN12_GLOBAL__N_120attn_fwd_bf16_kernelILi2EDF16bEEv8AttnArgs",
     "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<2>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<2, true, true>",
     "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<2, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<2, 4, 8, 3>",
     "ksr_gate_pw_fwd": "conv_fwd_kernel<2, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<2, 64, 0, 3>",
