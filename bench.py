@@ -281,7 +281,18 @@ def main():
                     model(xi)
                 torch.cuda.synchronize()
             ti = (time.perf_counter() - ti) / 20
+            from kan_sr.color import predict_rgb
+            with torch.no_grad():
+                for _ in range(3):
+                    predict_rgb(model, xi)
+                torch.cuda.synchronize()
+                tr = time.perf_counter()
+                for _ in range(20):
+                    predict_rgb(model, xi)
+                torch.cuda.synchronize()
+            tr = (time.perf_counter() - tr) / 20
             inference = {"value": round(3840 * 2160 / 1e6 / ti, 1), "unit": "MP/s", "ms_per_frame": round(ti * 1e3, 4),
+                         "ms_per_frame_rgb_in_rgb_out": round(tr * 1e3, 4),
                          "workload": "x4 SR inference fp32 eval, 960x540 -> 3840x2160, 1 GPU (BASELINE configs[1])"}
 
     if dist is not None:

@@ -237,6 +237,24 @@ int ksr_outer2(float* out, const float* r, const float* u, const float* c, const
                float* c_copy, ksr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Colour pre/post-processing: the steps either side of the model in the reference's data path
+ * (src/ml/utils/colors/ycbcr.py; dataset transform src/ml/datasets/huawei/datamodule.py:113-134 and
+ * GenerateCallback src/ml/callbacks/generate.py:43,65,80).  NCHW fp32 images; m9 / o3 are HOST arrays.
+ * ------------------------------------------------------------------------------------------- */
+
+/* rgb_to_ycbcr (ycbcr.py:13-41): ycbcr = rgb @ T + O per pixel; m9 = T row-major ([in][out]), o3 = O. */
+int ksr_rgb_to_ycbcr(const float* rgb, float* ycbcr, int B, int H, int W, const float* m9, const float* o3,
+                     ksr_stream_t stream);
+/* ycbcr_to_rgb (ycbcr.py:44-73): rgb = (ycbcr - O) @ Tinv per pixel; m9 = Tinv row-major, o3 = O. */
+int ksr_ycbcr_to_rgb(const float* ycbcr, float* rgb, int B, int H, int W, const float* m9, const float* o3,
+                     ksr_stream_t stream);
+/* Fused output stage of RGB inference: out_rgb [B,3,rH,rW] = ycbcr_to_rgb(concat(y_hr, up(Cb), up(Cr))), i.e.
+ * F.interpolate(bilinear) + torch.concat (conv_sep_kan.py:30-34,40) followed by ycbcr_to_rgb (generate.py:80)
+ * in one pass; y_hr [B,rH,rW] with images y_batch_stride elements apart; W*r a multiple of 4. */
+int ksr_bilinear_up_to_rgb(const float* x_lr, const float* y_hr, int64_t y_batch_stride, float* out_rgb, int B, int H,
+                           int W, int r, const float* m9, const float* o3, ksr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Channel attention: ConvSepKanAttention.forward (conv_sep_kan/conv_sep_kan_attention.py:48-71) with
  * in = mid = 64 channels on NHWC pixels.  q | k | v live in one [N,192] tensor.  All 64 x 64 per-image
  * algebra (normalisation, softmax, a_proj) is folded into per-image matrices so that the attention output

@@ -209,6 +209,27 @@ def bilinear_up(x: torch.Tensor, r: int) -> torch.Tensor:
     return top * (1 - ly)[:, None] + bot * ly[:, None]
 
 
+# --------------------------------------------------------------------------- colour
+YCBCR_O = torch.tensor([16., 128., 128.]) / 255.
+YCBCR_T = torch.tensor([[0.256788235294118, 0.504129411764706, 0.097905882352941],
+                        [-0.148223529411765, -0.290992156862745, 0.439215686274510],
+                        [0.439215686274510, -0.367788235294118, -0.071427450980392]]).T
+
+
+def rgb_to_ycbcr(image: torch.Tensor) -> torch.Tensor:
+    """src/ml/utils/colors/ycbcr.py:13-41: per pixel ycbcr = rgb @ T + O (SDTV range), shape (*, 3, H, W)."""
+    x = image.to(torch.float32)
+    rgb = x.reshape(-1, 3, x.shape[-2], x.shape[-1]).permute(0, 2, 3, 1)
+    return (rgb @ YCBCR_T + YCBCR_O).permute(0, 3, 1, 2).reshape(x.shape)
+
+
+def ycbcr_to_rgb(image: torch.Tensor) -> torch.Tensor:
+    """src/ml/utils/colors/ycbcr.py:44-73: per pixel rgb = (ycbcr - O) @ T^-1."""
+    x = image.to(torch.float32)
+    ycc = x.reshape(-1, 3, x.shape[-2], x.shape[-1]).permute(0, 2, 3, 1)
+    return ((ycc - YCBCR_O) @ YCBCR_T.inverse()).permute(0, 3, 1, 2).reshape(x.shape)
+
+
 # --------------------------------------------------------------------------- whole model
 def conv_sep_kan_forward(x: torch.Tensor, p: Params, *, out_channels: Sequence[int],
                          grid_size: int, spline_order: int, grid_range: Sequence[float],

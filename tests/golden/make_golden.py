@@ -242,6 +242,32 @@ def gold_chan_attention():
     save("chan_attention", **out)
 
 
+# ---------------------------------------------------------------- colour conversion
+def gold_color():
+    """src/ml/utils/colors/ycbcr.py, loaded by file path (the package __init__ pulls in modules that need
+    libraries which are not installed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_ycbcr", os.path.join(REF, "src/ml/utils/colors/ycbcr.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    gen = torch.Generator().manual_seed(123)
+    rgb = torch.rand(2, 3, 5, 7, generator=gen)
+    rgb[0, :, 0, 0] = torch.tensor([0., 0., 0.])
+    rgb[0, :, 0, 1] = torch.tensor([1., 1., 1.])
+    # The reference's rgb_to_ycbcr raises on every image with more than one pixel (a .view() on a permuted tensor,
+    # ycbcr.py:38), so only its stated formula `rgb @ T + O` with the module's own T and O is evaluated here;
+    # ycbcr_to_rgb (which uses reshape) runs as is.
+    try:
+        mod.rgb_to_ycbcr(rgb)
+        raise SystemExit("reference rgb_to_ycbcr works now: regenerate this fixture from it")
+    except RuntimeError:
+        pass
+    ycc = (rgb.permute(0, 2, 3, 1) @ mod.T + mod.O).permute(0, 3, 1, 2).contiguous()
+    back = mod.ycbcr_to_rgb(ycc)
+    ycc2 = torch.rand(3, 4, 6, generator=gen)
+    save("color", rgb=rgb, ycbcr=ycc, rgb_back=back, ycc2=ycc2, rgb2=mod.ycbcr_to_rgb(ycc2), T=mod.T, O=mod.O)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
@@ -256,3 +282,4 @@ if __name__ == "__main__":
     gold_cfg1()
     gold_dropout_stats()
     gold_chan_attention()
+    gold_color()

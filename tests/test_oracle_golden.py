@@ -169,3 +169,17 @@ def test_chan_attention(tag):
             assert v.grad is None and f"{tag}.g.{n}" not in g      # defined, never used by the forward
         else:
             assert rel_l2(v.grad, t(g[f"{tag}.g.{n}"])) <= GRAD_REL, n
+
+
+def test_color_conversion():
+    """ycbcr_to_rgb against the reference function's outputs; rgb_to_ycbcr against the reference's formula evaluated
+    with its own T and O (the function itself raises on multi-pixel images), known values and the round trip."""
+    g = load_golden("color")
+    assert torch.equal(t(g["T"]), orc.YCBCR_T) and torch.equal(t(g["O"]), orc.YCBCR_O)
+    assert (orc.ycbcr_to_rgb(t(g["ycbcr"])) - t(g["rgb_back"])).abs().max() <= 1e-6
+    assert (orc.ycbcr_to_rgb(t(g["ycc2"])) - t(g["rgb2"])).abs().max() <= 1e-6
+    ycc = orc.rgb_to_ycbcr(t(g["rgb"]))
+    assert (ycc - t(g["ycbcr"])).abs().max() <= 1e-6
+    assert (ycc[0, :, 0, 0] - torch.tensor([16., 128., 128.]) / 255).abs().max() <= 1e-6      # black
+    assert (ycc[0, :, 0, 1] - torch.tensor([235., 128., 128.]) / 255).abs().max() <= 2e-6     # white
+    assert (t(g["rgb_back"]) - t(g["rgb"])).abs().max() <= 1e-5
