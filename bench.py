@@ -67,9 +67,14 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         "ksr_wgrad": ("hbm", 2 * wg_jk, wg_bytes, pk),
         "ksr_colreduce": ("hbm", 0, 5 * 512 + 2 * 260, pk),
         "ksr_dwconv_wgrad": ("hbm", 3 * 2 * 10 * 64, 3 * 512, pk),
+        # loss (per LR pixel = 16 HR pixels): SSIM reads pred + tgt of 3 channels and writes 3 luma maps; the gradient
+        # reads the maps, pred, tgt, and updates gy
+        "ksr_ssim_fwd": ("hbm", 0, 16 * (3 * 8 + 12), pk),
+        "ksr_ssim_y_grad": ("hbm", 0, 16 * (12 + 8 + 8), pk),
+        "ksr_l1_y_loss": ("hbm", 0, 16 * 12, pk),
     }
     # activation bytes scale with the storage type; the image-side tensors of these entry points stay fp32
-    fixed = {"ksr_stem_fwd": 8, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_feed_kan_bwd": 64 + 4 + 128, "ksr_bilinear_up": 8 + 8 * 16,
+    fixed = {"ksr_ssim_fwd": 16 * 36, "ksr_ssim_y_grad": 16 * 28, "ksr_l1_y_loss": 16 * 12, "ksr_stem_fwd": 8, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_feed_kan_bwd": 64 + 4 + 128, "ksr_bilinear_up": 8 + 8 * 16,
              "ksr_gate_pw_fwd": 256 if act_bytes != 4 else 0, "ksr_batch_tx_layer_post_fwd": 128 if act_bytes != 4 else 0}
     out = {}
     for name, (bound, fl, by, peak) in models.items():
@@ -152,6 +157,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--loss", default=os.environ.get("KSR_BENCH_LOSS", "l1+ssim"), choices=["l1", "l1+ssim"],
+                    help="training loss: the reference's training_step loss L1(Y) + 0.15 (1 - SSIM) (default) or L1(Y) only")
     ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "bf16s"), choices=["fp32", "bf16", "bf16s"],
                     help="precision mode of the training workload: bf16 = bf16 MFMA operands / fp32 accumulate and "
                          "storage, bf16s = also bf16 storage of the activations between kernels (BASELINE configs[2] is "
@@ -193,10 +200,10 @@ def main():
         model.precision = args.precision
         x = torch.rand(B, 3, H, W, device=dev)
         tgt = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
-        ts = TrainStep(model, world_size=world, rank=rank)
+        ts = TrainStep(model, world_size=world, rank=rank, loss=args.loss)
         mode = {"fp32": "exact fp32", "bf16": "bf16 MFMA operands / fp32 accumulate and storage",
                 "bf16s": "bf16 MFMA operands and activation storage / fp32 accumulate"}[args.precision]
-        wl = (f"x4 SR training step, {mode} (fwd + bwd + RCCL gradient all-reduce + Adam), 64 patches of 128x128 per "
+        wl = (f"x4 SR training step, {mode} (fwd + loss {args.loss} + bwd + RCCL gradient all-reduce + Adam), 64 patches of 128x128 per "
               "GPU (BASELINE configs[2], per-rank batch), dropout live")
 
         def step():

@@ -236,6 +236,21 @@ int ksr_pointwise_bwd(const float* dz, int n_out, const float* w, float* dx, int
 int ksr_outer2(float* out, const float* r, const float* u, const float* c, const float* w, int J, int K,
                float* c_copy, ksr_stream_t stream);
 
+/* SSIM term of the reference's training loss (src/ml/pipelines/default.py:79-81: L1(Y) + 0.15 (1 - SSIM)) with
+ * torchmetrics' defaults for SSIM(data_range=(0, 1)) restated from the published definition (torchmetrics is not
+ * in the reference tree: parity unpinned): inputs clamped to [0,1], 11x11 Gaussian window sigma 1.5, c1 = 0.01^2,
+ * c2 = 0.03^2, variances clamped at 0, only windows entirely inside the image, mean over pixels, channels, images.
+ * maps (optional, 3*B*(H-10)*(W-10) floats) receives the per-window derivatives of channel 0 for ksr_ssim_y_grad.
+ * slab: ksr_ssim_slab_floats(C, B, H, W) floats. */
+int64_t ksr_ssim_slab_floats(int C, int B, int H, int W);
+int ksr_ssim_fwd(const float* pred, int64_t pred_batch_stride, const float* tgt, int64_t tgt_batch_stride, int C, int B,
+                 int H, int W, float* maps, float* slab, float* ssim_out, ksr_stream_t stream);
+/* grad[b, y, x] += scale * d(sum of the channel-0 window values)/d pred[b, 0, y, x]; pred / tgt point at the luma
+ * planes; scale carries the loss weight and the 1 / (B*C*(H-10)*(W-10)) of the mean. */
+int ksr_ssim_y_grad(const float* maps, const float* pred, int64_t pred_batch_stride, const float* tgt,
+                    int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W, float scale,
+                    ksr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Colour pre/post-processing: the steps either side of the model in the reference's data path
  * (src/ml/utils/colors/ycbcr.py; dataset transform src/ml/datasets/huawei/datamodule.py:113-134 and

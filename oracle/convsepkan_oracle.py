@@ -209,6 +209,42 @@ def bilinear_up(x: torch.Tensor, r: int) -> torch.Tensor:
     return top * (1 - ly)[:, None] + bot * ly[:, None]
 
 
+# --------------------------------------------------------------------------- training loss
+def ssim(pred: torch.Tensor, tgt: torch.Tensor, sigma: float = 1.5, k1: float = 0.01, k2: float = 0.03) -> torch.Tensor:
+    """torchmetrics' StructuralSimilarityIndexMeasure(data_range=(0, 1)) with its defaults, restated from the
+    published definition (torchmetrics is neither installed nor part of the reference tree: parity unpinned).
+    Inputs clamped to [0,1]; 11 x 11 Gaussian window; variances clamped at 0; only windows entirely inside the image
+    (the library reflect-pads by 5 and then crops 5 from every border of the result, which keeps exactly these);
+    mean over pixels and channels per image, then over images."""
+    p, t = pred.clamp(0.0, 1.0), tgt.clamp(0.0, 1.0)
+    ks = int(3.5 * sigma + 0.5) * 2 + 1
+    d = torch.arange((1 - ks) / 2, (1 + ks) / 2, 1, dtype=p.dtype)
+    g = torch.exp(-(d / sigma) ** 2 / 2)
+    g = g / g.sum()
+    C = p.shape[1]
+    k2d = (g[:, None] * g[None, :]).expand(C, 1, ks, ks).contiguous()
+    stack = torch.cat([p, t, p * p, t * t, p * t])
+    out = F.conv2d(stack, k2d, groups=C).split(p.shape[0])
+    mu_p, mu_t = out[0], out[1]
+    var_p = (out[2] - mu_p * mu_p).clamp_min(0.0)
+    var_t = (out[3] - mu_t * mu_t).clamp_min(0.0)
+    cov = out[4] - mu_p * mu_t
+    c1, c2 = k1 ** 2, k2 ** 2
+    s = ((2 * mu_p * mu_t + c1) * (2 * cov + c2)) / ((mu_p * mu_p + mu_t * mu_t + c1) * (var_p + var_t + c2))
+    return s.reshape(s.shape[0], -1).mean(-1).mean()
+
+
+def training_loss(pred: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+    """DefaultPipeline.training_step (src/ml/pipelines/default.py:75-84): L1 on the Y plane + 0.15 (1 - SSIM)."""
+    return (pred[:, :1] - tgt[:, :1]).abs().mean() + (1.0 - ssim(pred, tgt)) * 0.15
+
+
+def cosine_warm_restarts_lr(base_lr: float, epoch: int, T_0: int = 500, eta_min: float = 1e-5) -> float:
+    """CosineAnnealingWarmRestarts(T_0=500, T_mult=1, eta_min=1e-5) (default.py:66-68), stepped once per epoch."""
+    t_cur = epoch % T_0
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t_cur / T_0)) / 2
+
+
 # --------------------------------------------------------------------------- colour
 YCBCR_O = torch.tensor([16., 128., 128.]) / 255.
 YCBCR_T = torch.tensor([[0.256788235294118, 0.504129411764706, 0.097905882352941],

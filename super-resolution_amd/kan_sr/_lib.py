@@ -36,7 +36,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb")):
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad")):
             return fn
 
         def timed(*args):
@@ -72,6 +72,7 @@ def _declare(L: ctypes.CDLL) -> None:
         getattr(L, name).restype = c_int
     L.ksr_last_error.restype = c_char_p
     L.ksr_gram_slab_floats.restype = c_int64
+    L.ksr_ssim_slab_floats.restype = c_int64
 
 
 # every symbol include/ksr.h declares (checked by tests/test_abi_symbols.py)
@@ -90,6 +91,7 @@ EXPORTS = [
     "ksr_pointwise_bwd", "ksr_chan_dw_fwd", "ksr_chan_dw_bwd", "ksr_gram_slab_floats", "ksr_gram_batched",
     "ksr_chan_soft_fwd", "ksr_chan_soft_bwd", "ksr_sum_entries", "ksr_chan_apply",
     "ksr_rgb_to_ycbcr", "ksr_ycbcr_to_rgb", "ksr_bilinear_up_to_rgb",
+    "ksr_ssim_slab_floats", "ksr_ssim_fwd", "ksr_ssim_y_grad",
 ]
 
 

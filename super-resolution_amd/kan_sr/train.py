@@ -4,8 +4,9 @@ One process per GPU.  Parameters, gradients and Adam state of the live layer are
 buffers; the kernels write every gradient in place.  The flat order follows the order in which the
 backward FINISHES gradients (feed, transformer layers, final norm | conv trunk), so the first bucket
 can be all-reduced on a side stream (RCCL over xGMI) while the conv-trunk backward is still running.
-The loss of the step is L1 on the Y plane (the SSIM term of the reference's training_step,
-src/ml/pipelines/default.py:79-81, is not part of this step).
+The loss of the step is L1 on the Y plane (loss="l1") or the reference's training_step loss
+L1(Y) + 0.15 (1 - SSIM) (loss="l1+ssim", src/ml/pipelines/default.py:79-81; SSIM as torchmetrics defines it,
+restated - that library is not available here, so this term's parity is unpinned).
 
 The attention of the hyper-encoder mixes the images of the LOCAL batch (as under the reference's DDP),
 so no activation crosses GPUs: the only exchange is the gradient all-reduce.
@@ -41,6 +42,14 @@ def flat_layout(shapes: Dict[str, torch.Size]):
         if n == _TAIL[-1]:
             tail_end = off
     return table, tail_end, off
+
+
+def cosine_warm_restarts_lr(base_lr: float, epoch: int, T_0: int = 500, eta_min: float = 1e-5) -> float:
+    """Learning rate of CosineAnnealingWarmRestarts(T_0=500, T_mult=1, eta_min=1e-5) after `epoch` scheduler steps
+    (src/ml/pipelines/default.py:66-68; Lightning steps it once per epoch)."""
+    import math
+    t_cur = epoch % T_0
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t_cur / T_0)) / 2
 
 
 def shard_batch(global_batch: int, world_size: int, rank: int):
@@ -90,7 +99,11 @@ class GlooComm:
 
 class TrainStep:
     def __init__(self, model, world_size: int = 1, rank: int = 0, lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 0.0, comm=None):
+                 eps: float = 1e-8, weight_decay: float = 0.0, comm=None, loss: str = "l1"):
+        if loss not in ("l1", "l1+ssim"):
+            raise KsrError(f"loss must be 'l1' or 'l1+ssim', got {loss!r}")
+        self.loss_kind = loss
+        self.base_lr = lr
         self.model = model
         self.world_size, self.rank = world_size, rank
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -120,7 +133,8 @@ class TrainStep:
             self.comm = RcclComm(rank, world_size)
         self.side = torch.cuda.Stream(device=dev) if self.comm is not None else None
         self.slab = torch.empty(256, device=dev, dtype=torch.float32)
-        self.loss = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._l1 = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.loss = self._l1
         self.last_seed = 0
 
     def step(self, x: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
@@ -143,8 +157,11 @@ class TrainStep:
         plane = g.H * g.r * g.W * g.r
         gy = torch.empty(g.B, plane, device=x.device, dtype=torch.float32)
         check(L.ksr_l1_y_loss(ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
-                              c_int64(plane), c_int(g.B), c_int64(plane), c_float(1.0), ptr(self.slab), ptr(self.loss),
+                              c_int64(plane), c_int(g.B), c_int64(plane), c_float(1.0), ptr(self.slab), ptr(self._l1),
                               stream()), "ksr_l1_y_loss")
+        self.loss = self._l1
+        if self.loss_kind == "l1+ssim":
+            self._add_ssim_term(out, tgt, gy, g, plane)
         main = torch.cuda.current_stream()
 
         def tail_done():
@@ -166,6 +183,29 @@ class TrainStep:
                               c_float(1.0 / self.world_size), stream()), "ksr_adam_step")
         self.out = out
         return self.loss
+
+    def _add_ssim_term(self, out, tgt, gy, g, plane):
+        """loss += 0.15 (1 - SSIM(out, tgt)); gy += the luma gradient of that term."""
+        L = lib()
+        B, Hh, Wh = g.B, g.H * g.r, g.W * g.r
+        C = 3
+        nslab = int(L.ksr_ssim_slab_floats(c_int(C), c_int(B), c_int(Hh), c_int(Wh)))
+        if getattr(self, "_ssim_ws", None) is None or self._ssim_ws[0].numel() < nslab or self._ssim_ws[1].numel() < 3 * B * (Hh - 10) * (Wh - 10):
+            self._ssim_ws = (torch.empty(nslab, device=out.device), torch.empty(3 * B * (Hh - 10) * (Wh - 10), device=out.device),
+                             torch.zeros(1, device=out.device))
+        slab, maps, val = self._ssim_ws
+        check(L.ksr_ssim_fwd(ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), c_int(C), c_int(B),
+                             c_int(Hh), c_int(Wh), ptr(maps), ptr(slab), ptr(val), stream()), "ksr_ssim_fwd")
+        scale = -0.15 / (B * C * (Hh - 10) * (Wh - 10))
+        check(L.ksr_ssim_y_grad(ptr(maps), ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
+                                c_int64(plane), c_int(B), c_int(Hh), c_int(Wh), c_float(scale), stream()), "ksr_ssim_y_grad")
+        self.ssim = val
+        self.loss = self._l1 + (1.0 - val) * 0.15           # one-element tensors
+
+    def set_epoch(self, epoch: int, T_0: int = 500, eta_min: float = 1e-5) -> float:
+        """Applies the reference's CosineAnnealingWarmRestarts schedule for `epoch` and returns the new lr."""
+        self.lr = cosine_warm_restarts_lr(self.base_lr, epoch, T_0, eta_min)
+        return self.lr
 
     def close(self):
         if self.comm is not None:

@@ -157,3 +157,56 @@ def test_rccl_path_single_rank_matches_no_comm_path():
         comm.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 40, 52), (1, 33, 97), (3, 12, 11)])
+def test_ssim_kernels_vs_oracle(B, H, W):
+    """SSIM value and its luma gradient against autograd of the oracle's restatement (parity with torchmetrics itself
+    is unpinned: the library is not available).  Values outside [0,1] exercise the clamp."""
+    from ctypes import c_float, c_int, c_int64
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(H)
+    pred = (torch.rand(B, 3, H, W) * 1.2 - 0.1).requires_grad_()
+    tgt = torch.rand(B, 3, H, W) * 1.1 - 0.05
+    val = orc.ssim(pred, tgt)
+    val.backward()
+    L = lib()
+    p, t_ = pred.detach().cuda(), tgt.cuda()
+    slab = torch.empty(int(L.ksr_ssim_slab_floats(c_int(3), c_int(B), c_int(H), c_int(W))), device="cuda")
+    maps = torch.empty(3 * B * (H - 10) * (W - 10), device="cuda")
+    out = torch.zeros(1, device="cuda")
+    plane = H * W
+    check(L.ksr_ssim_fwd(ptr(p), c_int64(3 * plane), ptr(t_), c_int64(3 * plane), c_int(3), c_int(B), c_int(H), c_int(W),
+                         ptr(maps), ptr(slab), ptr(out), stream()), "ssim_fwd")
+    assert abs(float(out) - float(val.detach())) <= 2e-6
+    g = torch.zeros(B, plane, device="cuda")
+    check(L.ksr_ssim_y_grad(ptr(maps), ptr(p), c_int64(3 * plane), ptr(t_), c_int64(3 * plane), ptr(g), c_int64(plane), c_int(B),
+                            c_int(H), c_int(W), c_float(1.0 / (B * 3 * (H - 10) * (W - 10))), stream()), "ssim_grad")
+    ref = pred.grad[:, 0].reshape(B, plane)
+    assert rel_l2(g.cpu(), ref) <= 1e-4
+
+
+def test_train_step_with_ssim_loss_vs_oracle():
+    """TrainStep(loss='l1+ssim') = the reference's training_step loss: loss value and one Adam step against autograd of
+    the oracle (eval mode, so no dropout)."""
+    from kan_sr.module import ConvSepKan
+    from kan_sr.train import TrainStep
+    torch.manual_seed(11)
+    m = ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2).eval()
+    params = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    x, tgt = torch.rand(2, 3, 16, 20), torch.rand(2, 3, 32, 40)
+    p_ref = {n: v.clone().requires_grad_() for n, v in params.items()}
+    y = orc.conv_sep_kan_forward(x, p_ref, out_channels=[4], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=2)
+    loss = orc.training_loss(y, tgt)
+    loss.backward()
+    opt = torch.optim.Adam(list(p_ref.values()), lr=1e-3)
+    before = {n: v.detach().clone() for n, v in p_ref.items()}
+    opt.step()
+    ts = TrainStep(m.cuda(), loss="l1+ssim")
+    got = ts.step(x.cuda(), tgt.cuda())
+    assert abs(float(got) - float(loss)) <= 1e-5
+    for n, prm in m.named_parameters():
+        want = p_ref[n].detach() - before[n]
+        have = prm.detach().cpu() - before[n]
+        # Adam's first step moves every element by ~lr * sign(grad): compare the update direction and size
+        assert (have - want).abs().max() <= 2e-4 * 1e-3 + 0.02 * want.abs().max(), n

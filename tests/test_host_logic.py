@@ -141,3 +141,20 @@ def test_two_rank_gloo_gradient_exchange(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"OK {r}" in o, o[-2000:]
+
+
+def test_cosine_warm_restarts_schedule_matches_torch():
+    """The host-side lr schedule against torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(T_0=500, eta_min=1e-5)
+    (src/ml/pipelines/default.py:66-68)."""
+    import torch
+    from kan_sr.train import cosine_warm_restarts_lr
+    from oracle import convsepkan_oracle as orc
+    prm = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([prm], lr=1e-3)
+    sch = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(opt, T_0=500, T_mult=1, eta_min=1e-5)
+    for epoch in range(1203):
+        want = opt.param_groups[0]["lr"]
+        assert abs(cosine_warm_restarts_lr(1e-3, epoch) - want) <= 1e-12, epoch
+        assert abs(orc.cosine_warm_restarts_lr(1e-3, epoch) - want) <= 1e-12, epoch
+        opt.step()
+        sch.step()
