@@ -210,3 +210,27 @@ def test_train_step_with_ssim_loss_vs_oracle():
         have = prm.detach().cpu() - before[n]
         # Adam's first step moves every element by ~lr * sign(grad): compare the update direction and size
         assert (have - want).abs().max() <= 2e-4 * 1e-3 + 0.02 * want.abs().max(), n
+
+
+def test_training_trajectory_bf16_storage_tracks_fp32():
+    """25 optimisation steps (reference loss, eval-mode graph so that both runs see identical noise-free steps) on a
+    fixed batch: the loss goes down, and the bf16-storage run stays within 3 % of the exact fp32 run."""
+    from kan_sr.module import ConvSepKan
+    from kan_sr.init import init_like_training_setup
+    from kan_sr.train import TrainStep
+    torch.manual_seed(21)
+    x = torch.rand(4, 3, 32, 32, device="cuda")
+    tgt = torch.nn.functional.interpolate(x, scale_factor=2, mode="bicubic").clamp(0, 1)
+    hist = {}
+    for prec in ("fp32", "bf16s"):
+        torch.manual_seed(22)                # same default-initialised in_proj / LayerNorm parameters in both runs
+        m = ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2).eval()
+        init_like_training_setup(m, 0)
+        m = m.cuda()
+        m.precision = prec
+        ts = TrainStep(m, lr=2e-4, loss="l1+ssim")
+        hist[prec] = [float(ts.step(x, tgt)) for _ in range(25)]
+    assert hist["fp32"][-1] < 0.9 * hist["fp32"][0], hist["fp32"]
+    assert hist["bf16s"][-1] < 0.9 * hist["bf16s"][0], hist["bf16s"]
+    for a, b in zip(hist["fp32"], hist["bf16s"]):
+        assert abs(a - b) <= 0.03 * abs(a), (hist["fp32"], hist["bf16s"])
