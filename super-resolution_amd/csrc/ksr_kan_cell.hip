@@ -131,6 +131,113 @@ __global__ void __launch_bounds__(256) kan_cell_bwd_kernel(CellArgs a, KsrKnots 
     }
 }
 
+// ------------------------------------------------------------------------------------------ NHWC fast path
+// w [N, P]: the P parameters of a pixel are contiguous, so one-pixel-per-thread accesses are strided by P.  These
+// kernels stage the [32 pixels][P] block of a workgroup (one contiguous range of w) in LDS with lane-linear 16-byte
+// loads, let 8 threads share a pixel (thread (px, sub) owns outputs o = sub, sub + 8, ...), and in the backward build
+// the gradient block in place in LDS and write it back with lane-linear stores.
+constexpr int NH_TP = 32;          // pixels per workgroup
+constexpr int NH_PAD = 4;          // LDS row padding (floats)
+
+template <int K, bool BWD>
+__global__ void __launch_bounds__(256) kan_cell_nhwc_kernel(CellArgs a, KsrKnots kn) {
+    extern __shared__ __attribute__((aligned(16))) float wt[];      // [NH_TP][P + NH_PAD]
+    __shared__ float t[KSR_MAX_KNOTS];
+    const int tid = threadIdx.x;
+    if (tid < KSR_MAX_KNOTS) t[tid] = kn.t[tid < kn.M ? tid : 0];
+    const int HW = a.H * a.W;
+    const long N = (long)a.B * HW;
+    const long n0 = (long)blockIdx.x * NH_TP;
+    const int npx = (N - n0) < NH_TP ? (int)(N - n0) : NH_TP;
+    const int P = a.P, LD = P + NH_PAD, P4 = P / 4;
+    // stage the block (P is a multiple of 4: checked by the host)
+    const float4* src = reinterpret_cast<const float4*>(a.w + n0 * P);
+    for (int i = tid; i < npx * P4; i += 256) {
+        const int r = i / P4, q = i - r * P4;
+        *reinterpret_cast<float4*>(wt + r * LD + 4 * q) = src[i];
+    }
+    __syncthreads();
+    const int px = tid >> 3, sub = tid & 7;
+    const long n = n0 + px;
+    const bool live = px < npx;
+    const int b = live ? (int)(n / HW) : 0, hw = live ? (int)(n % HW) : 0;
+    const int h = hw / a.W, wx = hw % a.W;
+    float* row = wt + px * LD;
+    const int uw_off = a.O * a.I * a.Kc, rw_off = uw_off + a.O * a.I;
+    for (int i = 0; i < a.I; ++i) {
+        const float x = live ? a.x[((long)b * a.I + i) * HW + hw] : 0.f;
+        float Nv[K + 1], dN[K + 1];
+        const int m = ksr_bspline_local<K, BWD>(x, t, kn.M, Nv, dN);
+        const float sg = ksr_sigmoid(x);
+        const float sl = x * sg;
+        const float dsl = sg * (1.f + x * (1.f - sg));
+        float gxi = 0.f;
+        for (int o = sub; o < a.O; o += 8) {
+            float* cf = row + (o * a.I + i) * a.Kc;
+            const float uw = row[uw_off + o * a.I + i], rw = row[rw_off + o * a.I + i];
+            float S = 0.f, dS = 0.f;
+            if (m >= 0) {
+#pragma unroll
+                for (int q = 0; q <= K; ++q) {
+                    const int g = m - K + q;
+                    if (g >= 0 && g < a.Kc) { S += Nv[q] * cf[g]; if (BWD) dS += dN[q] * cf[g]; }
+                }
+            }
+            if (!BWD) {
+                if (live) {
+                    // accumulate over i in the output (I > 1 is rare: read-modify-write of this thread's own element)
+                    const long oi = out_index(a, b, o, h, wx);
+                    const float v = rw * sl + uw * S;
+                    a.out[oi] = (i == 0) ? v : a.out[oi] + v;
+                }
+            } else {
+                const float go = live ? a.gout[out_index(a, b, o, h, wx)] : 0.f;
+                for (int g = 0; g < a.Kc; ++g) {
+                    float bg = 0.f;
+                    if (m >= 0) {
+#pragma unroll
+                        for (int q = 0; q <= K; ++q) if (g == m - K + q) bg = Nv[q];
+                    }
+                    cf[g] = go * uw * bg;
+                }
+                row[uw_off + o * a.I + i] = go * S;
+                row[rw_off + o * a.I + i] = go * sl;
+                gxi += go * (rw * dsl + uw * dS);
+            }
+        }
+        if (BWD && a.gx) {
+            gxi += __shfl_xor(gxi, 1, 64); gxi += __shfl_xor(gxi, 2, 64); gxi += __shfl_xor(gxi, 4, 64);
+            if (live && sub == 0) a.gx[((long)b * a.I + i) * HW + hw] = gxi;
+        }
+    }
+    if (BWD) {
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(a.gw + n0 * P);
+        for (int i = tid; i < npx * P4; i += 256) {
+            const int r = i / P4, q = i - r * P4;
+            dst[i] = *reinterpret_cast<const float4*>(wt + r * LD + 4 * q);
+        }
+    }
+}
+
+template <int K>
+int launch_cell_nhwc(bool bwd, const CellArgs& a, const KsrKnots& kn, hipStream_t s) {
+    const long n = (long)a.B * a.H * a.W;
+    const size_t lds = (size_t)NH_TP * (a.P + NH_PAD) * sizeof(float);
+    const dim3 grid((unsigned)((n + NH_TP - 1) / NH_TP)), block(256);
+    if (bwd) {
+        static bool set_b = false;
+        if (!set_b) { (void)hipFuncSetAttribute((const void*)kan_cell_nhwc_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); set_b = true; }
+        hipLaunchKernelGGL((kan_cell_nhwc_kernel<K, true>), grid, block, lds, s, a, kn);
+    } else {
+        static bool set_f = false;
+        if (!set_f) { (void)hipFuncSetAttribute((const void*)kan_cell_nhwc_kernel<K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); set_f = true; }
+        hipLaunchKernelGGL((kan_cell_nhwc_kernel<K, false>), grid, block, lds, s, a, kn);
+    }
+    KSR_LAUNCH_CHECK("kan_cell(nhwc)");
+    return KSR_OK;
+}
+
 // ------------------------------------------------------------------------------------------ bilinear
 // out[b, oc0 + c, :, :] = bilinear_up(in[b, ic0 + c, :, :], r), c < nc.  align_corners = false.
 struct BilArgs {
@@ -234,6 +341,17 @@ int cell_common(bool bwd, CellArgs& a, const float* knots, int n_knots, int k, h
     KsrKnots kn;
     int rc = fill_knots(kn, knots, n_knots, k, a.Kc);
     if (rc) return rc;
+    // NHWC parameter tensors go through the LDS-staged kernels when a 32-pixel block fits (P <= ~980)
+    const bool staged = a.w_nhwc && a.P % 4 == 0 && (size_t)NH_TP * (a.P + NH_PAD) * sizeof(float) <= 128 * 1024 &&
+                        (reinterpret_cast<uintptr_t>(a.w) & 15) == 0 && (!bwd || (reinterpret_cast<uintptr_t>(a.gw) & 15) == 0);
+    if (staged) {
+        switch (k) {
+            case 0: return launch_cell_nhwc<0>(bwd, a, kn, s);
+            case 1: return launch_cell_nhwc<1>(bwd, a, kn, s);
+            case 2: return launch_cell_nhwc<2>(bwd, a, kn, s);
+            default: return launch_cell_nhwc<3>(bwd, a, kn, s);
+        }
+    }
     switch (k) {
         case 0: return launch_cell<0>(bwd, a, kn, s);
         case 1: return launch_cell<1>(bwd, a, kn, s);
