@@ -75,7 +75,7 @@ def _declare(L: ctypes.CDLL) -> None:
     L.ksr_ssim_slab_floats.restype = c_int64
 
 
-# every symbol include/ksr.h declares (checked by tests/test_abi_symbols.py)
+# every symbol include/ksr.h declares (tests/test_host_logic.py compares the two lists)
 EXPORTS = [
     "ksr_version", "ksr_last_error", "ksr_set_precision", "ksr_get_precision",
     "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",

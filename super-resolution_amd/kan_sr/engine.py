@@ -1,8 +1,8 @@
 """Launch sequences for the ConvSepKAN hot path: which kernel runs when, on which buffers.
 
-All activations between kernels are NHWC fp32 ([B*H*W, C]).  `forward_infer` is the no-grad
-path; the training path (forward that keeps what the backward needs + the backward itself) lives
-in `train_forward` / `train_backward` and is wrapped by one torch.autograd.Function in module.py.
+All activations between kernels are NHWC ([B*H*W, C]; fp32, or bf16 in the "bf16s" precision mode).
+`forward_infer` is the no-grad path; `encoder_forward(saves=...)` is the forward that keeps what the backward
+needs, and the backward itself lives in autograd.py (one torch.autograd.Function) and train.py (native step).
 """
 from __future__ import annotations
 
