@@ -124,9 +124,11 @@ __device__ __forceinline__ unsigned ksr_attn_drop_base(unsigned long long seed, 
     const unsigned s32 = (unsigned)seed * 0x9E3779B1u ^ (unsigned)(seed >> 32) * 0x85EBCA77u ^ 0x27D4EB2Fu;
     return ksr_hash32((unsigned)idx * 0x9E3779B1u ^ (unsigned)(idx >> 32) * 0x85EBCA77u ^ s32);
 }
+// One hash serves two neighbouring keys (16 bits each): the keep probability is quantised to 1/65536.
 __device__ __forceinline__ bool ksr_attn_keep(unsigned base, int key_b, float keep) {
-    const unsigned x = ksr_hash32(base + (unsigned)key_b * 0x9E3779B1u);
-    return (float)(x >> 8) * (1.0f / 16777216.0f) < keep;
+    const unsigned x = ksr_hash32(base + (unsigned)(key_b >> 1) * 0x9E3779B1u);
+    const unsigned half = (key_b & 1) ? (x >> 16) : (x & 0xffffu);
+    return half < (unsigned)(keep * 65536.0f);
 }
 
 __device__ __forceinline__ float ksr_silu(float x) { return x / (1.f + expf(-x)); }

@@ -103,6 +103,29 @@ def bench_pointwise():
         report(f"pointwise_bwd[{n_out}->64]", timeit(run), N * 4 * (64 + n_out))
 
 
+def bench_attn():
+    from kan_sr import engine
+    L = lib()
+    S, HW = 64, 128 * 128
+    N = S * HW
+    dt = engine.act_dtype()
+    qkv = torch.randn(N, 192, device="cuda").to(dt)
+    dctx = torch.randn(N, 64, device="cuda").to(dt)
+    ctx = torch.empty(N, 64, device="cuda", dtype=dt)
+    dqkv = torch.empty(N, 192, device="cuda", dtype=dt)
+    esz = qkv.element_size()
+    from ctypes import c_float, c_uint64
+    for p_drop in (0.0, 0.1):
+        def fwd():
+            check(L.ksr_batch_attn_fwd(ptr(qkv), ptr(ctx), c_int(S), c_int(HW), c_float(p_drop), c_uint64(5), stream()), "fwd")
+
+        def bwd():
+            check(L.ksr_batch_attn_bwd(ptr(qkv), ptr(ctx), ptr(dctx), ptr(dqkv), c_int(S), c_int(HW), c_float(p_drop), c_uint64(5),
+                                       stream()), "bwd")
+        report(f"attn_fwd[S=64,p={p_drop}]", timeit(fwd), N * esz * (192 + 64))
+        report(f"attn_bwd[S=64,p={p_drop}]", timeit(bwd), N * esz * (192 + 64 + 64 + 192))
+
+
 def bench_gram():
     L = lib()
     B, HW = 64, 128 * 128
@@ -122,6 +145,6 @@ def bench_gram():
 if __name__ == "__main__":
     from kan_sr import engine
     engine.set_precision(os.environ.get("KSR_PRECISION", "fp32"))
-    which = sys.argv[1:] or ["kan_cell", "wgrad", "gram", "pointwise"]
+    which = sys.argv[1:] or ["kan_cell", "wgrad", "gram", "pointwise", "attn"]
     for w in which:
         globals()["bench_" + w]()
