@@ -176,11 +176,11 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
     const int kbase0 = (Sp >= 32) ? pl * Sp : wv * 32;
     int lg = 0;
     while ((1 << lg) < Sp) ++lg;
-    const SlotMap smap{Sp, lg, Sp >= 32};
+    const SlotMap smap{Sp, lg, NW > 1 ? 1 : (Sp >= 32)};     // more than one block per query implies Sp >= 64
     float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const RowMap rm{Sp, lg, Sp >= 32, S, HW, wv, (wv * 32) / Sp, (wv * 32) % Sp, tile, PPW};
+        const RowMap rm{Sp, lg, NW > 1 ? true : (Sp >= 32), S, HW, wv, (wv * 32) / Sp, (wv * 32) % Sp, tile, PPW};
         const int p = tile * PPW + pl;
         const bool live = (b < S) && (p < HW);
         const long n = live ? ((long)b * HW + p) : 0;
@@ -294,11 +294,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
     const int base0 = (Sp >= 32) ? pl * Sp : wv * 32;
     int lg = 0;
     while ((1 << lg) < Sp) ++lg;
-    const SlotMap smap{Sp, lg, Sp >= 32};
+    const SlotMap smap{Sp, lg, NW > 1 ? 1 : (Sp >= 32)};     // more than one block per query implies Sp >= 64
     float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const RowMap rm{Sp, lg, Sp >= 32, S, HW, wv, (wv * 32) / Sp, (wv * 32) % Sp, tile, PPW};
+        const RowMap rm{Sp, lg, NW > 1 ? true : (Sp >= 32), S, HW, wv, (wv * 32) / Sp, (wv * 32) % Sp, tile, PPW};
         const int p = tile * PPW + pl;
         const bool live = (b < S) && (p < HW);
         const long n = live ? ((long)b * HW + p) : 0;
@@ -333,16 +333,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
 
 #pragma unroll 1
         for (int X = 0; X < 2; ++X) {
-            // this head's operands (selected by value: the loop is not unrolled, to bound register pressure)
-            bf16x8 qx[2], kx[2], vx[2], dox[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                qx[s] = X ? qb[1][s] : qb[0][s];
-                kx[s] = X ? kb_[1][s] : kb_[0][s];
-                vx[s] = X ? vb[1][s] : vb[0][s];
-                dox[s] = X ? dob[1][s] : dob[0][s];
-            }
-            const float DX = X ? D[1] : D[0];
+            // this head's operands sit in slot 0: head 1 moves down at the end of the first pass, so that the
+            // (not unrolled) loop body needs no second copy of them
+            bf16x8 (&qx)[2] = qb[0], (&kx)[2] = kb_[0], (&vx)[2] = vb[0], (&dox)[2] = dob[0];
+            const float DX = D[0];
             // ---------------- phase A: this lane is a query; LDS holds K rows, V rows, K^T ----------------
             __syncthreads();
             put_rows(sm.rowA, slot, g, kx);
@@ -430,6 +424,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                 store_dims32<ST>(xb, a.dqkv, rm, 192, 64 + 32 * X, lane, dk, 1.f);
                 store_dims32<ST>(xb, a.dqkv, rm, 192, 128 + 32 * X, lane, dv, 1.f);
             }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) { qb[0][s] = qb[1][s]; kb_[0][s] = kb_[1][s]; vb[0][s] = vb[1][s]; dob[0][s] = dob[1][s]; }
+            D[0] = D[1];
         }
     }
 }
