@@ -38,7 +38,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnArgs a) {
     const int kbase0 = (Sp >= 32) ? pl * Sp : wv * 32;       // first key slot of this lane's key blocks
     int lg = 0;
     while ((1 << lg) < Sp) ++lg;
-    const SlotMap smap{Sp, lg, Sp >= 32};
+    const SlotMap smap{Sp, lg, NW > 1 ? 1 : (Sp >= 32)};     // more than one block per query implies Sp >= 64
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int p = tile * PPW + pl;
@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnBwdArgs a) {
     const int base0 = (Sp >= 32) ? pl * Sp : wv * 32;     // first slot of this lane's key / query blocks
     int lg = 0;
     while ((1 << lg) < Sp) ++lg;
-    const SlotMap smap{Sp, lg, Sp >= 32};
+    const SlotMap smap{Sp, lg, NW > 1 ? 1 : (Sp >= 32)};     // more than one block per query implies Sp >= 64
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int p = tile * PPW + pl;

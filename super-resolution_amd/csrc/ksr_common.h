@@ -124,6 +124,14 @@ __device__ __forceinline__ unsigned ksr_attn_drop_base(unsigned long long seed, 
     const unsigned s32 = (unsigned)seed * 0x9E3779B1u ^ (unsigned)(seed >> 32) * 0x85EBCA77u ^ 0x27D4EB2Fu;
     return ksr_hash32((unsigned)idx * 0x9E3779B1u ^ (unsigned)(idx >> 32) * 0x85EBCA77u ^ s32);
 }
+// Workgroups are handed to the 8 XCDs round-robin and every XCD has its own L2.  Maps the hardware workgroup index to
+// a logical index such that each XCD works through one contiguous range of [0, total): neighbouring tiles, which
+// share halo rows and cache lines, then share an L2.
+__device__ __forceinline__ unsigned ksr_xcd_contiguous(unsigned wg, unsigned total) {
+    const unsigned per = total >> 3, rem = total & 7u, xcd = wg & 7u, slot = wg >> 3;
+    return xcd < rem ? xcd * (per + 1) + slot : rem * (per + 1) + (xcd - rem) * per + slot;
+}
+
 // One hash serves two neighbouring keys (16 bits each): the keep probability is quantised to 1/65536.
 __device__ __forceinline__ bool ksr_attn_keep(unsigned base, int key_b, float keep) {
     const unsigned x = ksr_hash32(base + (unsigned)(key_b >> 1) * 0x9E3779B1u);

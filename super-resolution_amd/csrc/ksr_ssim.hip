@@ -12,11 +12,14 @@
 // with the same window and combines them with p and t.
 #include "ksr_common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int SS_K = 11, SS_R = 5, SS_T = 32, SS_IN = SS_T + SS_K - 1;   // 42
 
 struct SsimWin { float g[SS_K]; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct SsimArgs {
     const float* pred; long pred_bs;     // [B, C, H, W] with images pred_bs elements apart
@@ -28,74 +31,139 @@ struct SsimArgs {
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
+// Both filter passes hand one thread a run of SS_RUN outputs along the filter direction: the SS_RUN + 10 inputs of
+// the run are read from LDS once and slide through registers (2.25 LDS reads per output and quantity, not 11).
+constexpr int SS_GRID = 256 * 3;       // persistent workgroups: three fit a CU (LDS)
+constexpr int SS_RUN = 8, SS_RUNS = SS_T / SS_RUN, SS_SPAN = SS_RUN + SS_K - 1;   // 4 runs, 18 inputs each
+
 __global__ void __launch_bounds__(256) ssim_fwd_kernel(SsimArgs a, SsimWin w) {
     __shared__ float ps[SS_IN][SS_IN + 1], ts[SS_IN][SS_IN + 1];
     __shared__ float hs[5][SS_IN][SS_T + 1];
     __shared__ float red[4];
     const int Hi = a.H - 2 * SS_R, Wi = a.W - 2 * SS_R;
     const int tiles_x = (Wi + SS_T - 1) / SS_T;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int c = blockIdx.y, b = blockIdx.z;
-    const int y0 = ty * SS_T, x0 = tx * SS_T;                  // first window of the tile = first pixel it reads
+    const int tiles = tiles_x * ((Hi + SS_T - 1) / SS_T), total = tiles * a.C * a.B;
+    // Persistent workgroups: each takes one contiguous range of (tile, channel, image) indices, tile fastest, and the
+    // ranges of one XCD are neighbours.  The next tile's pixels are fetched into registers while this one is filtered.
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = (int)ksr_xcd_contiguous(blockIdx.x, gridDim.x) * chunk, t_end = min(total, t_begin + chunk);
     const long plane = (long)a.H * a.W;
-    const float* P = a.pred + (long)b * a.pred_bs + (long)c * plane;
-    const float* T = a.tgt + (long)b * a.tgt_bs + (long)c * plane;
-    for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
-        const int r = i / SS_IN, q = i - r * SS_IN;
-        const int y = y0 + r, x = x0 + q;
-        const bool in = y < a.H && x < a.W;
-        ps[r][q] = in ? clamp01(P[(long)y * a.W + x]) : 0.f;
-        ts[r][q] = in ? clamp01(T[(long)y * a.W + x]) : 0.f;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < SS_IN * SS_T; i += 256) {
-        const int r = i / SS_T, q = i - r * SS_T;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    constexpr int NIT = (SS_IN + 3) / 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float pv[NIT], tv[NIT];
+    // wave v loads rows v, v + 4, ... (lane = column): all loads of a tile are in flight together
+    auto fetch = [&](int t) {
+        const int tile = t % tiles, c = (t / tiles) % a.C, b = t / (tiles * a.C);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * SS_T, x0 = tx * SS_T;
+        const float* P = a.pred + (long)b * a.pred_bs + (long)c * plane;
+        const float* T = a.tgt + (long)b * a.tgt_bs + (long)c * plane;
+        const bool col_in = lane < SS_IN && x0 + lane < a.W;
+        const long first = (long)(y0 + wv) * a.W + x0 + lane;
 #pragma unroll
-        for (int k = 0; k < SS_K; ++k) {
-            const float p = ps[r][q + k], t = ts[r][q + k], g = w.g[k];
-            s0 += g * p; s1 += g * t; s2 += g * p * p; s3 += g * t * t; s4 += g * p * t;
+        for (int it = 0; it < NIT; ++it) {
+            const int r = wv + 4 * it;
+            const bool in = col_in && r < SS_IN && y0 + r < a.H;
+            pv[it] = in ? P[first + (long)(4 * it) * a.W] : 0.f;
+            tv[it] = in ? T[first + (long)(4 * it) * a.W] : 0.f;
         }
-        hs[0][r][q] = s0; hs[1][r][q] = s1; hs[2][r][q] = s2; hs[3][r][q] = s3; hs[4][r][q] = s4;
-    }
-    __syncthreads();
+    };
     const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
     float sum = 0.f;
-    for (int i = threadIdx.x; i < SS_T * SS_T; i += 256) {
-        const int r = i / SS_T, q = i - r * SS_T;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    if (t_begin < t_end) fetch(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+    const int tile = t % tiles, c = (t / tiles) % a.C, b = t / (tiles * a.C);
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    // the filter passes keep only the first waves busy: rotating the wave numbering with the tile index spreads that
+    // work over the four SIMDs of a CU, which holds several workgroups at a time
+    const int tid = (threadIdx.x + 64 * (t & 3)) & 255;
+    const int y0 = ty * SS_T, x0 = tx * SS_T;                  // first window of the tile = first pixel it reads
+    // ps / ts were last read before the barrier that follows the row pass of the previous tile
 #pragma unroll
-        for (int k = 0; k < SS_K; ++k) {
-            const float g = w.g[k];
-            m1 += g * hs[0][r + k][q]; m2 += g * hs[1][r + k][q]; e11 += g * hs[2][r + k][q];
-            e22 += g * hs[3][r + k][q]; e12 += g * hs[4][r + k][q];
+    for (int it = 0; it < NIT; ++it) {
+        const int r = wv + 4 * it;
+        if (lane < SS_IN && r < SS_IN) { ps[r][lane] = clamp01(pv[it]); ts[r][lane] = clamp01(tv[it]); }
+    }
+    if (t + 1 < t_end) fetch(t + 1);
+    __syncthreads();
+    // rows: item = (run j, row r), r fastest.  Sums are kept as (p, t), (pp, tt) pairs and pt: packed fp32 FMAs.
+    if (tid < SS_RUNS * SS_IN) {
+        const int j = tid / SS_IN, r = tid - j * SS_IN, q0 = j * SS_RUN;
+        f32x2 sa[SS_RUN], sb[SS_RUN];
+        float sc[SS_RUN];
+#pragma unroll
+        for (int o = 0; o < SS_RUN; ++o) { sa[o] = f32x2{0.f, 0.f}; sb[o] = f32x2{0.f, 0.f}; sc[o] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < SS_SPAN; ++i) {
+            const f32x2 x = {ps[r][q0 + i], ts[r][q0 + i]};
+            const f32x2 xx = x * x;
+            const float pt = x[0] * x[1];
+#pragma unroll
+            for (int o = 0; o < SS_RUN; ++o) {
+                if (i - o < 0 || i - o >= SS_K) continue;
+                const float g = w.g[i - o];
+                sa[o] += g * x; sb[o] += g * xx; sc[o] += g * pt;
+            }
         }
-        const int uy = y0 + r, ux = x0 + q;
-        if (uy >= Hi || ux >= Wi) continue;
-        const float vp_raw = e11 - m1 * m1, vt_raw = e22 - m2 * m2;
-        const float vp = fmaxf(vp_raw, 0.f), vt = fmaxf(vt_raw, 0.f);
-        const float cov = e12 - m1 * m2;
-        const float N1 = 2.f * m1 * m2 + c1, D1 = m1 * m1 + m2 * m2 + c1;
-        const float N2 = 2.f * cov + c2, D2 = vp + vt + c2;
-        const float inv = 1.f / (D1 * D2);
-        const float S = N1 * N2 * inv;
-        sum += S;
-        if (a.maps && c == 0) {
-            const float vp_on = vp_raw > 0.f ? 1.f : 0.f;              // derivative of the clamp at 0
-            const float dC = 2.f * N1 * inv;                            // dS/dE[pt]
-            const float dB = -S / D2 * vp_on;                           // dS/dE[p^2]
-            const float dA = (2.f * m2 * N2 - 2.f * m2 * N1) * inv - S * (2.f * m1) / D1 + S * (2.f * m1) / D2 * vp_on;
-            const long mi = ((long)b * Hi + uy) * Wi + ux;
-            const long ms = (long)a.B * Hi * Wi;
-            a.maps[mi] = dA; a.maps[ms + mi] = dB; a.maps[2 * ms + mi] = dC;
+#pragma unroll
+        for (int o = 0; o < SS_RUN; ++o) {
+            hs[0][r][q0 + o] = sa[o][0]; hs[1][r][q0 + o] = sa[o][1]; hs[2][r][q0 + o] = sb[o][0];
+            hs[3][r][q0 + o] = sb[o][1]; hs[4][r][q0 + o] = sc[o];
         }
     }
+    __syncthreads();
+    // columns: item = (run j, column q), q fastest
+    if (tid < SS_RUNS * SS_T) {
+        const int j = tid / SS_T, q = tid - j * SS_T, r0 = j * SS_RUN;
+        f32x2 sa[SS_RUN], sb[SS_RUN];
+        float sc[SS_RUN];
+#pragma unroll
+        for (int o = 0; o < SS_RUN; ++o) { sa[o] = f32x2{0.f, 0.f}; sb[o] = f32x2{0.f, 0.f}; sc[o] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < SS_SPAN; ++i) {
+            const f32x2 va = {hs[0][r0 + i][q], hs[1][r0 + i][q]}, vb = {hs[2][r0 + i][q], hs[3][r0 + i][q]};
+            const float vc = hs[4][r0 + i][q];
+#pragma unroll
+            for (int o = 0; o < SS_RUN; ++o) {
+                if (i - o < 0 || i - o >= SS_K) continue;
+                const float g = w.g[i - o];
+                sa[o] += g * va; sb[o] += g * vb; sc[o] += g * vc;
+            }
+        }
+        const int ux = x0 + q;
+#pragma unroll
+        for (int o = 0; o < SS_RUN; ++o) {
+            const int uy = y0 + r0 + o;
+            if (uy >= Hi || ux >= Wi) continue;
+            const float m1 = sa[o][0], m2 = sa[o][1], e11 = sb[o][0], e22 = sb[o][1], e12 = sc[o];
+            const float vp_raw = e11 - m1 * m1, vt_raw = e22 - m2 * m2;
+            const float vp = fmaxf(vp_raw, 0.f), vt = fmaxf(vt_raw, 0.f);
+            const float cov = e12 - m1 * m2;
+            const float N1 = 2.f * m1 * m2 + c1, D1 = m1 * m1 + m2 * m2 + c1;
+            const float N2 = 2.f * cov + c2, D2 = vp + vt + c2;
+            // hardware reciprocals (1 ulp) instead of four IEEE divisions per window
+            const float i1 = __builtin_amdgcn_rcpf(D1), i2 = __builtin_amdgcn_rcpf(D2);
+            const float inv = i1 * i2;
+            const float S = N1 * N2 * inv;
+            sum += S;
+            if (a.maps && c == 0) {
+                const float vp_on = vp_raw > 0.f ? 1.f : 0.f;              // derivative of the clamp at 0
+                const float dC = 2.f * N1 * inv;                            // dS/dE[pt]
+                const float dB = -S * i2 * vp_on;                           // dS/dE[p^2]
+                const float dA = 2.f * m2 * (N2 - N1) * inv - 2.f * m1 * S * (i1 - i2 * vp_on);
+                const long mi = ((long)b * Hi + uy) * Wi + ux;
+                const long ms = (long)a.B * Hi * Wi;
+                a.maps[mi] = dA; a.maps[ms + mi] = dB; a.maps[2 * ms + mi] = dC;
+            }
+        }
+    }
+    }   // tiles
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0)
-        a.slab[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+        a.slab[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 // One workgroup: strided partial sums in double, then a fixed-order tree (deterministic).
@@ -127,48 +195,96 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin 
     __shared__ float hs[3][SS_IN][SS_T + 1];
     const int Hi = a.H - 2 * SS_R, Wi = a.W - 2 * SS_R;
     const int tiles_x = (a.W + SS_T - 1) / SS_T;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int b = blockIdx.z;
-    const int py0 = ty * SS_T, px0 = tx * SS_T;
+    const int tiles = tiles_x * ((a.H + SS_T - 1) / SS_T), total = tiles * a.B;
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;          // persistent, as in ssim_fwd_kernel
+    const int t_begin = (int)ksr_xcd_contiguous(blockIdx.x, gridDim.x) * chunk, t_end = min(total, t_begin + chunk);
     const long msz = (long)a.B * Hi * Wi;
+    constexpr int NIT = (SS_IN + 3) / 4;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float mv[NIT][3];
     // local index j <-> window u = p0 - 10 + j; pixel x = p0 + q is covered by windows j = q .. q + 10
-    for (int i = threadIdx.x; i < SS_IN * SS_IN; i += 256) {
-        const int r = i / SS_IN, q = i - r * SS_IN;
-        const int uy = py0 - (SS_K - 1) + r, ux = px0 - (SS_K - 1) + q;
-        const bool in = uy >= 0 && uy < Hi && ux >= 0 && ux < Wi;
-        const long mi = ((long)b * Hi + uy) * Wi + ux;
+    auto fetch = [&](int t) {
+        const int tile = t % tiles, b = t / tiles;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int ux = tx * SS_T - (SS_K - 1) + lane, uy0 = ty * SS_T - (SS_K - 1) + wv;
+        const bool col_in = lane < SS_IN && ux >= 0 && ux < Wi;
+        const long first = ((long)b * Hi + uy0) * Wi + ux;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) ms[m][r][q] = in ? a.maps[m * msz + mi] : 0.f;
+        for (int it = 0; it < NIT; ++it) {
+            const int r = wv + 4 * it, uy = uy0 + 4 * it;
+            const bool in = col_in && r < SS_IN && uy >= 0 && uy < Hi;
+#pragma unroll
+            for (int m = 0; m < 3; ++m) mv[it][m] = in ? a.maps[m * msz + first + (long)(4 * it) * Wi] : 0.f;
+        }
+    };
+    if (t_begin < t_end) fetch(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+    const int tile = t % tiles, b = t / tiles;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int tid = (threadIdx.x + 64 * (t & 3)) & 255;     // see ssim_fwd_kernel
+    const int py0 = ty * SS_T, px0 = tx * SS_T;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int r = wv + 4 * it;
+        if (lane < SS_IN && r < SS_IN) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) ms[m][r][lane] = mv[it][m];
+        }
     }
+    if (t + 1 < t_end) fetch(t + 1);
     __syncthreads();
     // pixel x sits at tap k = x - u of window u: weight g[k] = g[10 - k] (symmetric), so the sums below are plain
     // sliding sums over the 11 windows j = q .. q + 10
-    for (int i = threadIdx.x; i < SS_IN * SS_T; i += 256) {
-        const int r = i / SS_T, q = i - r * SS_T;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if (tid < SS_RUNS * SS_IN) {
+        const int j = tid / SS_IN, r = tid - j * SS_IN, q0 = j * SS_RUN;
+        f32x2 sa[SS_RUN];
+        float sc[SS_RUN];
 #pragma unroll
-        for (int k = 0; k < SS_K; ++k) {
-            const float g = w.g[SS_K - 1 - k];
-            s0 += g * ms[0][r][q + k]; s1 += g * ms[1][r][q + k]; s2 += g * ms[2][r][q + k];
+        for (int o = 0; o < SS_RUN; ++o) { sa[o] = f32x2{0.f, 0.f}; sc[o] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < SS_SPAN; ++i) {
+            const f32x2 va = {ms[0][r][q0 + i], ms[1][r][q0 + i]};
+            const float vc = ms[2][r][q0 + i];
+#pragma unroll
+            for (int o = 0; o < SS_RUN; ++o) {
+                if (i - o < 0 || i - o >= SS_K) continue;
+                const float g = w.g[SS_K - 1 - (i - o)];
+                sa[o] += g * va; sc[o] += g * vc;
+            }
         }
-        hs[0][r][q] = s0; hs[1][r][q] = s1; hs[2][r][q] = s2;
+#pragma unroll
+        for (int o = 0; o < SS_RUN; ++o) { hs[0][r][q0 + o] = sa[o][0]; hs[1][r][q0 + o] = sa[o][1]; hs[2][r][q0 + o] = sc[o]; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SS_T * SS_T; i += 256) {
-        const int r = i / SS_T, q = i - r * SS_T;
-        const int y = py0 + r, x = px0 + q;
-        if (y >= a.H || x >= a.W) continue;
-        float gA = 0.f, gB = 0.f, gC = 0.f;
+    if (tid < SS_RUNS * SS_T) {
+        const int j = tid / SS_T, q = tid - j * SS_T, r0 = j * SS_RUN;
+        f32x2 sa[SS_RUN];
+        float sc[SS_RUN];
 #pragma unroll
-        for (int k = 0; k < SS_K; ++k) {
-            const float g = w.g[SS_K - 1 - k];
-            gA += g * hs[0][r + k][q]; gB += g * hs[1][r + k][q]; gC += g * hs[2][r + k][q];
+        for (int o = 0; o < SS_RUN; ++o) { sa[o] = f32x2{0.f, 0.f}; sc[o] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < SS_SPAN; ++i) {
+            const f32x2 va = {hs[0][r0 + i][q], hs[1][r0 + i][q]};
+            const float vc = hs[2][r0 + i][q];
+#pragma unroll
+            for (int o = 0; o < SS_RUN; ++o) {
+                if (i - o < 0 || i - o >= SS_K) continue;
+                const float g = w.g[SS_K - 1 - (i - o)];
+                sa[o] += g * va; sc[o] += g * vc;
+            }
         }
-        const long off = (long)y * a.W + x;
-        const float p = a.pred[(long)b * a.pred_bs + off], t = clamp01(a.tgt[(long)b * a.tgt_bs + off]);
-        const float inside = (p >= 0.f && p <= 1.f) ? 1.f : 0.f;
-        a.grad[(long)b * a.grad_bs + off] += a.scale * inside * (gA + 2.f * clamp01(p) * gB + t * gC);
+        const int x = px0 + q;
+#pragma unroll
+        for (int o = 0; o < SS_RUN; ++o) {
+            const int y = py0 + r0 + o;
+            if (y >= a.H || x >= a.W) continue;
+            const long off = (long)y * a.W + x;
+            const float p = a.pred[(long)b * a.pred_bs + off], tg = clamp01(a.tgt[(long)b * a.tgt_bs + off]);
+            const float inside = (p >= 0.f && p <= 1.f) ? 1.f : 0.f;
+            a.grad[(long)b * a.grad_bs + off] += a.scale * inside * (sa[o][0] + 2.f * clamp01(p) * sa[o][1] + tg * sc[o]);
+        }
     }
+    }   // tiles
 }
 
 int fill_window(SsimWin& w) {
@@ -197,15 +313,16 @@ extern "C" int ksr_ssim_fwd(const float* pred, int64_t pred_batch_stride, const 
                             int B, int H, int W, float* maps, float* slab, float* ssim_out, hipStream_t stream) {
     KSR_CHECK_ARG(pred && tgt && slab && ssim_out && C > 0 && B > 0, "ssim_fwd: bad argument");
     KSR_CHECK_ARG(H > 2 * SS_R && W > 2 * SS_R, "ssim_fwd: the image must be larger than the 11 x 11 window");
-    KSR_CHECK_ARG(B <= 65535 && C <= 65535, "ssim_fwd: too many images / channels");
     SsimWin w;
     fill_window(w);
     SsimArgs a{pred, (long)pred_batch_stride, tgt, (long)tgt_batch_stride, maps, slab, C, B, H, W};
     const int Hi = H - 2 * SS_R, Wi = W - 2 * SS_R;
     const unsigned tiles = (unsigned)(((Hi + SS_T - 1) / SS_T) * ((Wi + SS_T - 1) / SS_T));
-    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(tiles, C, B), dim3(256), 0, stream, a, w);
+    KSR_CHECK_ARG((long)tiles * C * B < (1L << 31), "ssim_fwd: too many tiles for one launch");
+    const unsigned grid = (unsigned)std::min<long>((long)tiles * C * B, SS_GRID);
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(grid), dim3(256), 0, stream, a, w);
     KSR_LAUNCH_CHECK("ssim_fwd");
-    hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, slab, (long)tiles * C * B,
+    hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, slab, (long)grid,
                        1.0 / ((double)B * C * Hi * Wi), ssim_out);
     KSR_LAUNCH_CHECK("ssim_fwd(finish)");
     return KSR_OK;
@@ -216,13 +333,14 @@ extern "C" int ksr_ssim_fwd(const float* pred, int64_t pred_batch_stride, const 
 extern "C" int ksr_ssim_y_grad(const float* maps, const float* pred, int64_t pred_batch_stride, const float* tgt,
                                int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W,
                                float scale, hipStream_t stream) {
-    KSR_CHECK_ARG(maps && pred && tgt && grad && B > 0 && B <= 65535, "ssim_y_grad: bad argument");
+    KSR_CHECK_ARG(maps && pred && tgt && grad && B > 0, "ssim_y_grad: bad argument");
     KSR_CHECK_ARG(H > 2 * SS_R && W > 2 * SS_R, "ssim_y_grad: the image must be larger than the 11 x 11 window");
     SsimWin w;
     fill_window(w);
     SsimGradArgs a{maps, pred, (long)pred_batch_stride, tgt, (long)tgt_batch_stride, grad, (long)grad_batch_stride, B, H, W, scale};
     const unsigned tiles = (unsigned)(((H + SS_T - 1) / SS_T) * ((W + SS_T - 1) / SS_T));
-    hipLaunchKernelGGL(ssim_grad_kernel, dim3(tiles, 1, B), dim3(256), 0, stream, a, w);
+    KSR_CHECK_ARG((long)tiles * B < (1L << 31), "ssim_y_grad: too many tiles for one launch");
+    hipLaunchKernelGGL(ssim_grad_kernel, dim3(tiles * B), dim3(256), 0, stream, a, w);
     KSR_LAUNCH_CHECK("ssim_y_grad");
     return KSR_OK;
 }

@@ -142,6 +142,29 @@ def bench_gram():
         report(f"gram_batched[J={J}]", timeit(run), N * 4 * (J + 64))
 
 
+def bench_ssim():
+    """SSIM forward (3 planes, with derivative maps) and luma gradient on 64 images of 512 x 512."""
+    from ctypes import c_float
+    L = lib()
+    B, C, H, W = 64, 3, 512, 512
+    dev = torch.device("cuda:0")
+    pred, tgt = torch.rand(B, C, H, W, device=dev), torch.rand(B, C, H, W, device=dev)
+    slab = torch.empty(int(L.ksr_ssim_slab_floats(c_int(C), c_int(B), c_int(H), c_int(W))), device=dev)
+    maps = torch.empty(3 * B * (H - 10) * (W - 10), device=dev)
+    val, gy = torch.zeros(1, device=dev), torch.zeros(B, H, W, device=dev)
+    plane = H * W
+
+    def fwd():
+        check(L.ksr_ssim_fwd(ptr(pred), c_int64(3 * plane), ptr(tgt), c_int64(3 * plane), c_int(C), c_int(B), c_int(H),
+                             c_int(W), ptr(maps), ptr(slab), ptr(val), stream()), "ssim_fwd")
+
+    def grad():
+        check(L.ksr_ssim_y_grad(ptr(maps), ptr(pred), c_int64(3 * plane), ptr(tgt), c_int64(3 * plane), ptr(gy),
+                                c_int64(plane), c_int(B), c_int(H), c_int(W), c_float(1e-6), stream()), "ssim_y_grad")
+    report("ssim_fwd", timeit(fwd), 4 * (2 * B * C * plane + 3 * B * (H - 10) * (W - 10)))
+    report("ssim_y_grad", timeit(grad), 4 * (3 * B * (H - 10) * (W - 10) + 4 * B * plane))
+
+
 if __name__ == "__main__":
     from kan_sr import engine
     engine.set_precision(os.environ.get("KSR_PRECISION", "fp32"))
