@@ -368,36 +368,44 @@ __device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, 
         }
     }
 }
+// registers of one fetched 32 x 32 tile
+template <class T> struct KsrTile16 { float4 v[4]; };
+template <> struct KsrTile16<__bf16> { uint4 v[2]; };
+// Phase 1 for a tensor with 32 channels per row (rows [n0, n0+32), nvalid real ones)
 template <class T>
-__device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const void* __restrict__ base, long n0, int nvalid,
-                                              int lane, float (&x)[16]) {
-    ksr_wave_fence();
+__device__ __forceinline__ void ksr_co16_fetch(const void* __restrict__ base, long n0, int nvalid, int lane, KsrTile16<T>& t) {
     if constexpr (sizeof(T) == 4) {
-        float4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nvalid) v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * 32 + c4);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
-            *reinterpret_cast<float4*>(xb + row * KSR_XPOSE16_LD + c4) = v[i];
+            t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < nvalid) t.v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * 32 + c4);
         }
     } else {
-        uint4 v[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = i * 64 + lane, row = idx >> 2, c8 = (idx & 3) * 8;
-            v[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (row < nvalid) v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * 32 + c8);
+            t.v[i] = make_uint4(0u, 0u, 0u, 0u);
+            if (row < nvalid) t.v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * 32 + c8);
         }
+    }
+}
+// Phase 2: this lane's 16 channels (16 * (lane >> 5) ..) of row lane & 31
+template <class T>
+__device__ __forceinline__ void ksr_co16_finish(float* __restrict__ xb, int lane, const KsrTile16<T>& t, float (&x)[16]) {
+    ksr_wave_fence();
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            *reinterpret_cast<float4*>(xb + row * KSR_XPOSE16_LD + c4) = t.v[i];
+        }
+    } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = i * 64 + lane, row = idx >> 2, c8 = (idx & 3) * 8;
             float f[8];
-            ksr_unpack8(v[i], f);
+            ksr_unpack8(t.v[i], f);
             float* d = xb + row * KSR_XPOSE16_LD + c8;
             *reinterpret_cast<float4*>(d) = make_float4(f[0], f[1], f[2], f[3]);
             *reinterpret_cast<float4*>(d + 4) = make_float4(f[4], f[5], f[6], f[7]);
@@ -407,9 +415,16 @@ __device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const void
     const float* rp = xb + (lane & 31) * KSR_XPOSE16_LD + 16 * (lane >> 5);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(rp + 4 * q);
-        x[4 * q + 0] = t.x; x[4 * q + 1] = t.y; x[4 * q + 2] = t.z; x[4 * q + 3] = t.w;
+        const float4 v = *reinterpret_cast<const float4*>(rp + 4 * q);
+        x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
     }
+}
+template <class T>
+__device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const void* __restrict__ base, long n0, int nvalid,
+                                              int lane, float (&x)[16]) {
+    KsrTile16<T> t;
+    ksr_co16_fetch<T>(base, n0, nvalid, lane, t);
+    ksr_co16_finish<T>(xb, lane, t, x);
 }
 template <class T>
 __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,

@@ -70,20 +70,35 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         const int nvalid = (a.N - n0w) < 32 ? (int)(a.N - n0w > 0 ? a.N - n0w : 0) : 32;
         float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
 
+        // bf16 storage: the inputs of the tile are requested ahead of their use (loads complete in issue order, so
+        // each stage waits only for its own), which keeps several tiles of loads in flight per wave; fp32 tiles are
+        // twice as many registers and are fetched where they are used
+        constexpr bool EARLY = sizeof(ST) == 2;
+        KsrTile<ST> t_dy, t_xf, t_x2, t_x1;
+        KsrTile16<ST> t_hm;
+        ksr_co_fetch<ST>(a.dy, n0w, nvalid, 64, 0, lane, t_dy);
+        if (EARLY) {
+            if (a.nf_w) ksr_co_fetch<ST>(a.xhatf, n0w, nvalid, 64, 0, lane, t_xf);
+            ksr_co_fetch<ST>(a.xhat2, n0w, nvalid, 64, 0, lane, t_x2);
+            ksr_co16_fetch<ST>(a.hmid, n0w, nvalid, lane, t_hm);
+        }
+        const float rs_f = a.nf_w ? a.rstdf[n] : 0.f, rs_2 = a.rstd2[n], rs_1 = a.rstd1[n];
         float g[32], xh[32];
-        ksr_load32_co<ST>(xb, a.dy, n0w, nvalid, 64, 0, lane, g);
+        ksr_co_finish<ST>(xb, lane, t_dy, g);
         if (a.nf_w) {
             float t[32];
-            ksr_load32_co<ST>(xb, a.xhatf, n0w, nvalid, 64, 0, lane, xh);
-            ln_bwd(g, sm.ln[0], h, xh, a.rstdf[n], t);
+            if (!EARLY) ksr_co_fetch<ST>(a.xhatf, n0w, nvalid, 64, 0, lane, t_xf);
+            ksr_co_finish<ST>(xb, lane, t_xf, xh);
+            ln_bwd(g, sm.ln[0], h, xh, rs_f, t);
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = t[i];
             ksr_store32_co<ST>(xb, a.ds2, n0w, nvalid, 64, 0, lane, g);
         }
         // LayerNorm 2
         float du2[32];
-        ksr_load32_co<ST>(xb, a.xhat2, n0w, nvalid, 64, 0, lane, xh);
-        ln_bwd(g, sm.ln[1], h, xh, a.rstd2[n], du2);
+        if (!EARLY) ksr_co_fetch<ST>(a.xhat2, n0w, nvalid, 64, 0, lane, t_x2);
+        ksr_co_finish<ST>(xb, lane, t_x2, xh);
+        ln_bwd(g, sm.ln[1], h, xh, rs_2, du2);
         // MLP
         float dm[32];
 #pragma unroll
@@ -91,12 +106,14 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
             dm[i] = drop ? (ksr_uniform(a.seed, 3u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du2[i] * inv_keep : 0.f)
                          : du2[i];
         ksr_store32_co<ST>(xb, a.dm, n0w, nvalid, 64, 0, lane, dm);
+        if (EARLY) ksr_co_fetch<ST>(a.xhat1, n0w, nvalid, 64, 0, lane, t_x1);
         float dpre[16];
         {
             f32x16 acc[1];
             ksr_wave_gemm<PREC, 32, 1>(sm.f_l2t, nullptr, dm, acc, lane);
             float hm[16];
-            ksr_load16_co<ST>(xb, a.hmid, n0w, nvalid, lane, hm);
+            if (!EARLY) ksr_co16_fetch<ST>(a.hmid, n0w, nvalid, lane, t_hm);
+            ksr_co16_finish<ST>(xb, lane, t_hm, hm);
 #pragma unroll
             for (int i = 0; i < 16; ++i) dpre[i] = hm[i] > 0.f ? (drop ? acc[0][i] * inv_keep : acc[0][i]) : 0.f;
             ksr_store16_co<ST>(xb, a.dpre, n0w, nvalid, lane, dpre);
@@ -111,8 +128,9 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         }
         // LayerNorm 1
         float du1[32];
-        ksr_load32_co<ST>(xb, a.xhat1, n0w, nvalid, 64, 0, lane, xh);
-        ln_bwd(ds1, sm.ln[2], h, xh, a.rstd1[n], du1);
+        if (!EARLY) ksr_co_fetch<ST>(a.xhat1, n0w, nvalid, 64, 0, lane, t_x1);
+        ksr_co_finish<ST>(xb, lane, t_x1, xh);
+        ln_bwd(ds1, sm.ln[2], h, xh, rs_1, du1);
         ksr_store32_co<ST>(xb, a.du1, n0w, nvalid, 64, 0, lane, du1);
         float da[32];
 #pragma unroll
