@@ -287,10 +287,12 @@ struct RedArgs {
     long out_bstride;
 };
 
-__global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
-    // 32 outputs x 8 slab groups per workgroup (lanes = consecutive outputs: 128-byte rows of the slabs); every
+constexpr int RED_GROUPS = 32;     // slab groups per workgroup (1024 threads)
+
+__global__ void __launch_bounds__(32 * RED_GROUPS) reduce_kernel(RedArgs a) {
+    // 32 outputs x 32 slab groups per workgroup (lanes = consecutive outputs: 128-byte rows of the slabs); every
     // thread keeps 4 independent partial sums; all partials are combined in a fixed order
-    __shared__ float part[8][33];
+    __shared__ float part[RED_GROUPS][33];
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + o;
     const int total = a.J * a.K + (a.bias ? a.tail_len : 0);
@@ -299,20 +301,20 @@ __global__ void __launch_bounds__(256) reduce_kernel(RedArgs a) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (idx < total) {
         int g = grp;
-        for (; g + 24 < a.G; g += 32) {
+        for (; g + 3 * RED_GROUPS < a.G; g += 4 * RED_GROUPS) {
             s0 += slab[(long)g * a.stride];
-            s1 += slab[(long)(g + 8) * a.stride];
-            s2 += slab[(long)(g + 16) * a.stride];
-            s3 += slab[(long)(g + 24) * a.stride];
+            s1 += slab[(long)(g + RED_GROUPS) * a.stride];
+            s2 += slab[(long)(g + 2 * RED_GROUPS) * a.stride];
+            s3 += slab[(long)(g + 3 * RED_GROUPS) * a.stride];
         }
-        for (; g < a.G; g += 8) s0 += slab[(long)g * a.stride];
+        for (; g < a.G; g += RED_GROUPS) s0 += slab[(long)g * a.stride];
     }
     part[grp][o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp != 0 || idx >= total) return;
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) s += part[r][o];
+    for (int r = 0; r < RED_GROUPS; ++r) s += part[r][o];
     int j, k;
     if (is_bias) { j = idx - a.J * a.K; k = 0; }
     else { j = idx / a.K; k = idx - j * a.K; }
@@ -522,7 +524,7 @@ int launch_reduce(const float* slab, int G, int J, int K, long stride, float* ou
     if (tail_off < 0) { tail_off = J * K; tail_len = J; }
     RedArgs r{slab, G, J, K, stride, out, sj, sk, bias, kan_O, kan_Kc, kan_nbh, tail_off, tail_len, out_bstride};
     const int total = J * K + (bias ? tail_len : 0);
-    hipLaunchKernelGGL(reduce_kernel, dim3((total + 31) / 32, nb), dim3(256), 0, s, r);
+    hipLaunchKernelGGL(reduce_kernel, dim3((total + 31) / 32, nb), dim3(32 * RED_GROUPS), 0, s, r);
     KSR_LAUNCH_CHECK("reduce");
     return KSR_OK;
 }
