@@ -234,3 +234,32 @@ def test_training_trajectory_bf16_storage_tracks_fp32():
     assert hist["bf16s"][-1] < 0.9 * hist["bf16s"][0], hist["bf16s"]
     for a, b in zip(hist["fp32"], hist["bf16s"]):
         assert abs(a - b) <= 0.03 * abs(a), (hist["fp32"], hist["bf16s"])
+
+
+def test_checkpoint_resume_reproduces_the_next_step(tmp_path):
+    """Three steps, save, load into a fresh model + TrainStep, one more step on both with the same dropout stream:
+    parameters and loss agree bit for bit (every kernel on the step is deterministic)."""
+    from kan_sr.checkpoint import load_checkpoint, save_checkpoint
+    from kan_sr.train import TrainStep
+    r, B, H, W = 2, 4, 16, 24
+    torch.manual_seed(11)
+    m, _ = _model(r)
+    m = m.cuda().train()
+    ts = TrainStep(m, lr=1e-3, loss="l1+ssim")
+    xs = [torch.rand(B, 3, H, W).cuda() for _ in range(4)]
+    tg = [torch.rand(B, 3, r * H, r * W).cuda() for _ in range(4)]
+    for it in range(3):
+        ts.step(xs[it], tg[it])
+    path = str(tmp_path / "last.ckpt")
+    save_checkpoint(m, path, epoch=3, global_step=3, train_step=ts)
+    m2, _ = _model(r, seed=99)
+    m2 = m2.cuda().train()
+    ts2 = TrainStep(m2, lr=5.0, loss="l1+ssim")
+    assert load_checkpoint(m2, path, train_step=ts2) == {"epoch": 3, "global_step": 3}
+    torch.manual_seed(77)
+    l1 = float(ts.step(xs[3], tg[3]))
+    torch.manual_seed(77)
+    l2 = float(ts2.step(xs[3], tg[3]))
+    assert l1 == l2 and ts2.steps == 4
+    assert torch.equal(ts.flat_p, ts2.flat_p) and torch.equal(ts.exp_avg, ts2.exp_avg)
+    ts.close(); ts2.close()

@@ -158,3 +158,48 @@ def test_cosine_warm_restarts_schedule_matches_torch():
         assert abs(orc.cosine_warm_restarts_lr(1e-3, epoch) - want) <= 1e-12, epoch
         opt.step()
         sch.step()
+
+
+def test_checkpoint_roundtrip_in_reference_layout(tmp_path):
+    """save_checkpoint writes what the reference's tools read back (src/cli/transfer.py:57-58: torch.load with
+    weights_only=True, ['state_dict'], 'model.' prefix) and an Adam state torch.optim.Adam accepts."""
+    from kan_sr.checkpoint import PREFIX, adam_state_dict, load_checkpoint, save_checkpoint
+    from kan_sr.module import ConvSepKan
+    from kan_sr.train import TrainStep
+    torch.manual_seed(5)
+    m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4)
+    ts = TrainStep(m, lr=3e-4)
+    ts.steps = 7
+    ts.exp_avg.normal_()
+    ts.exp_avg_sq.uniform_(0.0, 1.0)
+    path = str(tmp_path / "last.ckpt")
+    save_checkpoint(m, path, epoch=12, global_step=340, train_step=ts)
+    raw = torch.load(path, weights_only=True)
+    assert set(raw["state_dict"]) == {PREFIX + k for k in orc.param_shapes(16, 5, 3)}
+    assert raw["epoch"] == 12 and raw["global_step"] == 340
+    sched = raw["lr_schedulers"][0]
+    assert sched["T_0"] == 500 and sched["last_epoch"] == 12 and abs(sched["_last_lr"][0] - orc.cosine_warm_restarts_lr(3e-4, 12)) < 1e-12
+    # torch's own optimiser takes the state, parameter by parameter
+    opt = torch.optim.Adam(m.parameters(), lr=1.0)
+    opt.load_state_dict(raw["optimizer_states"][0])
+    assert opt.param_groups[0]["lr"] == 3e-4
+    named = dict(m.named_parameters())
+    off = 0
+    from kan_sr.train import FLAT_ORDER
+    for n in FLAT_ORDER:
+        prm = named[ts.pre + n]
+        st = opt.state[prm]
+        assert float(st["step"]) == 7.0
+        assert torch.equal(st["exp_avg"].reshape(-1), ts.exp_avg[off:off + prm.numel()])
+        assert torch.equal(st["exp_avg_sq"].reshape(-1), ts.exp_avg_sq[off:off + prm.numel()])
+        off += prm.numel()
+    # and back into a fresh model / TrainStep
+    m2 = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4)
+    ts2 = TrainStep(m2, lr=1.0)
+    info = load_checkpoint(m2, path, train_step=ts2)
+    assert info == {"epoch": 12, "global_step": 340}
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert ts2.steps == 7 and ts2.lr == 3e-4 and torch.equal(ts2.exp_avg, ts.exp_avg) and torch.equal(ts2.exp_avg_sq, ts.exp_avg_sq)
+    assert m2.layers[-1].encoder.encoder.feed.weight.data_ptr() >= ts2.flat_p.data_ptr()      # still bound to the flat buffer
+    assert adam_state_dict(TrainStep(ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2)))["state"] == {}
