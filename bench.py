@@ -92,6 +92,7 @@ ENTRY_KERNEL = {
     "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<2>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<2, true, true>",
     "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<2, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<2, 4, 8, 3>",
     "ksr_gate_pw_fwd": "conv_fwd_kernel<2, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<2, 64, 0, 3>",
+    "ksr_wgrad": "entry:ksr_wgrad",      # launch-weighted average over the wgrad_kernel instances + the slab reduction
 }
 
 

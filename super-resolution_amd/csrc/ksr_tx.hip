@@ -36,9 +36,13 @@ struct TxArgs {
 
 constexpr int KV_LD = 132;        // floats per slot: [h0: k32 v32][h1: k32 v32] + 4 pad
 
-template <bool POST>
+// MODE 0: whole layer (QKV projection, attention over S, rest).  MODE 1 ("post"): starts from ctx.
+// MODE 2: one image per pixel (S = 1): softmax over a single key is 1, so ctx = V projection of the token and
+// neither Q, K nor the exchange buffer exist; tiles are consecutive rows as in MODE 1.
+template <int MODE>
 struct __attribute__((aligned(16))) TxSmem {
-    float f_in[POST ? 4 : 6 * 32 * 64];      // 64 -> 192
+    static constexpr bool POST = MODE != 0;
+    float f_in[MODE == 0 ? 6 * 32 * 64 : (MODE == 2 ? 2 * 32 * 64 : 4)];      // 64 -> 192 (MODE 2: the V rows only)
     float f_out[2 * 32 * 64];     // 64 -> 64
     float f_l1[1 * 32 * 64];      // 64 -> 32
     float f_l2[2 * 16 * 64];      // 32 -> 64
@@ -59,17 +63,19 @@ __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* 
     }
 }
 
-// POST = true: the QKV projection and the attention ran in separate kernels (ksr_pointwise_fwd,
+// MODE 1 (post): the QKV projection and the attention ran in separate kernels (ksr_pointwise_fwd,
 // ksr_batch_attn_fwd); this kernel starts from ctx and needs neither the QKV weights nor the K/V
-// exchange buffer in LDS (4x the occupancy).
-template <int PREC, bool TRAIN, bool POST>
-__global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs a) {
+// exchange buffer in LDS (4x the occupancy).  MODE 2: see TxSmem.
+template <int PREC, bool TRAIN, int MODE>
+__global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(TxArgs a) {
     using ST = typename KsrStore<PREC>::T;
-    __shared__ TxSmem<POST> sm;
+    constexpr bool POST = MODE != 0;          // row tiles, coalesced loads / stores, no cross-token step
+    __shared__ TxSmem<MODE> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
 
-    if (!POST) ksr_stage_weights<PREC, 32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
+    if (MODE == 0) ksr_stage_weights<PREC, 32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
+    if (MODE == 2) ksr_stage_weights<PREC, 32, 2, false>(sm.f_in, sm.b_in, a.in_w + 128 * 64, 64, a.in_b + 128, MapHL{32}, MapHL{32}, tid, 256);
     ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, 256);
     ksr_stage_weights<PREC, 32, 1, false>(sm.f_l1, sm.b_l1, a.l1_w, 64, a.l1_b, MapSplit{16}, MapHL{32}, tid, 256);
     ksr_stage_weights<PREC, 16, 2, false>(sm.f_l2, sm.b_l2, a.l2_w, 32, a.l2_b, MapHL{32}, MapSplit{16}, tid, 256);
@@ -118,8 +124,13 @@ __global__ void __launch_bounds__(256, POST ? 2 : 1) tx_layer_fwd_kernel(TxArgs 
         }
 
         float ctx[32];
-        if (POST) {
+        if (MODE == 1) {
             ksr_load32_co<ST>(xb, a.ctx_in, n0w, nvalid, 64, 0, lane, ctx);
+        } else if (MODE == 2) {
+            f32x16 acc[2];
+            ksr_wave_gemm<PREC, 32, 2>(sm.f_in, sm.b_in, s0, acc, lane);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ctx[i] = acc[0][i]; ctx[16 + i] = acc[1][i]; }
         } else {
         // ---- QKV projection -------------------------------------------------------------
         float q[32];
@@ -290,10 +301,18 @@ extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* 
     const int ntiles = (HW + PPW - 1) / PPW;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     const bool train = saves || p_drop > 0.f;
+    if (S == 1 && !train) {      // inference on one image: no attention step is left (see TxSmem)
+        const unsigned g1 = (unsigned)(ntiles < 1024 ? ntiles : 1024);
+#define KSR_CALL(P) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, 2>), dim3(g1), dim3(256), 0, stream, a)
+        KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
+        KSR_LAUNCH_CHECK("batch_tx_layer_fwd(single image)");
+        return KSR_OK;
+    }
 #define KSR_CALL(P)                                                                                                   \
     do {                                                                                                              \
-        if (train) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, true, false>), dim3(grid), dim3(256), 0, stream, a);    \
-        else hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, false>), dim3(grid), dim3(256), 0, stream, a);         \
+        if (train) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, true, 0>), dim3(grid), dim3(256), 0, stream, a);    \
+        else hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, 0>), dim3(grid), dim3(256), 0, stream, a);         \
     } while (0)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
@@ -326,8 +345,8 @@ extern "C" int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, fl
     const bool train = saves || p_drop > 0.f;
 #define KSR_CALL(P)                                                                                                   \
     do {                                                                                                              \
-        if (train) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, true, true>), dim3(grid), dim3(256), 0, stream, a);     \
-        else hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, true>), dim3(grid), dim3(256), 0, stream, a);          \
+        if (train) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, true, 1>), dim3(grid), dim3(256), 0, stream, a);     \
+        else hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, 1>), dim3(grid), dim3(256), 0, stream, a);          \
     } while (0)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
