@@ -100,15 +100,19 @@ __device__ __forceinline__ int ksr_bspline_local(float x, const float* __restric
     return m;
 }
 
-// Counter-based uniform in [0,1) for dropout: a 32-bit avalanche hash of (seed, stream, element index).
-// Stateless, so the backward regenerates exactly the masks of the forward.
-__device__ __forceinline__ float ksr_uniform(unsigned long long seed, unsigned stream, unsigned long long idx) {
+// Dropout keep decision for element base + i of a stream (base even, i a small unrolled index): one hash serves the
+// two elements of a pair, 16 bits each, so the keep probability is quantised to 1/65536.  Counter-based
+// (a 32-bit avalanche hash of seed, stream and element index) and stateless, so the backward regenerates exactly
+// the masks of the forward.
+__device__ __forceinline__ bool ksr_keep(unsigned long long seed, unsigned stream, unsigned long long base, int i, float keep) {
     const unsigned s32 = (unsigned)seed * 0x9E3779B1u ^ (unsigned)(seed >> 32) * 0x85EBCA77u ^ (stream * 0xC2B2AE3Du + 0x27D4EB2Fu);
-    unsigned x = (unsigned)idx * 0x9E3779B1u ^ (unsigned)(idx >> 32) * 0x85EBCA77u ^ s32;
+    const unsigned long long pair = (base >> 1) + (unsigned)(i >> 1);
+    unsigned x = (unsigned)pair * 0x9E3779B1u ^ (unsigned)(pair >> 32) * 0x85EBCA77u ^ s32;
     x ^= x >> 16; x *= 0x7FEB352Du;
     x ^= x >> 15; x *= 0x846CA68Bu;
     x ^= x >> 16;
-    return (float)(x >> 8) * (1.0f / 16777216.0f);
+    const unsigned half = (i & 1) ? (x >> 16) : (x & 0xffffu);
+    return half < (unsigned)(keep * 65536.0f);
 }
 
 __device__ __forceinline__ unsigned ksr_hash32(unsigned x) {

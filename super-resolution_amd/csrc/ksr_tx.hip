@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
             if (TRAIN && a.p_drop > 0.f) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i)
-                    u[i] = ksr_uniform(a.seed, 1u, (unsigned long long)n * 64 + 32 * h + i) < keep ? u[i] * inv_keep : 0.f;
+                    u[i] = ksr_keep(a.seed, 1u, (unsigned long long)n * 64 + 32 * h, i, keep) ? u[i] * inv_keep : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 32; ++i) u[i] += s0[i];
@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
             if (TRAIN && a.p_drop > 0.f) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
-                    hm[i] = ksr_uniform(a.seed, 2u, (unsigned long long)n * 32 + 16 * h + i) < keep ? hm[i] * inv_keep : 0.f;
+                    hm[i] = ksr_keep(a.seed, 2u, (unsigned long long)n * 32 + 16 * h, i, keep) ? hm[i] * inv_keep : 0.f;
             }
             if (TRAIN && a.sv_hmid) {
                 if (POST) ksr_store16_co<ST>(xb, a.sv_hmid, n0w, nvalid, lane, hm);
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
             if (TRAIN && a.p_drop > 0.f) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i)
-                    u[i] = ksr_uniform(a.seed, 3u, (unsigned long long)n * 64 + 32 * h + i) < keep ? u[i] * inv_keep : 0.f;
+                    u[i] = ksr_keep(a.seed, 3u, (unsigned long long)n * 64 + 32 * h, i, keep) ? u[i] * inv_keep : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < 32; ++i) u[i] += s1[i];

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         float dm[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i)
-            dm[i] = drop ? (ksr_uniform(a.seed, 3u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du2[i] * inv_keep : 0.f)
+            dm[i] = drop ? (ksr_keep(a.seed, 3u, (unsigned long long)n * 64 + 32 * h, i, keep) ? du2[i] * inv_keep : 0.f)
                          : du2[i];
         ksr_store32_co<ST>(xb, a.dm, n0w, nvalid, 64, 0, lane, dm);
         if (EARLY) ksr_co_fetch<ST>(a.xhat1, n0w, nvalid, 64, 0, lane, t_x1);
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         float da[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i)
-            da[i] = drop ? (ksr_uniform(a.seed, 1u, (unsigned long long)n * 64 + 32 * h + i) < keep ? du1[i] * inv_keep : 0.f)
+            da[i] = drop ? (ksr_keep(a.seed, 1u, (unsigned long long)n * 64 + 32 * h, i, keep) ? du1[i] * inv_keep : 0.f)
                          : du1[i];
         if (drop) ksr_store32_co<ST>(xb, a.da, n0w, nvalid, 64, 0, lane, da);
         {
