@@ -5,8 +5,12 @@
 // are rounded to bf16.  A 16-deep MFMA step pairs k-slot j of lane half g with
 //   dims   16*s + 8*g + j                          for products over the 32 dims of a head, and
 //   slots  16*s + 8*(j>>2) + 4*g + (j&3)           for products over the 32 slots of a block
-// (the second is the order in which an accumulator tile holds its rows), so LDS rows are read with one
-// 16-byte access per step and transposed tiles with two 8-byte accesses.
+// (the second is the order in which an accumulator tile holds its rows).
+// LDS holds every operand once, as rows of the 32 dims of one head (64 bytes, no padding): a product over dims
+// reads a row with one 16-byte access per step; a product over slots reads the same rows with the transposing
+// load ds_read_b64_tr_b16 (each 16-lane group fetches a 4-slot x 16-dim block and lane i receives dim i of the 4
+// slots), two per step.  The four 16-byte chunks of row r are stored at chunk position c ^ ((r >> 2) & 3), which
+// makes the row writes, the row reads and the transposing reads all bank-conflict free.
 // Rows of qkv / ctx are fetched with lane-linear 16-byte accesses (16 lanes per 256-byte row) and
 // redistributed through a wave-private LDS tile.
 #include "ksr_attn.h"
@@ -14,10 +18,10 @@
 namespace {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int KLH = 72;      // forward K rows: 64 dims + 8 pad (bf16)
-constexpr int VLH = 136;     // transposed tiles: 128 slots + 8 pad (bf16)
-constexpr int RLH = 40;      // backward per-head rows: 32 dims + 8 pad (bf16)
+// element offset of chunk c (8 bf16) of row r in a swizzled row array
+__device__ __forceinline__ int sw_off(int r, int c) { return r * 32 + 8 * (c ^ ((r >> 2) & 3)); }
 
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -96,28 +100,31 @@ __device__ __forceinline__ void pack_split(const float (&x)[2][2][8], float mul,
 }
 
 // acc[row = slot of block][col = lane] += sum over the 32 dims of rows[(rbase + slot)][dim] * x[dim]
-__device__ __forceinline__ void rows_times_x(const __bf16* __restrict__ rows, int ld, int rbase, int coff, int tok, int g,
+__device__ __forceinline__ void rows_times_x(const __bf16* __restrict__ rows, int rbase, int tok, int g,
                                              const bf16x8 (&x)[2], f32x16& acc) {
-    const __bf16* rp = rows + (rbase + tok) * ld + coff + 8 * g;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) acc = mfma16(*reinterpret_cast<const bf16x8*>(rp + 16 * s), x[s], acc);
+    for (int s = 0; s < 2; ++s)
+        acc = mfma16(*reinterpret_cast<const bf16x8*>(rows + sw_off(rbase + tok, 2 * s + g)), x[s], acc);
 }
 
-// acc[row = dim][col = lane] += sum over the 32 slots of a block of tr[dim][cbase + slot] * y[slot], y an
-// accumulator tile (register r of lane half g <-> slot (r&3) + 8(r>>2) + 4g)
-__device__ __forceinline__ void tr_times_acc(const __bf16* __restrict__ tr, int cbase, int tok, int g, const f32x16& y,
+// acc[row = dim][col = lane] += sum over the 32 slots of a block of rows[cbase + slot][dim] * y[slot], y an
+// accumulator tile (register r of lane half g <-> slot (r&3) + 8(r>>2) + 4g).  Every lane of the wave must be active.
+__device__ __forceinline__ void tr_times_acc(const __bf16* __restrict__ rows, int cbase, int lane, const f32x16& y,
                                              f32x16& acc) {
-    const __bf16* tp = tr + tok * VLH + cbase + 4 * g;
+    const int g = lane >> 5, db = (lane >> 4) & 1, q = (lane & 15) >> 2, p = lane & 3;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        const bf16x4 lo = *reinterpret_cast<const bf16x4*>(tp + 16 * s);
-        const bf16x4 hi = *reinterpret_cast<const bf16x4*>(tp + 16 * s + 8);
-        bf16x8 a, b;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = lo[j]; a[4 + j] = hi[j]; }
+        const int r0 = cbase + 16 * s + 4 * g + q;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(rows + sw_off(r0, 2 * db + (p >> 1)) + 4 * (p & 1)));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(rows + sw_off(r0 + 8, 2 * db + (p >> 1)) + 4 * (p & 1)));
+        union { s16x4 h[2]; bf16x8 v; } a;
+        a.h[0] = lo; a.h[1] = hi;
+        bf16x8 b;
 #pragma unroll
         for (int j = 0; j < 8; ++j) b[j] = (__bf16)y[8 * s + j];
-        acc = mfma16(a, b, acc);
+        acc = mfma16(a.v, b, acc);
     }
 }
 
@@ -155,8 +162,8 @@ __device__ __forceinline__ void store_dims32(float* __restrict__ xb, void* __res
 
 // ------------------------------------------------------------------------------------------ forward
 struct __attribute__((aligned(16))) FwdSmem {
-    __bf16 k[128 * KLH];
-    __bf16 vt[64 * VLH];
+    __bf16 k[2][128 * 32];     // K rows per head (swizzled chunks, see sw_off)
+    __bf16 v[2][128 * 32];     // V rows per head
     float xpose[4 * KSR_XPOSE_FLOATS];
 };
 
@@ -194,7 +201,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
             float x[2][2][8];
             finish_split<ST>(xb, lane, fq, x);
             pack_split(x, scale, qb);
-            __syncthreads();                        // previous tile's readers of k / vt are done
+            __syncthreads();                        // previous tile's readers of k / v are done
             finish_split<ST>(xb, lane, fk, x);
 #pragma unroll
             for (int X = 0; X < 2; ++X)
@@ -203,15 +210,18 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
                     bf16x8 w;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) w[j] = (__bf16)x[X][s][j];
-                    *reinterpret_cast<bf16x8*>(&sm.k[slot * KLH + 32 * X + 16 * s + 8 * g]) = w;
+                    *reinterpret_cast<bf16x8*>(&sm.k[X][sw_off(slot, 2 * s + g)]) = w;
                 }
             finish_split<ST>(xb, lane, fv, x);
 #pragma unroll
             for (int X = 0; X < 2; ++X)
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 w;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) sm.vt[(32 * X + 16 * s + 8 * g + j) * VLH + slot] = (__bf16)x[X][s][j];
+                    for (int j = 0; j < 8; ++j) w[j] = (__bf16)x[X][s][j];
+                    *reinterpret_cast<bf16x8*>(&sm.v[X][sw_off(slot, 2 * s + g)]) = w;
+                }
         }
         __syncthreads();
 
@@ -224,7 +234,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
 #pragma unroll
             for (int kb = 0; kb < NW; ++kb) {
                 sc[kb] = zero16();
-                rows_times_x(sm.k, KLH, kbase0 + 32 * kb, 32 * X, tok, g, qb[X], sc[kb]);
+                rows_times_x(sm.k[X], kbase0 + 32 * kb, tok, g, qb[X], sc[kb]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int same, kbb;
@@ -252,7 +262,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
             // ---- ctx^T = V^T P^T ----
             f32x16 acc = zero16();
 #pragma unroll
-            for (int kb = 0; kb < NW; ++kb) tr_times_acc(sm.vt + 32 * X * VLH, kbase0 + 32 * kb, tok, g, sc[kb], acc);
+            for (int kb = 0; kb < NW; ++kb) tr_times_acc(sm.v[X], kbase0 + 32 * kb, lane, sc[kb], acc);
             store_dims32<ST>(xb, a.ctx, rm, 64, 32 * X, lane, acc, inv_l);
         }
     }
@@ -260,23 +270,15 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
 
 // ------------------------------------------------------------------------------------------ backward
 struct __attribute__((aligned(16))) BwdSmem {
-    __bf16 rowA[128 * RLH];   // phase A: K rows  | phase B: Q rows (scaled)
-    __bf16 rowB[128 * RLH];   // phase A: V rows  | phase B: dO rows
-    __bf16 trA[32 * VLH];     // phase A: K^T     | phase B: Q^T (scaled)
-    __bf16 trB[32 * VLH];     //                  | phase B: dO^T
+    __bf16 rowA[128 * 32];    // phase A: K rows  | phase B: Q rows (scaled); swizzled chunks, see sw_off
+    __bf16 rowB[128 * 32];    // phase A: V rows  | phase B: dO rows
     float stat[128 * 4];      // per query slot: m, 1/l, D, dropout base (bits)
     float xpose[4 * KSR_XPOSE_FLOATS];
 };
 
 __device__ __forceinline__ void put_rows(__bf16* __restrict__ rows, int slot, int g, const bf16x8 (&x)[2]) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(&rows[slot * RLH + 16 * s + 8 * g]) = x[s];
-}
-__device__ __forceinline__ void put_tr(__bf16* __restrict__ tr, int slot, int g, const bf16x8 (&x)[2]) {
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tr[(16 * s + 8 * g + j) * VLH + slot] = x[s][j];
+    for (int s = 0; s < 2; ++s) *reinterpret_cast<bf16x8*>(&rows[sw_off(slot, 2 * s + g)]) = x[s];
 }
 
 template <int NW, bool DROP, class ST>
@@ -337,11 +339,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
             // (not unrolled) loop body needs no second copy of them
             bf16x8 (&qx)[2] = qb[0], (&kx)[2] = kb_[0], (&vx)[2] = vb[0], (&dox)[2] = dob[0];
             const float DX = D[0];
-            // ---------------- phase A: this lane is a query; LDS holds K rows, V rows, K^T ----------------
+            // ---------------- phase A: this lane is a query; LDS holds K rows and V rows ----------------
             __syncthreads();
             put_rows(sm.rowA, slot, g, kx);
             put_rows(sm.rowB, slot, g, vx);
-            put_tr(sm.trA, slot, g, kx);
             __syncthreads();
             float m = -INFINITY, inv_l;
             const unsigned dbase = DROP ? ksr_attn_drop_base(a.seed, (unsigned long long)n, X) : 0u;
@@ -350,7 +351,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < NW; ++kb) {
                     st[kb] = zero16();
-                    rows_times_x(sm.rowA, RLH, base0 + 32 * kb, 0, tok, g, qx, st[kb]);
+                    rows_times_x(sm.rowA, base0 + 32 * kb, tok, g, qx, st[kb]);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         int same, kbb;
@@ -370,7 +371,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < NW; ++kb) {
                     f32x16 dp = zero16();
-                    rows_times_x(sm.rowB, RLH, base0 + 32 * kb, 0, tok, g, dox, dp);
+                    rows_times_x(sm.rowB, base0 + 32 * kb, tok, g, dox, dp);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float dpr = dp[r];
@@ -381,17 +382,15 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                         }
                         dp[r] = st[kb][r] * inv_l * (dpr - DX) * scale;      // dS (scaled for dq)
                     }
-                    tr_times_acc(sm.trA, base0 + 32 * kb, tok, g, dp, dq);
+                    tr_times_acc(sm.rowA, base0 + 32 * kb, lane, dp, dq);
                 }
                 store_dims32<ST>(xb, a.dqkv, rm, 192, 32 * X, lane, dq, 1.f);
             }
-            // ---------------- phase B: this lane is a key; LDS holds Q rows, dO rows, Q^T, dO^T, stats ----------------
+            // ---------------- phase B: this lane is a key; LDS holds Q rows, dO rows, stats ----------------
             __builtin_amdgcn_sched_barrier(0);
             __syncthreads();
             put_rows(sm.rowA, slot, g, qx);
             put_rows(sm.rowB, slot, g, dox);
-            put_tr(sm.trA, slot, g, qx);
-            put_tr(sm.trB, slot, g, dox);
             if (g == 0) *reinterpret_cast<f32x4*>(&sm.stat[slot * 4]) = f32x4{m, inv_l, DX, __uint_as_float(dbase)};
             __syncthreads();
             {
@@ -399,8 +398,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
 #pragma unroll
                 for (int qblk = 0; qblk < NW; ++qblk) {
                     f32x16 sq = zero16(), dp = zero16();
-                    rows_times_x(sm.rowA, RLH, base0 + 32 * qblk, 0, tok, g, kx, sq);
-                    rows_times_x(sm.rowB, RLH, base0 + 32 * qblk, 0, tok, g, vx, dp);
+                    rows_times_x(sm.rowA, base0 + 32 * qblk, tok, g, kx, sq);
+                    rows_times_x(sm.rowB, base0 + 32 * qblk, tok, g, vx, dp);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int qs = base0 + 32 * qblk + key_of_reg(r, g);      // query slot
@@ -418,8 +417,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                         sq[r] = pij * (dpr - stt[2]);    // dS
                         dp[r] = pt;                       // probabilities after dropout
                     }
-                    tr_times_acc(sm.trA, base0 + 32 * qblk, tok, g, sq, dk);
-                    tr_times_acc(sm.trB, base0 + 32 * qblk, tok, g, dp, dv);
+                    tr_times_acc(sm.rowA, base0 + 32 * qblk, lane, sq, dk);
+                    tr_times_acc(sm.rowB, base0 + 32 * qblk, lane, dp, dv);
                 }
                 store_dims32<ST>(xb, a.dqkv, rm, 192, 64 + 32 * X, lane, dk, 1.f);
                 store_dims32<ST>(xb, a.dqkv, rm, 192, 128 + 32 * X, lane, dv, 1.f);
