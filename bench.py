@@ -56,7 +56,7 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         "ksr_bilinear_up": ("hbm", 0, 8 + 8 * 16, pk),
         # backward
         "ksr_feed_kan_bwd": ("hbm", 2 * 64 * P + 800, 64 + 4 + 128 + 256 + 4 * P, pk),
-        "ksr_batch_tx_layer_bwd_token": ("hbm", 2 * lin_post, 2304 + 2816, pk),
+        "ksr_batch_tx_layer_bwd_token": ("hbm", 2 * lin_post, 2304 + 2304, pk),     # LayerNorm gain / shift sums are fused in
         "ksr_batch_attn_bwd": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
         "ksr_batch_tx_layer_bwd_attn": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
         "ksr_in_proj_bwd": ("hbm", 2 * 2 * 192 * 64, 2 * (768 + 256 + 256 + 256), pk),
@@ -65,7 +65,7 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         "ksr_pw2_bwd": ("hbm", 2 * 64 * 64, 768, pk),
         "ksr_pw1_bwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 1024, pk),
         "ksr_wgrad": ("hbm", 2 * wg_jk, wg_bytes, pk),
-        "ksr_colreduce": ("hbm", 0, 5 * 512 + 2 * 260, pk),
+        "ksr_colreduce": ("hbm", 0, 3 * 260, pk),        # ffn1.pointwise2 only (three per-pixel-scalar reductions)
         "ksr_dwconv_wgrad": ("hbm", 3 * 2 * 10 * 64, 3 * 512, pk),
         # loss (per LR pixel = 16 HR pixels): SSIM reads pred + tgt of 3 channels and writes 3 luma maps; the gradient
         # reads the maps, pred, tgt, and updates gy

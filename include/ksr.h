@@ -161,9 +161,14 @@ int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, const float* 
  * linear1.weight, out_proj.weight.  saved[7]: xhat_final, rstd_final, xhat2, rstd2, hmid, xhat1, rstd1.
  * outs[7]: ds2 [N,64] (gradient of norm2's output; only with the final norm), dm [N,64] (of linear2's
  * output), dpre [N,32] (of linear1's output), ds1 [N,64] (of norm1's output), du1 [N,64] (of norm1's
- * input), da [N,64] (of out_proj's output; only when p_drop > 0, else it equals du1), dctx [N,64]. */
+ * input), da [N,64] (of out_proj's output; only when p_drop > 0, else it equals du1), dctx [N,64].
+ * ln_slab (optional, 3 * 768 * 128 floats of workspace): the kernel then also reduces the LayerNorm gain /
+ * shift gradients; ln_grads[3] (final norm, norm2, norm1; NULL entries are skipped) each receive the gain
+ * gradient at [c] and the shift gradient at [ln_row_stride + c], c < 64, and ds2 / ds1, which only feed
+ * those sums (ksr_colreduce otherwise), may be NULL. */
 int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const* params, const float* const* saved,
-                                 float* const* outs, int64_t N, float p_drop, uint64_t seed, ksr_stream_t stream);
+                                 float* const* outs, int64_t N, float p_drop, uint64_t seed, float* ln_slab,
+                                 float* const* ln_grads, int ln_row_stride, ksr_stream_t stream);
 
 /* Attention backward over the S images of each pixel: qkv [N,192], ctx [N,64] (saved), dctx -> dqkv [N,192]. */
 int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, const float* dctx, float* dqkv, int S, int HW,

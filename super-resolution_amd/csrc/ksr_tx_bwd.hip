@@ -17,6 +17,7 @@ struct TxBwdTokArgs {
     const float *xhat1, *rstd1, *n1_w;
     const float *l2_w, *l1_w, *out_w;         // [64,32], [32,64], [64,64]
     float *ds2, *dm, *dpre, *ds1, *du1, *da, *dctx;   // outputs (ds2 only with the final LayerNorm)
+    float* ln_slab;                           // optional [3][gridDim.x][2][64]: per-workgroup LayerNorm gain / shift sums
     long N;
     float p_drop;
     unsigned long long seed;
@@ -44,6 +45,31 @@ __device__ __forceinline__ void ln_bwd(const float (&dy)[32], const float* __res
     for (int i = 0; i < 32; ++i) dx[i] = rstd * (dxh[i] - m1 - xhat[i] * m2);
 }
 
+// LayerNorm gain / shift gradients: sum over the wave's 32 tokens of g * xhat and of g, per channel.  The products
+// go through the wave's transposer tile (rows of 68 floats); lane c then adds up column c in row order, so the result
+// does not depend on scheduling.  Rows past the end of the tensor hold zeros in g.
+__device__ __forceinline__ void ln_colsum(float* __restrict__ xb, int lane, const float (&g)[32], const float (&xh)[32],
+                                          float& s_gx, float& s_g) {
+    float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        ksr_wave_fence();
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            *reinterpret_cast<float4*>(wp + 4 * q) =
+                pass == 0 ? make_float4(g[4 * q] * xh[4 * q], g[4 * q + 1] * xh[4 * q + 1], g[4 * q + 2] * xh[4 * q + 2], g[4 * q + 3] * xh[4 * q + 3])
+                          : make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+        ksr_wave_fence();
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; r += 4) {
+            t0 += xb[(r + 0) * KSR_XPOSE_LD + lane]; t1 += xb[(r + 1) * KSR_XPOSE_LD + lane];
+            t2 += xb[(r + 2) * KSR_XPOSE_LD + lane]; t3 += xb[(r + 3) * KSR_XPOSE_LD + lane];
+        }
+        (pass == 0 ? s_gx : s_g) += (t0 + t1) + (t2 + t3);
+    }
+}
+
 template <int PREC>
 __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
     using ST = typename KsrStore<PREC>::T;
@@ -62,6 +88,8 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
     const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
     const bool drop = a.p_drop > 0.f;
     const long ntiles = (a.N + 127) / 128;
+    const bool ln_sums = a.ln_slab != nullptr;
+    float cs[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};     // lane = channel: [final, norm2, norm1][sum g*xhat, sum g]
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long n0 = tile * 128 + wv * 32 + tok;
         const bool live = n0 < a.N;
@@ -89,15 +117,17 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
             float t[32];
             if (!EARLY) ksr_co_fetch<ST>(a.xhatf, n0w, nvalid, 64, 0, lane, t_xf);
             ksr_co_finish<ST>(xb, lane, t_xf, xh);
+            if (ln_sums) ln_colsum(xb, lane, g, xh, cs[0][0], cs[0][1]);
             ln_bwd(g, sm.ln[0], h, xh, rs_f, t);
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = t[i];
-            ksr_store32_co<ST>(xb, a.ds2, n0w, nvalid, 64, 0, lane, g);
+            if (a.ds2) ksr_store32_co<ST>(xb, a.ds2, n0w, nvalid, 64, 0, lane, g);
         }
         // LayerNorm 2
         float du2[32];
         if (!EARLY) ksr_co_fetch<ST>(a.xhat2, n0w, nvalid, 64, 0, lane, t_x2);
         ksr_co_finish<ST>(xb, lane, t_x2, xh);
+        if (ln_sums) ln_colsum(xb, lane, g, xh, cs[1][0], cs[1][1]);
         ln_bwd(g, sm.ln[1], h, xh, rs_2, du2);
         // MLP
         float dm[32];
@@ -124,12 +154,13 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
             ksr_wave_gemm<PREC, 16, 2>(sm.f_l1t, nullptr, dpre, acc, lane);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { ds1[i] = du2[i] + acc[0][i]; ds1[16 + i] = du2[16 + i] + acc[1][i]; }
-            ksr_store32_co<ST>(xb, a.ds1, n0w, nvalid, 64, 0, lane, ds1);
+            if (a.ds1) ksr_store32_co<ST>(xb, a.ds1, n0w, nvalid, 64, 0, lane, ds1);
         }
         // LayerNorm 1
         float du1[32];
         if (!EARLY) ksr_co_fetch<ST>(a.xhat1, n0w, nvalid, 64, 0, lane, t_x1);
         ksr_co_finish<ST>(xb, lane, t_x1, xh);
+        if (ln_sums) ln_colsum(xb, lane, ds1, xh, cs[2][0], cs[2][1]);
         ln_bwd(ds1, sm.ln[2], h, xh, rs_1, du1);
         ksr_store32_co<ST>(xb, a.du1, n0w, nvalid, 64, 0, lane, du1);
         float da[32];
@@ -147,6 +178,42 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
             ksr_store32_co<ST>(xb, a.dctx, n0w, nvalid, 64, 0, lane, dc);
         }
     }
+    if (ln_sums) {
+        // the four waves' sums meet in LDS (each wave's own transposer first, so no wave is still reading it)
+        float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+        ksr_wave_fence();
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) xb[(2 * l + q) * 64 + lane] = cs[l][q];
+        __syncthreads();
+        for (int i = tid; i < 6 * 64; i += 256) {
+            const float v = (sm.xpose[i] + sm.xpose[KSR_XPOSE_FLOATS + i]) + (sm.xpose[2 * KSR_XPOSE_FLOATS + i] + sm.xpose[3 * KSR_XPOSE_FLOATS + i]);
+            const int l = i / 128, r = i - 128 * l;
+            a.ln_slab[((long)l * gridDim.x + blockIdx.x) * 128 + r] = v;
+        }
+    }
+}
+
+// gain / shift gradients of up to three LayerNorms from the per-workgroup sums: out[l][q * row_stride + c]
+struct LnRedArgs { const float* slab; int G; float* out[3]; int row_stride; };
+__global__ void __launch_bounds__(1024) ln_reduce_kernel(LnRedArgs a) {
+    __shared__ float part[8][128];
+    const int l = blockIdx.x;
+    if (a.out[l] == nullptr) return;
+    const int e = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const float* slab = a.slab + (long)l * a.G * 128 + e;
+    float s0 = 0.f, s1 = 0.f;
+    int g = grp;
+    for (; g + 8 < a.G; g += 16) { s0 += slab[(long)g * 128]; s1 += slab[(long)(g + 8) * 128]; }
+    if (g < a.G) s0 += slab[(long)g * 128];
+    part[grp][e] = s0 + s1;
+    __syncthreads();
+    if (grp != 0) return;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += part[r][e];
+    a.out[l][(e >> 6) * a.row_stride + (e & 63)] = s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -298,8 +365,12 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
 // params[6]: norm_final.weight (or NULL), norm2.weight, norm1.weight, linear2.weight, linear1.weight,
 // out_proj.weight.  saved[7]: xhat_final, rstd_final, xhat2, rstd2, hmid, xhat1, rstd1.
 // outs[7]: ds2 (only with the final norm), dm, dpre [N,32], ds1, du1, da (only when p_drop > 0), dctx.
+// ln_slab (optional): 3 * 768 * 128 floats of workspace; with it the kernel also reduces the LayerNorm gain / shift
+// gradients, ln_grads[l] (l = final norm, norm2, norm1; NULL to skip) receiving the gain gradient at [c] and the shift
+// gradient at [ln_row_stride + c], and the outputs ds2 / ds1 (which only those reductions consume) may be NULL.
 extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const* params, const float* const* saved,
                                             float* const* outs, int64_t N, float p_drop, uint64_t seed,
+                                            float* ln_slab, float* const* ln_grads, int ln_row_stride,
                                             hipStream_t stream) {
     KSR_CHECK_ARG(dy && params && saved && outs && N > 0, "batch_tx_layer_bwd_token: bad argument");
     TxBwdTokArgs a{};
@@ -310,8 +381,11 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     a.ds2 = outs[0]; a.dm = outs[1]; a.dpre = outs[2]; a.ds1 = outs[3]; a.du1 = outs[4]; a.da = outs[5]; a.dctx = outs[6];
     for (int i = 1; i < 6; ++i) KSR_CHECK_ARG(params[i] != nullptr, "batch_tx_layer_bwd_token: params[%d] is null", i);
     for (int i = 2; i < 7; ++i) KSR_CHECK_ARG(saved[i] != nullptr, "batch_tx_layer_bwd_token: saved[%d] is null", i);
-    KSR_CHECK_ARG(a.dm && a.dpre && a.ds1 && a.du1 && a.dctx, "batch_tx_layer_bwd_token: null output");
-    KSR_CHECK_ARG(!a.nf_w || (a.xhatf && a.rstdf && a.ds2), "batch_tx_layer_bwd_token: final norm needs xhat/rstd/ds2");
+    KSR_CHECK_ARG(a.dm && a.dpre && a.du1 && a.dctx, "batch_tx_layer_bwd_token: null output");
+    KSR_CHECK_ARG(!a.nf_w || (a.xhatf && a.rstdf), "batch_tx_layer_bwd_token: final norm needs xhat/rstd");
+    KSR_CHECK_ARG(ln_slab || (a.ds1 && (!a.nf_w || a.ds2)), "batch_tx_layer_bwd_token: ds1 / ds2 are required without ln_slab");
+    KSR_CHECK_ARG(!ln_slab || (ln_grads && ln_row_stride >= 64), "batch_tx_layer_bwd_token: ln_slab needs ln_grads and a row stride >= 64");
+    a.ln_slab = ln_slab;
     KSR_CHECK_ARG(!(p_drop > 0.f) || a.da, "batch_tx_layer_bwd_token: dropout needs the da output");
     a.N = (long)N; a.p_drop = p_drop; a.seed = seed;
     const long ntiles = (N + 127) / 128;
@@ -319,6 +393,11 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token");
+    if (ln_slab) {
+        LnRedArgs r{ln_slab, (int)(ntiles < 768 ? ntiles : 768), {a.nf_w ? ln_grads[0] : nullptr, ln_grads[1], ln_grads[2]}, ln_row_stride};
+        hipLaunchKernelGGL(ln_reduce_kernel, dim3(3), dim3(1024), 0, stream, r);
+        KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token(ln reduce)");
+    }
     return KSR_OK;
 }
 

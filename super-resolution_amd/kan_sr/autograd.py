@@ -33,6 +33,7 @@ class _Ws:
     def __init__(self, dev, arena=None):
         self.dev = dev
         self._slab = None
+        self._ln_slab = None
         self.arena = arena
 
     def new(self, *shape):
@@ -56,6 +57,11 @@ class _Ws:
         w, b = self.arena[name_w], self.arena[name_b]
         assert w.numel() == n and b.numel() == n and b.data_ptr() == w.data_ptr() + 4 * n, (name_w, name_b)
         return torch.as_strided(w, (2, n), (n, 1))
+
+    def ln_slab(self):
+        if self._ln_slab is None:
+            self._ln_slab = torch.empty(3 * 768 * 128, device=self.dev, dtype=torch.float32)
+        return self._ln_slab
 
     def slab(self, nfloats):
         if self._slab is None or self._slab.numel() < nfloats:
@@ -99,26 +105,23 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     params = [nf_w, p[q + "norm2.weight"], p[q + "norm1.weight"], p[q + "linear2.weight"], p[q + "linear1.weight"],
               p[q + "self_attn.out_proj.weight"]]
     saved = [sv["xhatf"], sv["rstdf"], sv["xhat2"], sv["rstd2"], sv["hmid"], sv["xhat1"], sv["rstd1"]]
-    ds2 = ws.act(N, 64) if last else None
-    dm, dpre, ds1, du1, dctx = ws.act(N, 64), ws.act(N, 32), ws.act(N, 64), ws.act(N, 64), ws.act(N, 64)
+    dm, dpre, du1, dctx = ws.act(N, 64), ws.act(N, 32), ws.act(N, 64), ws.act(N, 64)
     da = ws.act(N, 64) if p_drop > 0 else None
     lseed = (seed * 4 + li) & 0xFFFFFFFFFFFFFFFF
+    # LayerNorm gains / shifts are summed inside the token kernel (ds2 / ds1 would only feed those sums)
+    gn2 = ws.grad_pair(q + "norm2.weight", q + "norm2.bias", 64)
+    gn1 = ws.grad_pair(q + "norm1.weight", q + "norm1.bias", 64)
+    gnf = ws.grad_pair(pre + "encoder.norm.weight", pre + "encoder.norm.bias", 64) if last else None
     check(L.ksr_batch_tx_layer_bwd_token(ptr(dy), _ptr_array(params), _ptr_array(saved),
-                                         _ptr_array([ds2, dm, dpre, ds1, du1, da, dctx]), c_int64(N),
-                                         c_float(p_drop), c_uint64(lseed), stream()), "ksr_batch_tx_layer_bwd_token")
+                                         _ptr_array([None, dm, dpre, None, du1, da, dctx]), c_int64(N),
+                                         c_float(p_drop), c_uint64(lseed), ptr(ws.ln_slab()), _ptr_array([gnf, gn2, gn1]),
+                                         c_int(64), stream()), "ksr_batch_tx_layer_bwd_token")
     if da is None:
         da = du1
-    # LayerNorm gains / shifts
     if last:
-        r = _colreduce(ws, dy, 64, 0, sv["xhatf"], False, N,
-                       ws.grad_pair(pre + "encoder.norm.weight", pre + "encoder.norm.bias", 64))
-        grads[pre + "encoder.norm.weight"], grads[pre + "encoder.norm.bias"] = r[0], r[1]
-        r = _colreduce(ws, ds2, 64, 0, sv["xhat2"], False, N, ws.grad_pair(q + "norm2.weight", q + "norm2.bias", 64))
-    else:
-        r = _colreduce(ws, dy, 64, 0, sv["xhat2"], False, N, ws.grad_pair(q + "norm2.weight", q + "norm2.bias", 64))
-    grads[q + "norm2.weight"], grads[q + "norm2.bias"] = r[0], r[1]
-    r = _colreduce(ws, ds1, 64, 0, sv["xhat1"], False, N, ws.grad_pair(q + "norm1.weight", q + "norm1.bias", 64))
-    grads[q + "norm1.weight"], grads[q + "norm1.bias"] = r[0], r[1]
+        grads[pre + "encoder.norm.weight"], grads[pre + "encoder.norm.bias"] = gnf[0], gnf[1]
+    grads[q + "norm2.weight"], grads[q + "norm2.bias"] = gn2[0], gn2[1]
+    grads[q + "norm1.weight"], grads[q + "norm1.bias"] = gn1[0], gn1[1]
     # linear2 / linear1 / out_proj weights
     gw, gb = ws.grad(q + "linear2.weight", 64, 32), ws.grad(q + "linear2.bias", 64)
     _wgrad(ws, dm, 64, 0, 64, sv["hmid"], 32, 0, 32, N, gw, gb)
