@@ -82,6 +82,16 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
     const long ntiles = spatial ? (long)a.B * tiles_y * tiles_x : (N + 127) / 128;
 
+    // plain 1x1 conv with bf16 storage: the next tile's rows are requested before this tile's product
+    constexpr bool AHEAD = (PRO == PRO_PLAIN) && sizeof(ST) == 2;
+    KsrTile<ST> ahead;
+    auto fetch_tile = [&](long tile) {
+        const long n0 = tile * 128 + wv * 32;
+        const int nv = (N - n0) < 32 ? (int)(N - n0 > 0 ? N - n0 : 0) : 32;
+        ksr_co_fetch<ST>(a.in, n0, nv, a.in_ld, 0, lane, ahead);
+    };
+    if (AHEAD && (long)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
+
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y, x;
         bool live;
@@ -115,7 +125,12 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
         else nvalid = (N - n0w) < 32 ? (int)(N - n0w > 0 ? N - n0w : 0) : 32;
         float op[32];
         if (PRO == PRO_PLAIN) {
-            ksr_load32_co<ST>(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, op);
+            if (AHEAD) {
+                ksr_co_finish<ST>(xb, lane, ahead, op);
+                if (tile + gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
+            } else {
+                ksr_load32_co<ST>(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, op);
+            }
         } else if (PRO == PRO_STEM) {
             const float w1 = a.p1[0], b1 = a.p1b[0];
             const float* Y = a.in + (long)b * a.img_bstride;
