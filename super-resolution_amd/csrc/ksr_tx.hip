@@ -11,6 +11,8 @@
 // that neighbouring lanes read neighbouring pixels (contiguous 256-byte rows).
 #include "ksr_gemm.h"
 
+#include <cstddef>
+
 namespace {
 
 struct TxArgs {
@@ -38,11 +40,13 @@ constexpr int KV_LD = 132;        // floats per slot: [h0: k32 v32][h1: k32 v32]
 
 // MODE 0: whole layer (QKV projection, attention over S, rest).  MODE 1 ("post"): starts from ctx.
 // MODE 2: one image per pixel (S = 1): softmax over a single key is 1, so ctx = V projection of the token and
-// neither Q, K nor the exchange buffer exist; tiles are consecutive rows as in MODE 1.
+// neither Q, K nor the exchange buffer exist; the out-projection then acts on a linear function of the token, and the
+// kernel applies the product matrix W_out W_v (bias W_out b_v + b_out), which every workgroup forms once in LDS.
+// Tiles are consecutive rows as in MODE 1.
 template <int MODE>
 struct __attribute__((aligned(16))) TxSmem {
     static constexpr bool POST = MODE != 0;
-    float f_in[MODE == 0 ? 6 * 32 * 64 : (MODE == 2 ? 2 * 32 * 64 : 4)];      // 64 -> 192 (MODE 2: the V rows only)
+    float f_in[MODE == 0 ? 6 * 32 * 64 : 4];      // 64 -> 192
     float f_out[2 * 32 * 64];     // 64 -> 64
     float f_l1[1 * 32 * 64];      // 64 -> 32
     float f_l2[2 * 16 * 64];      // 32 -> 64
@@ -75,8 +79,43 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
     const int tok = lane & 31, h = lane >> 5;
 
     if (MODE == 0) ksr_stage_weights<PREC, 32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
-    if (MODE == 2) ksr_stage_weights<PREC, 32, 2, false>(sm.f_in, sm.b_in, a.in_w + 128 * 64, 64, a.in_b + 128, MapHL{32}, MapHL{32}, tid, 256);
-    ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, 256);
+    if (MODE == 2) {
+        // W_out and W_v (rows 128..191 of in_proj) -> the transposer area; their product -> the (not yet staged)
+        // MLP fragment area, row-major; then staged like any weight matrix
+        float* wo = sm.xpose;
+        float* wvv = sm.xpose + 4096;
+        float* prod = sm.f_l1;                       // f_l1 | f_l2 are adjacent: 4096 floats
+        static_assert(offsetof(TxSmem<MODE>, f_l2) == offsetof(TxSmem<MODE>, f_l1) + sizeof(float) * 2048, "f_l1 and f_l2 must be adjacent");
+        for (int i = tid; i < 1024; i += 256) {
+            reinterpret_cast<float4*>(wo)[i] = reinterpret_cast<const float4*>(a.out_w)[i];
+            reinterpret_cast<float4*>(wvv)[i] = reinterpret_cast<const float4*>(a.in_w + 128 * 64)[i];
+        }
+        __syncthreads();
+        {
+            const int i = tid >> 2, j0 = (tid & 3) * 16;
+            float acc[16], bsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            for (int k = 0; k < 64; ++k) {
+                const float w = wo[i * 64 + k];
+                bsum = fmaf(w, a.in_b[128 + k], bsum);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(wvv + k * 64 + j0 + 4 * q);
+                    acc[4 * q] = fmaf(w, v.x, acc[4 * q]); acc[4 * q + 1] = fmaf(w, v.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(w, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(w, v.w, acc[4 * q + 3]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) prod[i * 64 + j0 + j] = acc[j];
+            if ((tid & 3) == 0) sm.b_in[i] = bsum + a.out_b[i];
+        }
+        __syncthreads();
+        ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, prod, 64, sm.b_in, MapHL{32}, MapHL{32}, tid, 256);
+        __syncthreads();
+    } else {
+        ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, 256);
+    }
     ksr_stage_weights<PREC, 32, 1, false>(sm.f_l1, sm.b_l1, a.l1_w, 64, a.l1_b, MapSplit{16}, MapHL{32}, tid, 256);
     ksr_stage_weights<PREC, 16, 2, false>(sm.f_l2, sm.b_l2, a.l2_w, 32, a.l2_b, MapHL{32}, MapSplit{16}, tid, 256);
     if (tid < 64) {
@@ -93,6 +132,18 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
     const int b = slot / PPW, pl = slot - b * PPW;
     const float scale = 0.17677669529663687f;         // 1/sqrt(32)
     const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+
+    // row-tiled modes: the next tile's rows are requested before this tile's arithmetic (bf16 storage, or the
+    // single-image mode whose only input is one tile)
+    constexpr bool AHEAD = (MODE == 2) || (MODE == 1 && sizeof(ST) == 2);
+    KsrTile<ST> nx_in, nx_ctx;
+    auto fetch_next = [&](int t) {
+        const long r0 = (long)t * 128 + wv * 32, left = (long)S * HW - r0;
+        const int nv = left < 32 ? (int)(left > 0 ? left : 0) : 32;
+        if (!a.in32) ksr_co_fetch<ST>(a.in, r0, nv, 64, 0, lane, nx_in);
+        if (MODE == 1) ksr_co_fetch<ST>(a.ctx_in, r0, nv, 64, 0, lane, nx_ctx);
+    };
+    if (AHEAD && (int)blockIdx.x < ntiles) fetch_next(blockIdx.x);
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // POST: no cross-token step is left, tiles are 128 consecutive rows of [S*HW, 64]
@@ -113,6 +164,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
         float s0[32];
         if (POST) {
             if (a.in32) ksr_load32_co<float>(xb, a.in32, n0w, nvalid, 64, 0, lane, s0);
+            else if (AHEAD) ksr_co_finish<ST>(xb, lane, nx_in, s0);
             else ksr_load32_co<ST>(xb, a.in, n0w, nvalid, 64, 0, lane, s0);
         } else if (live) {
             if (a.in32) ksr_loadn<float, 32>(a.in32, n * 64 + 32 * h, s0);
@@ -125,12 +177,11 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
 
         float ctx[32];
         if (MODE == 1) {
-            ksr_load32_co<ST>(xb, a.ctx_in, n0w, nvalid, 64, 0, lane, ctx);
+            if (AHEAD) ksr_co_finish<ST>(xb, lane, nx_ctx, ctx);
+            else ksr_load32_co<ST>(xb, a.ctx_in, n0w, nvalid, 64, 0, lane, ctx);
         } else if (MODE == 2) {
-            f32x16 acc[2];
-            ksr_wave_gemm<PREC, 32, 2>(sm.f_in, sm.b_in, s0, acc, lane);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { ctx[i] = acc[0][i]; ctx[16 + i] = acc[1][i]; }
+            for (int i = 0; i < 32; ++i) ctx[i] = s0[i];      // f_out holds W_out W_v
         } else {
         // ---- QKV projection -------------------------------------------------------------
         float q[32];
@@ -198,6 +249,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
         }
 
         }
+        if (AHEAD && tile + (int)gridDim.x < ntiles) fetch_next(tile + gridDim.x);
         // ---- out projection + residual + LayerNorm 1 -------------------------------------
         float s1[32];
         {
