@@ -57,6 +57,29 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
     const long ntiles = spatial ? (long)a.B * tiles_y * tiles_x : (N + 127) / 128;
 
+    // PLAIN: dz and the epilogue operands of a tile are fetched together, one memory latency for the whole tile; with
+    // bf16 storage (tiles of 16 registers) they are requested one tile ahead: dz right after the previous tile's dz
+    // has been unpacked, the epilogue operands after the previous epilogue has consumed its own (wide inputs only)
+    constexpr bool PRE_R = BPRO == BPRO_PLAIN && (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD);
+    constexpr bool PRE_E1 = BPRO == BPRO_PLAIN && (BEPI == BEPI_RELUMASK || BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD || BEPI == BEPI_GATE);
+    constexpr bool PRE_E2 = BPRO == BPRO_PLAIN && BEPI == BEPI_GATE;
+    constexpr bool AHEAD = BPRO == BPRO_PLAIN && sizeof(ST) == 2 && KIN > 64;     // the 64-wide instances keep 3 waves per SIMD without it
+    KsrTile<ST> f[KIN / 64], pf_r, pf_e1, pf_e2;
+    auto fetch_dz = [&](long t) {
+        const long r0 = t * 128 + wv * 32;
+        const int nv = (N - r0) < 32 ? (int)(N - r0 > 0 ? N - r0 : 0) : 32;
+#pragma unroll
+        for (int grp = 0; grp < KIN / 64; ++grp) ksr_co_fetch<ST>(a.dz, r0, nv, a.dz_ld, 64 * grp, lane, f[grp]);
+    };
+    auto fetch_epi = [&](long t) {
+        const long r0 = t * 128 + wv * 32;
+        const int nv = (N - r0) < 32 ? (int)(N - r0 > 0 ? N - r0 : 0) : 32;
+        if constexpr (PRE_R) ksr_co_fetch<ST>(a.resid, r0, nv, 64, 0, lane, pf_r);
+        if constexpr (PRE_E1) ksr_co_fetch<ST>(a.e1, r0, nv, a.e1_ld, a.e1_c0, lane, pf_e1);
+        if constexpr (PRE_E2) ksr_co_fetch<ST>(a.e2, r0, nv, a.e2_ld, a.e2_c0, lane, pf_e2);
+    };
+    if (AHEAD && (long)blockIdx.x < ntiles) { fetch_dz(blockIdx.x); fetch_epi(blockIdx.x); }
+
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         bool live;
         long n, n0w;          // this lane's pixel; first pixel of the wave's 32-pixel run
@@ -83,18 +106,8 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         float* xb = (spatial ? sm.halo : sm.xpose) + wv * KSR_XPOSE_FLOATS;
 
         float dz[KH];
-        // PLAIN: the epilogue operands are fetched together with dz (one memory latency for the whole tile)
-        constexpr bool PRE_R = BPRO == BPRO_PLAIN && (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD);
-        constexpr bool PRE_E1 = BPRO == BPRO_PLAIN && (BEPI == BEPI_RELUMASK || BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD || BEPI == BEPI_GATE);
-        constexpr bool PRE_E2 = BPRO == BPRO_PLAIN && BEPI == BEPI_GATE;
-        KsrTile<ST> pf_r, pf_e1, pf_e2;
         if (BPRO == BPRO_PLAIN) {
-            KsrTile<ST> f[KIN / 64];
-#pragma unroll
-            for (int grp = 0; grp < KIN / 64; ++grp) ksr_co_fetch<ST>(a.dz, n0w, nvalid, a.dz_ld, 64 * grp, lane, f[grp]);
-            if constexpr (PRE_R) ksr_co_fetch<ST>(a.resid, n0w, nvalid, 64, 0, lane, pf_r);
-            if constexpr (PRE_E1) ksr_co_fetch<ST>(a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, pf_e1);
-            if constexpr (PRE_E2) ksr_co_fetch<ST>(a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, pf_e2);
+            if (!AHEAD) { fetch_dz(tile); fetch_epi(tile); }
 #pragma unroll
             for (int grp = 0; grp < KIN / 64; ++grp) {
                 float t[32];
@@ -102,6 +115,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) dz[32 * grp + i] = t[i];
             }
+            if (AHEAD && tile + gridDim.x < ntiles) fetch_dz(tile + gridDim.x);
         } else {
             float g[32];
 #pragma unroll
@@ -181,6 +195,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             if (live && h == 0) a.dpre[n] = a.v[n] > 0.f ? s : 0.f;
         }
         ksr_store32_co<ST>(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
+        if (AHEAD && tile + gridDim.x < ntiles) fetch_epi(tile + gridDim.x);
     }
 }
 
