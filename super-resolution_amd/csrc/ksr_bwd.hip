@@ -79,6 +79,15 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         if constexpr (PRE_E2) ksr_co_fetch<ST>(a.e2, r0, nv, a.e2_ld, a.e2_c0, lane, pf_e2);
     };
     if (AHEAD && (long)blockIdx.x < ntiles) { fetch_dz(blockIdx.x); fetch_epi(blockIdx.x); }
+    // stencil prologues with bf16 storage: the next halo tile is requested while this one is processed
+    constexpr bool HAHEAD = spatial && sizeof(ST) == 2;
+    KsrHalo<ST> hr;
+    auto fetch_halo = [&](long t) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const int tb = (int)(t / ((long)tiles_x * tiles_y));
+        ksr_halo_fetch<ST>(a.halo_src, 64, 0, tb, ty * 4, tx * 32, a.H, a.W, tid, hr);
+    };
+    if (HAHEAD && (long)blockIdx.x < ntiles) fetch_halo(blockIdx.x);
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         bool live;
@@ -94,8 +103,10 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             n0w = (long)b * HW + (long)y * a.W + x0;
             nvalid = (y < a.H) ? ((a.W - x0) < 32 ? a.W - x0 : 32) : 0;
             __syncthreads();
-            ksr_stage_halo<ST>(sm.halo, a.halo_src, 64, 0, b, y0, x0, a.H, a.W, tid);
+            if (!HAHEAD) fetch_halo(tile);
+            ksr_halo_commit<ST>(sm.halo, tid, hr);
             __syncthreads();
+            if (HAHEAD && tile + gridDim.x < ntiles) fetch_halo(tile + gridDim.x);     // in flight during this tile
         } else {
             n = tile * 128 + wv * 32 + tok;
             live = n < N;

@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
 
     const int HW = a.H * a.W;
     const long N = (long)a.B * HW;
-    const bool spatial = (PRO == PRO_DWRELU || PRO == PRO_GATE);
+    constexpr bool spatial = (PRO == PRO_DWRELU || PRO == PRO_GATE);
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
     const long ntiles = spatial ? (long)a.B * tiles_y * tiles_x : (N + 127) / 128;
 
@@ -91,6 +91,15 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
         ksr_co_fetch<ST>(a.in, n0, nv, a.in_ld, 0, lane, ahead);
     };
     if (AHEAD && (long)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
+    // stencil kernels with bf16 storage: likewise for the halo tile (7 x 16 bytes per thread)
+    constexpr bool HAHEAD = spatial && sizeof(ST) == 2;
+    KsrHalo<ST> hr;
+    auto fetch_halo = [&](long t) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const int tb = (int)(t / ((long)tiles_x * tiles_y));
+        ksr_halo_fetch<ST>(a.in, a.in_ld, (PRO == PRO_GATE) ? 64 : 0, tb, ty * 4, tx * 32, a.H, a.W, tid, hr);
+    };
+    if (HAHEAD && (long)blockIdx.x < ntiles) fetch_halo(blockIdx.x);
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         int b, y, x;
@@ -104,10 +113,11 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             live = (y < a.H) && (x < a.W);
             n = (long)b * HW + (long)y * a.W + x;
             // ---- stage the halo tile (rows y0-1..y0+4, cols x0-1..x0+32, 64 channels) ----
-            const int c0 = (PRO == PRO_GATE) ? 64 : 0;
             __syncthreads();   // previous tile's readers are done
-            ksr_stage_halo<ST>(sm.halo, a.in, a.in_ld, c0, b, y0, x0, a.H, a.W, tid);
+            if (!HAHEAD) fetch_halo(tile);
+            ksr_halo_commit<ST>(sm.halo, tid, hr);
             __syncthreads();
+            if (HAHEAD && tile + gridDim.x < ntiles) fetch_halo(tile + gridDim.x);     // in flight during this tile
         } else {
             n = tile * 128 + wv * 32 + tok;
             live = n < N;

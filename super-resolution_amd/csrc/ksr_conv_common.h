@@ -9,37 +9,63 @@
 constexpr int HALO_W = 34, HALO_H = 6, HALO_LD = 68;   // 4 x 32 pixel tile + 1 pixel rim; 64 ch + 4 pad
 constexpr int HALO_FLOATS = HALO_H * HALO_W * HALO_LD;
 
-// Load channels [c0, c0+64) of the (6 x 34) pixel window whose interior starts at (y0, x0) of image b into an
-// fp32 LDS tile.  src is NHWC with `ld` channels per pixel, stored as T; pixels outside the image are zero.
-// All 256 threads call.
+// Channels [c0, c0+64) of the (6 x 34) pixel window whose interior starts at (y0, x0) of image b, as an fp32 LDS
+// tile.  src is NHWC with `ld` channels per pixel, stored as T; pixels outside the image are zero.  Two phases, both
+// called by all 256 threads: ksr_halo_fetch issues every global load of the thread (they are in flight together, and
+// may stay in flight across other work), ksr_halo_commit converts and writes them to LDS.
+template <class T> struct KsrHalo { float4 v[(HALO_H * HALO_W * 16 + 255) / 256]; };
+template <> struct KsrHalo<__bf16> { uint4 v[(HALO_H * HALO_W * 8 + 255) / 256]; };
+
 template <class T>
-__device__ __forceinline__ void ksr_stage_halo(float* __restrict__ halo, const void* __restrict__ src, int ld,
-                                               int c0, int b, int y0, int x0, int H, int W, int tid) {
+__device__ __forceinline__ void ksr_halo_fetch(const void* __restrict__ src, int ld, int c0, int b, int y0, int x0, int H,
+                                               int W, int tid, KsrHalo<T>& r) {
     const long HW = (long)H * W;
-    if constexpr (sizeof(T) == 4) {
-        for (int c = tid; c < HALO_H * HALO_W * 16; c += 256) {
-            const int q = c & 15, pix = c >> 4;
-            const int hx = pix % HALO_W, hy = pix / HALO_W;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + ((long)b * HW + (long)gy * W + gx) * ld + c0 + 4 * q);
-            *reinterpret_cast<float4*>(&halo[pix * HALO_LD + 4 * q]) = v;
+    constexpr int PER = sizeof(T) == 4 ? 16 : 8;                 // 16-byte pieces per pixel
+    constexpr int NIT = (HALO_H * HALO_W * PER + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = tid + 256 * it;
+        const int q = c % PER, pix = c / PER;
+        const int hx = pix % HALO_W, hy = pix / HALO_W;
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+        const bool in = c < HALO_H * HALO_W * PER && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const long e = ((long)b * HW + (long)gy * W + gx) * ld + c0;
+        if constexpr (sizeof(T) == 4) {
+            r.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in) r.v[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + e + 4 * q);
+        } else {
+            r.v[it] = make_uint4(0u, 0u, 0u, 0u);
+            if (in) r.v[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(src) + e + 8 * q);
         }
-    } else {
-        for (int c = tid; c < HALO_H * HALO_W * 8; c += 256) {
-            const int q = c & 7, pix = c >> 3;
-            const int hx = pix % HALO_W, hy = pix / HALO_W;
-            const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
-            uint4 w = make_uint4(0u, 0u, 0u, 0u);
-            if (gy >= 0 && gy < H && gx >= 0 && gx < W)
-                w = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(src) + ((long)b * HW + (long)gy * W + gx) * ld + c0 + 8 * q);
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void ksr_halo_commit(float* __restrict__ halo, int tid, const KsrHalo<T>& r) {
+    constexpr int PER = sizeof(T) == 4 ? 16 : 8;
+    constexpr int NIT = (HALO_H * HALO_W * PER + 255) / 256;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = tid + 256 * it;
+        const int q = c % PER, pix = c / PER;
+        if (c >= HALO_H * HALO_W * PER) continue;
+        if constexpr (sizeof(T) == 4) {
+            *reinterpret_cast<float4*>(&halo[pix * HALO_LD + 4 * q]) = r.v[it];
+        } else {
             float x[8];
-            ksr_unpack8(w, x);
+            ksr_unpack8(r.v[it], x);
             *reinterpret_cast<float4*>(&halo[pix * HALO_LD + 8 * q]) = make_float4(x[0], x[1], x[2], x[3]);
             *reinterpret_cast<float4*>(&halo[pix * HALO_LD + 8 * q + 4]) = make_float4(x[4], x[5], x[6], x[7]);
         }
     }
+}
+
+template <class T>
+__device__ __forceinline__ void ksr_stage_halo(float* __restrict__ halo, const void* __restrict__ src, int ld,
+                                               int c0, int b, int y0, int x0, int H, int W, int tid) {
+    KsrHalo<T> r;
+    ksr_halo_fetch<T>(src, ld, c0, b, y0, x0, H, W, tid, r);
+    ksr_halo_commit<T>(halo, tid, r);
 }
 
 // Stage depthwise weights [64][9] as [tap][channel]; FLIP stores tap 8-t (transposed convolution).
