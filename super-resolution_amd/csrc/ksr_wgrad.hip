@@ -402,25 +402,38 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
     float acc[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) acc[i] = 0.f;
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
-        const int b = (int)(tile / ((long)tiles_x * tiles_y));
+    // Both inputs of a tile are requested one tile ahead: the 32 gradient values of this thread's (row, channel) and
+    // its share of the halo tile (rows / columns outside the image are loaded from a clamped address and zeroed later)
+    KsrHalo<T> hr;
+    T dnext[32];
+    auto fetch = [&](long t) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const int b = (int)(t / ((long)tiles_x * tiles_y));
         const int y0 = ty * 4, x0 = tx * 32;
-        // all 32 gradient values of this (row, channel) first: independent loads whose latency overlaps
-        // the halo staging (rows / columns outside the image are loaded from a clamped address and zeroed)
         const int y = y0 + row;
         const int yc = y < a.H ? y : a.H - 1;
         const int xmax = (a.W - x0) < 32 ? (a.W - x0) : 32;
         const T* dsp = reinterpret_cast<const T*>(a.ds) + ((long)b * HW + (long)yc * a.W + x0) * a.ds_ld + a.ds_c0 + c;
-        float dv[32];
 #pragma unroll
         for (int col = 0; col < 32; ++col) {
             const int cc = col < xmax ? col : xmax - 1;
-            dv[col] = (float)dsp[(long)cc * a.ds_ld];
+            dnext[col] = dsp[(long)cc * a.ds_ld];
         }
+        ksr_halo_fetch<T>(a.in, a.in_ld, a.in_c0, b, y0, x0, a.H, a.W, tid, hr);
+    };
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const int y0 = ty * 4, x0 = tx * 32;
+        const int y = y0 + row;
+        const int xmax = (a.W - x0) < 32 ? (a.W - x0) : 32;
+        float dv[32];
+#pragma unroll
+        for (int col = 0; col < 32; ++col) dv[col] = (float)dnext[col];
         __syncthreads();
-        ksr_stage_halo<T>(halo, a.in, a.in_ld, a.in_c0, b, y0, x0, a.H, a.W, tid);
+        ksr_halo_commit<T>(halo, tid, hr);
         __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         {
 #pragma unroll
             for (int col = 0; col < 32; ++col) {
