@@ -69,14 +69,14 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         const long r0 = t * 128 + wv * 32;
         const int nv = (N - r0) < 32 ? (int)(N - r0 > 0 ? N - r0 : 0) : 32;
 #pragma unroll
-        for (int grp = 0; grp < KIN / 64; ++grp) ksr_co_fetch<ST>(a.dz, r0, nv, a.dz_ld, 64 * grp, lane, f[grp]);
+        for (int grp = 0; grp < KIN / 64; ++grp) ksr_co_fetch<ST, AHEAD>(a.dz, r0, nv, a.dz_ld, 64 * grp, lane, f[grp]);
     };
     auto fetch_epi = [&](long t) {
         const long r0 = t * 128 + wv * 32;
         const int nv = (N - r0) < 32 ? (int)(N - r0 > 0 ? N - r0 : 0) : 32;
-        if constexpr (PRE_R) ksr_co_fetch<ST>(a.resid, r0, nv, 64, 0, lane, pf_r);
-        if constexpr (PRE_E1) ksr_co_fetch<ST>(a.e1, r0, nv, a.e1_ld, a.e1_c0, lane, pf_e1);
-        if constexpr (PRE_E2) ksr_co_fetch<ST>(a.e2, r0, nv, a.e2_ld, a.e2_c0, lane, pf_e2);
+        if constexpr (PRE_R) ksr_co_fetch<ST, AHEAD>(a.resid, r0, nv, 64, 0, lane, pf_r);
+        if constexpr (PRE_E1) ksr_co_fetch<ST, AHEAD>(a.e1, r0, nv, a.e1_ld, a.e1_c0, lane, pf_e1);
+        if constexpr (PRE_E2) ksr_co_fetch<ST, AHEAD>(a.e2, r0, nv, a.e2_ld, a.e2_c0, lane, pf_e2);
     };
     if (AHEAD && (long)blockIdx.x < ntiles) { fetch_dz(blockIdx.x); fetch_epi(blockIdx.x); }
     // stencil prologues with bf16 storage: the next halo tile is requested while this one is processed
@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
                 o2[i] = dA[i] * val[i];
                 dA[i] = val[i] > 0.f ? dA[i] * gte[i] : 0.f;
             }
-            ksr_store32_co<ST>(xb, a.out2, n0w, nvalid, 64, 0, lane, o2);
+            ksr_store32_co<ST, !AHEAD>(xb, a.out2, n0w, nvalid, 64, 0, lane, o2);
         }
         if (BEPI == BEPI_STEM) {
             float s = 0.f;
@@ -205,7 +205,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             s = ksr_pair_sum(s);
             if (live && h == 0) a.dpre[n] = a.v[n] > 0.f ? s : 0.f;
         }
-        ksr_store32_co<ST>(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
+        ksr_store32_co<ST, !AHEAD>(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
         if (AHEAD && tile + gridDim.x < ntiles) fetch_epi(tile + gridDim.x);
     }
 }

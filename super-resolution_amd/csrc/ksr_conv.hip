@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
     auto fetch_tile = [&](long tile) {
         const long n0 = tile * 128 + wv * 32;
         const int nv = (N - n0) < 32 ? (int)(N - n0 > 0 ? N - n0 : 0) : 32;
-        ksr_co_fetch<ST>(a.in, n0, nv, a.in_ld, 0, lane, ahead);
+        ksr_co_fetch<ST, true>(a.in, n0, nv, a.in_ld, 0, lane, ahead);
     };
     if (AHEAD && (long)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
     // stencil kernels with bf16 storage: likewise for the halo tile (7 x 16 bytes per thread)
@@ -189,8 +189,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
                 o[q] = apply_act<ACT>(acc[2 * grp][q]);
                 o[16 + q] = apply_act<ACT>(acc[2 * grp + 1][q]);
             }
-            ksr_store32_co<ST>(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
-            if (a.out32) ksr_store32_co<float>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            ksr_store32_co<ST, !AHEAD>(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            if (a.out32) ksr_store32_co<float, !AHEAD>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
         }
     }
 }

@@ -16,6 +16,7 @@
 // Exact fp32: the MFMA is a k-ordered fmaf chain (one rounding per product).
 #pragma once
 #include "ksr_common.h"
+#include <type_traits>
 
 #if defined(__HIPCC__)
 
@@ -248,24 +249,51 @@ template <> struct KsrTile<__bf16> { uint4 v[4]; };
 
 // Phase 1: issue the global loads of rows [n0, n0+32) (nvalid real rows, the rest read as 0), channels
 // [c0, c0+64) of a tensor with ld elements per row.  Several tiles can be in flight.
-template <class T>
+template <class T, bool PREDICATED = false>
 __device__ __forceinline__ void ksr_co_fetch(const void* __restrict__ base, long n0, int nvalid, int ld, int c0, int lane,
                                              KsrTile<T>& t) {
+    if constexpr (PREDICATED) {
+        // per-row predicated loads: fewer instructions when the tile is requested one loop iteration ahead
+        if constexpr (sizeof(T) == 4) {
+            const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = 4 * i + r4;
+                t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < nvalid) t.v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * ld + c0 + c4);
+            }
+        } else {
+            const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 8 * i + r8;
+                t.v[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (row < nvalid) t.v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * ld + c0 + c8);
+            }
+        }
+        return;
+    }
+
+    // no branches: rows past nvalid are read from row 0 of the tile (or of the tensor when the tile is empty) and
+    // zeroed afterwards, so that the loads can stay in flight across loop iterations and uniform branches
+    const long nb = nvalid > 0 ? n0 : 0;
     if constexpr (sizeof(T) == 4) {
         const int r4 = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = 4 * i + r4;
-            t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nvalid) t.v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * ld + c0 + c4);
+            const bool ok = row < nvalid;
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (nb + (ok ? row : 0)) * ld + c0 + c4);
+            t.v[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     } else {
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int row = 8 * i + r8;
-            t.v[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (row < nvalid) t.v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * ld + c0 + c8);
+            const bool ok = row < nvalid;
+            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (nb + (ok ? row : 0)) * ld + c0 + c8);
+            t.v[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
         }
     }
 }
@@ -309,16 +337,22 @@ __device__ __forceinline__ void ksr_load32_co(float* __restrict__ xb, const void
     ksr_co_finish<T>(xb, lane, t, x);
 }
 // fp32 LDS tile -> rows [n0, n0 + nvalid) of the tensor (caller has written the tile and fenced)
-template <class T>
+template <class T, bool TWO_PATH = true>
 __device__ __forceinline__ void ksr_co_from_lds(const float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                 int ld, int c0, int lane) {
+    // full tiles (all but the last one of a tensor) take a path without per-row predicates; nvalid is wave-uniform.
+    // TWO_PATH = false keeps the single predicated path: a kernel that has loads in flight across this call (tiles
+    // requested one iteration ahead) loses them at the branch's join otherwise
+    auto body = [&](auto guard) {
+        constexpr bool GUARD = decltype(guard)::value;
+
     if constexpr (sizeof(T) == 4) {
         const int r4 = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = 4 * i + r4;
             const float4 v = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE_LD + c4);
-            if (row < nvalid) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4) = v;
+            if (!GUARD || row < nvalid) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4) = v;
         }
     } else {
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
@@ -328,12 +362,15 @@ __device__ __forceinline__ void ksr_co_from_lds(const float* __restrict__ xb, vo
             const float* sp = xb + row * KSR_XPOSE_LD + c8;
             const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
             const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if (row < nvalid) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8) = ksr_pack8(x);
+            if (!GUARD || row < nvalid) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8) = ksr_pack8(x);
         }
     }
+    };
+    if (TWO_PATH && __builtin_amdgcn_readfirstlane(nvalid) == 32) body(std::false_type{});
+    else body(std::true_type{});
 }
 // The reverse of ksr_load32_co: x (half layout) -> rows [n0, n0 + nvalid).
-template <class T>
+template <class T, bool TWO_PATH = true>
 __device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                int ld, int c0, int lane, const float (&x)[32]) {
     float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
@@ -341,21 +378,27 @@ __device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, void* __r
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     ksr_wave_fence();
-    ksr_co_from_lds<T>(xb, base, n0, nvalid, ld, c0, lane);
+    ksr_co_from_lds<T, TWO_PATH>(xb, base, n0, nvalid, ld, c0, lane);
 }
 
 // 32-channel rows (lane half h holds channels 16h .. 16h+15): same scheme with rows padded to 36 floats.
 constexpr int KSR_XPOSE16_LD = 36;
 // fp32 LDS tile [32][36] <-> rows of a tensor with ld elements per row, channels c0 .. c0+31
-template <class T>
+template <class T, bool TWO_PATH = true>
 __device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                   int ld, int c0, int lane) {
+    // full tiles (all but the last one of a tensor) take a path without per-row predicates; nvalid is wave-uniform.
+    // TWO_PATH = false keeps the single predicated path: a kernel that has loads in flight across this call (tiles
+    // requested one iteration ahead) loses them at the branch's join otherwise
+    auto body = [&](auto guard) {
+        constexpr bool GUARD = decltype(guard)::value;
+
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
             const float4 v = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE16_LD + c4);
-            if (row < nvalid) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4) = v;
+            if (!GUARD || row < nvalid) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4) = v;
         }
     } else {
 #pragma unroll
@@ -364,9 +407,12 @@ __device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, 
             const float* sp = xb + row * KSR_XPOSE16_LD + c8;
             const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
             const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if (row < nvalid) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8) = ksr_pack8(x);
+            if (!GUARD || row < nvalid) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8) = ksr_pack8(x);
         }
     }
+    };
+    if (TWO_PATH && __builtin_amdgcn_readfirstlane(nvalid) == 32) body(std::false_type{});
+    else body(std::true_type{});
 }
 // registers of one fetched 32 x 32 tile
 template <class T> struct KsrTile16 { float4 v[4]; };
@@ -374,19 +420,22 @@ template <> struct KsrTile16<__bf16> { uint4 v[2]; };
 // Phase 1 for a tensor with 32 channels per row (rows [n0, n0+32), nvalid real ones)
 template <class T>
 __device__ __forceinline__ void ksr_co16_fetch(const void* __restrict__ base, long n0, int nvalid, int lane, KsrTile16<T>& t) {
+    const long nb = nvalid > 0 ? n0 : 0;      // branch-free, as ksr_co_fetch
     if constexpr (sizeof(T) == 4) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
-            t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nvalid) t.v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * 32 + c4);
+            const bool ok = row < nvalid;
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (nb + (ok ? row : 0)) * 32 + c4);
+            t.v[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int idx = i * 64 + lane, row = idx >> 2, c8 = (idx & 3) * 8;
-            t.v[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (row < nvalid) t.v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * 32 + c8);
+            const bool ok = row < nvalid;
+            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (nb + (ok ? row : 0)) * 32 + c8);
+            t.v[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
         }
     }
 }
@@ -426,7 +475,7 @@ __device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const void
     ksr_co16_fetch<T>(base, n0, nvalid, lane, t);
     ksr_co16_finish<T>(xb, lane, t, x);
 }
-template <class T>
+template <class T, bool TWO_PATH = true>
 __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                int lane, const float (&x)[16]) {
     float* wp = xb + (lane & 31) * KSR_XPOSE16_LD + 16 * (lane >> 5);
@@ -434,7 +483,7 @@ __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     ksr_wave_fence();
-    ksr_co16_from_lds<T>(xb, base, n0, nvalid, 32, 0, lane);
+    ksr_co16_from_lds<T, TWO_PATH>(xb, base, n0, nvalid, 32, 0, lane);
 }
 
 // Sum of v over the two lanes that share a token (lanes l and l^32).

@@ -140,8 +140,8 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
     auto fetch_next = [&](int t) {
         const long r0 = (long)t * 128 + wv * 32, left = (long)S * HW - r0;
         const int nv = left < 32 ? (int)(left > 0 ? left : 0) : 32;
-        if (!a.in32) ksr_co_fetch<ST>(a.in, r0, nv, 64, 0, lane, nx_in);
-        if (MODE == 1) ksr_co_fetch<ST>(a.ctx_in, r0, nv, 64, 0, lane, nx_ctx);
+        if (!a.in32) ksr_co_fetch<ST, true>(a.in, r0, nv, 64, 0, lane, nx_in);
+        if (MODE == 1) ksr_co_fetch<ST, true>(a.ctx_in, r0, nv, 64, 0, lane, nx_ctx);
     };
     if (AHEAD && (int)blockIdx.x < ntiles) fetch_next(blockIdx.x);
 
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
         const int nvalid = POST ? (((long)S * HW - n0w) < 32 ? (int)((long)S * HW - n0w > 0 ? (long)S * HW - n0w : 0) : 32) : 0;
         float* xb = sm.xpose + (POST ? wv * KSR_XPOSE_FLOATS : 0);
         auto st32 = [&](float* base, const float (&v)[32]) {
-            if (POST) ksr_store32_co<ST>(xb, base, n0w, nvalid, 64, 0, lane, v);
+            if (POST) ksr_store32_co<ST, !AHEAD>(xb, base, n0w, nvalid, 64, 0, lane, v);
             else if (live) ksr_storen<ST, 32>(base, n * 64 + 32 * h, v);
         };
 
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
                     hm[i] = ksr_keep(a.seed, 2u, (unsigned long long)n * 32 + 16 * h, i, keep) ? hm[i] * inv_keep : 0.f;
             }
             if (TRAIN && a.sv_hmid) {
-                if (POST) ksr_store16_co<ST>(xb, a.sv_hmid, n0w, nvalid, lane, hm);
+                if (POST) ksr_store16_co<ST, !AHEAD>(xb, a.sv_hmid, n0w, nvalid, lane, hm);
                 else if (live) ksr_storen<ST, 16>(a.sv_hmid, n * 32 + 16 * h, hm);
             }
             f32x16 acc2[2];
