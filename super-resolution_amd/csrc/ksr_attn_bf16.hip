@@ -50,9 +50,32 @@ struct RowMap {
 };
 
 // Lane-linear fetch of 32 rows x 64 channels (channels c0.. of a tensor with ld elements per row, stored as T).
-template <class T>
+// SELECT: no branch (absent rows read row 0 and are zeroed afterwards) - fewer stalls where the registers allow it.
+template <class T, bool SELECT = false>
 __device__ __forceinline__ void fetch_rows(const void* __restrict__ base, const RowMap& rm, int ld, int c0, int lane,
                                            KsrTile<T>& t) {
+    if constexpr (SELECT) {
+        if constexpr (sizeof(T) == 4) {
+            const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long n = rm(4 * i + r4);
+                const bool ok = n >= 0;
+                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (ok ? n : 0) * ld + c0 + c4);
+                t.v[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+            }
+        } else {
+            const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const long n = rm(8 * i + r8);
+                const bool ok = n >= 0;
+                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (ok ? n : 0) * ld + c0 + c8);
+                t.v[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
+            }
+        }
+        return;
+    }
     if constexpr (sizeof(T) == 4) {
         const int r4 = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
@@ -195,9 +218,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
         bf16x8 qb[2][2];
         {
             KsrTile<ST> fq, fk, fv;
-            fetch_rows<ST>(a.qkv, rm, 192, 0, lane, fq);
-            fetch_rows<ST>(a.qkv, rm, 192, 64, lane, fk);
-            fetch_rows<ST>(a.qkv, rm, 192, 128, lane, fv);
+            fetch_rows<ST, true>(a.qkv, rm, 192, 0, lane, fq);
+            fetch_rows<ST, true>(a.qkv, rm, 192, 64, lane, fk);
+            fetch_rows<ST, true>(a.qkv, rm, 192, 128, lane, fv);
             float x[2][2][8];
             finish_split<ST>(xb, lane, fq, x);
             pack_split(x, scale, qb);
