@@ -82,8 +82,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
     const long ntiles = spatial ? (long)a.B * tiles_y * tiles_x : (N + 127) / 128;
 
-    // plain 1x1 conv with bf16 storage: the next tile's rows are requested before this tile's product
-    constexpr bool AHEAD = (PRO == PRO_PLAIN) && sizeof(ST) == 2;
+    // plain 1x1 conv (bf16 storage, or fp32 up to 128 outputs): the next tile's rows are requested before this tile's product
+    constexpr bool AHEAD = (PRO == PRO_PLAIN) && (sizeof(ST) == 2 || NOUT <= 128);
     KsrTile<ST> ahead;
     auto fetch_tile = [&](long tile) {
         const long n0 = tile * 128 + wv * 32;
