@@ -235,15 +235,17 @@ def main():
     roofline = None
     cpu = None
     inference = None
+    # ---- per-kernel live timing (events on the launch stream), separate short run.  Every rank steps (the training
+    # step contains the gradient all-reduce, a collective); only rank 0 records.
+    nlaunch = max(3, min(args.steps, 10))
     if rank == 0:
-        # ---- per-kernel live timing (events on the launch stream), separate short run ----
         _lib.PROFILE = {}
-        for _ in range(max(3, min(args.steps, 10))):
-            step()
-        torch.cuda.synchronize()
+    for _ in range(nlaunch):
+        step()
+    sync()
+    if rank == 0:
         prof = {k: [s.elapsed_time(e) for s, e in v] for k, v in _lib.PROFILE.items()}
         _lib.PROFILE = None
-        nlaunch = max(3, min(args.steps, 10))
         totals = {k: sum(v) / nlaunch for k, v in prof.items()}            # ms per step per entry point
         dom = max(totals, key=totals.get)
         avg_ms = sum(prof[dom]) / len(prof[dom])
@@ -303,6 +305,8 @@ def main():
                          "ms_per_frame_rgb_in_rgb_out": round(tr * 1e3, 4),
                          "workload": "x4 SR inference fp32 eval, 960x540 -> 3840x2160, 1 GPU (BASELINE configs[1])"}
 
+    if args.workload == "train":
+        ts.close()                      # every rank: destroys the gradient communicator
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
