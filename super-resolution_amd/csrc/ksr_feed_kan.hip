@@ -240,8 +240,16 @@ int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
 
 }  // namespace
 
+// Fused kernels exist for cubic splines (the reference's default spline_order) with upscale 2 or 4 and
+// grid_size in {3, 5, 8, 10, 16}, i.e. grid_size + spline_order = n_coef in {6, 8, 11, 13, 19}.
+#define KSR_FEED_CONFIGS(X) X(2, 6) X(2, 8) X(2, 11) X(2, 13) X(2, 19) X(4, 6) X(4, 8) X(4, 11) X(4, 13) X(4, 19)
+
 extern "C" int ksr_feed_kan_supported(int upscale, int n_coef, int spline_order) {
-    return (spline_order == 3) && ((upscale == 2 && n_coef == 8) || (upscale == 4 && (n_coef == 8 || n_coef == 19)));
+    if (spline_order != 3) return 0;
+#define KSR_X(R, KC) if (upscale == R && n_coef == KC) return 1;
+    KSR_FEED_CONFIGS(KSR_X)
+#undef KSR_X
+    return 0;
 }
 
 extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
@@ -261,9 +269,10 @@ extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t i
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
-    if (upscale == 2) return launch_feed_fwd<2, 8, 3>(a, kn, stream);
-    if (n_coef == 8) return launch_feed_fwd<4, 8, 3>(a, kn, stream);
-    return launch_feed_fwd<4, 19, 3>(a, kn, stream);
+#define KSR_X(R, KC) if (upscale == R && n_coef == KC) return launch_feed_fwd<R, KC, 3>(a, kn, stream);
+    KSR_FEED_CONFIGS(KSR_X)
+#undef KSR_X
+    return KSR_ERR_UNSUPPORTED;
 }
 
 // Per-half padded length of the lane-ordered parameter gradient: gparam is [N, 2, this].
@@ -287,7 +296,8 @@ extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, co
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
-    if (upscale == 2) return launch_feed_bwd<2, 8, 3>(a, kn, stream);
-    if (n_coef == 8) return launch_feed_bwd<4, 8, 3>(a, kn, stream);
-    return launch_feed_bwd<4, 19, 3>(a, kn, stream);
+#define KSR_X(R, KC) if (upscale == R && n_coef == KC) return launch_feed_bwd<R, KC, 3>(a, kn, stream);
+    KSR_FEED_CONFIGS(KSR_X)
+#undef KSR_X
+    return KSR_ERR_UNSUPPORTED;
 }

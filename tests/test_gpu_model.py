@@ -211,6 +211,36 @@ def test_gradients_odd_sizes_vs_oracle():
         assert rel <= GRAD_REL, f"{n}: rel-L2 {rel:.3e}"
 
 
+@pytest.mark.parametrize("r,G", [(2, 3), (2, 8), (2, 10), (2, 16), (4, 3), (4, 8), (4, 10)])
+def test_other_grid_sizes_vs_oracle(r, G):
+    """The grid sizes without a reference fixture (cubic splines): forward and all gradients against the oracle, whose
+    basis / KAN code is pinned by the G = 5 and G = 16 fixtures; one TrainStep in bf16 storage mode must also run."""
+    from kan_sr.module import ConvSepKan
+    torch.manual_seed(100 + 10 * r + G)
+    B, H, W, O = 2, 10, 37, r * r
+    p0 = orc.random_params(O, G, 3, seed=31 + G)
+    m = ConvSepKan([1], [O], [3], G, 3, 0.1, [-1, 1], r)
+    m.load_state_dict(p0)
+    x = torch.rand(B, 3, H, W) * 1.6 - 0.3            # reaches the outer knot intervals as well
+    p = {n: v.clone().requires_grad_() for n, v in p0.items()}
+    yr = orc.conv_sep_kan_forward(x, p, out_channels=[O], grid_size=G, spline_order=3, grid_range=[-1, 1], upscale=r)
+    gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(5))
+    (yr * gy).sum().backward()
+    m = m.cuda().eval()
+    y = m(x.cuda())
+    assert_fwd(y, yr, atol=2e-5)
+    y.backward(gy.cuda())
+    for n, prm in m.named_parameters():
+        rel = rel_l2(prm.grad.cpu(), p[n].grad)
+        assert rel <= GRAD_REL, f"{n}: rel-L2 {rel:.3e}"
+    from kan_sr.train import TrainStep
+    m.train()
+    m.precision = "bf16s"
+    ts = TrainStep(m, lr=1e-3, loss="l1+ssim")
+    loss = float(ts.step(x.cuda().clamp(0, 1), torch.rand(B, 3, r * H, r * W).cuda()))
+    assert loss == loss and 0.0 < loss < 2.0
+
+
 def test_backward_is_bitwise_reproducible():
     g, m = _load_model_golden(4, 5, 3)
     x, gy = t(g["x"]).cuda(), t(g["gy"]).cuda()
