@@ -135,7 +135,7 @@ int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, float* out, c
  * upscale^2.  Writes plane 0 of out [B, C, rH, rW] (out_batch_stride elements between images).
  * save_us [N, O, 2] optional: (spline weight, spline sum) per output for the backward.
  * ksr_feed_kan_supported() tells whether a fused kernel exists for the configuration: spline_order 3,
- * upscale 2 or 4, n_coef = grid_size + spline_order in {6, 8, 11, 13, 19}. */
+ * upscale 2 or 4, n_coef = grid_size + spline_order in {6, 8, 11, 13, 19}; spline_order 1 / 2 with grid_size 5. */
 int ksr_feed_kan_supported(int upscale, int n_coef, int spline_order);
 int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
                      const float* feed_b, float* out, int64_t out_batch_stride, float* save_us, int B, int H,

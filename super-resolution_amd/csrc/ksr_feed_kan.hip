@@ -240,13 +240,15 @@ int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
 
 }  // namespace
 
-// Fused kernels exist for cubic splines (the reference's default spline_order) with upscale 2 or 4 and
-// grid_size in {3, 5, 8, 10, 16}, i.e. grid_size + spline_order = n_coef in {6, 8, 11, 13, 19}.
-#define KSR_FEED_CONFIGS(X) X(2, 6) X(2, 8) X(2, 11) X(2, 13) X(2, 19) X(4, 6) X(4, 8) X(4, 11) X(4, 13) X(4, 19)
+// Fused kernels exist for upscale 2 or 4 with cubic splines (the reference's default spline_order) and grid_size in
+// {3, 5, 8, 10, 16}, i.e. n_coef = grid_size + spline_order in {6, 8, 11, 13, 19}, and with grid_size 5 for the
+// linear and quadratic splines (n_coef 6 and 7).
+#define KSR_FEED_CONFIGS(X)                                                                                   \
+    X(2, 6, 3) X(2, 8, 3) X(2, 11, 3) X(2, 13, 3) X(2, 19, 3) X(4, 6, 3) X(4, 8, 3) X(4, 11, 3) X(4, 13, 3) X(4, 19, 3) \
+    X(2, 6, 1) X(2, 7, 2) X(4, 6, 1) X(4, 7, 2)
 
 extern "C" int ksr_feed_kan_supported(int upscale, int n_coef, int spline_order) {
-    if (spline_order != 3) return 0;
-#define KSR_X(R, KC) if (upscale == R && n_coef == KC) return 1;
+#define KSR_X(R, KC, KO) if (upscale == R && n_coef == KC && spline_order == KO) return 1;
     KSR_FEED_CONFIGS(KSR_X)
 #undef KSR_X
     return 0;
@@ -269,7 +271,7 @@ extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t i
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
-#define KSR_X(R, KC) if (upscale == R && n_coef == KC) return launch_feed_fwd<R, KC, 3>(a, kn, stream);
+#define KSR_X(R, KC, KO) if (upscale == R && n_coef == KC && spline_order == KO) return launch_feed_fwd<R, KC, KO>(a, kn, stream);
     KSR_FEED_CONFIGS(KSR_X)
 #undef KSR_X
     return KSR_ERR_UNSUPPORTED;
@@ -296,7 +298,7 @@ extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, co
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
-#define KSR_X(R, KC) if (upscale == R && n_coef == KC) return launch_feed_bwd<R, KC, 3>(a, kn, stream);
+#define KSR_X(R, KC, KO) if (upscale == R && n_coef == KC && spline_order == KO) return launch_feed_bwd<R, KC, KO>(a, kn, stream);
     KSR_FEED_CONFIGS(KSR_X)
 #undef KSR_X
     return KSR_ERR_UNSUPPORTED;

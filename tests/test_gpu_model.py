@@ -211,19 +211,21 @@ def test_gradients_odd_sizes_vs_oracle():
         assert rel <= GRAD_REL, f"{n}: rel-L2 {rel:.3e}"
 
 
-@pytest.mark.parametrize("r,G", [(2, 3), (2, 8), (2, 10), (2, 16), (4, 3), (4, 8), (4, 10)])
-def test_other_grid_sizes_vs_oracle(r, G):
-    """The grid sizes without a reference fixture (cubic splines): forward and all gradients against the oracle, whose
-    basis / KAN code is pinned by the G = 5 and G = 16 fixtures; one TrainStep in bf16 storage mode must also run."""
+@pytest.mark.parametrize("r,G,k", [(2, 3, 3), (2, 8, 3), (2, 10, 3), (2, 16, 3), (4, 3, 3), (4, 8, 3), (4, 10, 3),
+                                   (2, 5, 1), (2, 5, 2), (4, 5, 1), (4, 5, 2)])
+def test_other_grid_sizes_vs_oracle(r, G, k):
+    """The (grid size, spline order) pairs without a full-model reference fixture: forward and all gradients against
+    the oracle, whose basis / KAN code is pinned by the bspline fixtures (orders 1-3) and the G = 5 / G = 16 model
+    fixtures; one TrainStep in bf16 storage mode must also run."""
     from kan_sr.module import ConvSepKan
-    torch.manual_seed(100 + 10 * r + G)
+    torch.manual_seed(100 + 10 * r + G + k)
     B, H, W, O = 2, 10, 37, r * r
-    p0 = orc.random_params(O, G, 3, seed=31 + G)
-    m = ConvSepKan([1], [O], [3], G, 3, 0.1, [-1, 1], r)
+    p0 = orc.random_params(O, G, k, seed=31 + G)
+    m = ConvSepKan([1], [O], [3], G, k, 0.1, [-1, 1], r)
     m.load_state_dict(p0)
     x = torch.rand(B, 3, H, W) * 1.6 - 0.3            # reaches the outer knot intervals as well
     p = {n: v.clone().requires_grad_() for n, v in p0.items()}
-    yr = orc.conv_sep_kan_forward(x, p, out_channels=[O], grid_size=G, spline_order=3, grid_range=[-1, 1], upscale=r)
+    yr = orc.conv_sep_kan_forward(x, p, out_channels=[O], grid_size=G, spline_order=k, grid_range=[-1, 1], upscale=r)
     gy = torch.randn(yr.shape, generator=torch.Generator().manual_seed(5))
     (yr * gy).sum().backward()
     m = m.cuda().eval()
@@ -232,7 +234,8 @@ def test_other_grid_sizes_vs_oracle(r, G):
     y.backward(gy.cuda())
     for n, prm in m.named_parameters():
         rel = rel_l2(prm.grad.cpu(), p[n].grad)
-        assert rel <= GRAD_REL, f"{n}: rel-L2 {rel:.3e}"
+        # the 1- and 9-element stem tensors are cancelling sums over all pixels: fp32 summation order shows at 1e-4
+        assert rel <= (GRAD_REL if prm.numel() >= 64 else 10 * GRAD_REL), f"{n}: rel-L2 {rel:.3e}"
     from kan_sr.train import TrainStep
     m.train()
     m.precision = "bf16s"
