@@ -61,7 +61,7 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         "ksr_batch_tx_layer_bwd_attn": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
         "ksr_in_proj_bwd": ("hbm", 2 * 2 * 192 * 64, 2 * (768 + 256 + 256 + 256), pk),
         "ksr_gate_pw_bwd": ("hbm", 2 * 2 * 64 * 64, 2 * 1280, pk),
-        "ksr_fn1_bwd": ("hbm", 2 * (2 * 128 * 64 + 2 * 9 * 64), 2 * 1280, pk),
+        "ksr_fn1_bwd": ("hbm", 2 * (2 * 128 * 64 + 2 * 9 * 64), 2 * 1280 - 512, pk),   # the stem call writes neither dx nor dt[:, 64:]
         "ksr_pw2_bwd": ("hbm", 2 * 64 * 64, 768, pk),
         "ksr_pw1_bwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 1024, pk),
         "ksr_wgrad": ("hbm", 2 * wg_jk, wg_bytes, pk),

@@ -192,10 +192,14 @@ int ksr_gate_pw_bwd(const float* dz, const float* fn2_w, const float* gate_saved
 
 /* fn_1 (1x1 conv 64 -> 128 + ReLU) backward.  Completes dt[:, 64:128] = convT3x3(dgate) * (t[:, 64:] > 0),
  * then dx [N,64] = dt * fn_1.weight.  stem = 1: the conv's input was ffn1 (ksr_stem_fwd); additionally
- * dpre [N] = (sum_c dx[c] * pointwise2.weight[c]) * (v > 0), the gradient at ffn1's depthwise output. */
+ * dpre [N] = (sum_c dx[c] * pointwise2.weight[c]) * (v > 0), the gradient at ffn1's depthwise output.
+ * stem with sums_slab (3 * 512 * 128 floats of workspace, else NULL): the kernel also reduces over all pixels
+ * dt_sums[0][c] = sum dt[n,c] v[n], dt_sums[1][c] = sum dt[n,c] (c < 128; rows 128 floats apart) and
+ * dx_sums[c] = sum dx[n,c] v[n], dx_sums[dx_row_stride + c] = sum dx[n,c] (c < 64) - everything the stem's
+ * parameter gradients need of dt[:, 64:128] and dx, which are then not written (dx may be NULL). */
 int ksr_fn1_bwd(float* dt, const float* dgate, const float* gate_w, const float* t_saved, const float* fn1_w,
-                float* dx, int stem, const float* v_saved, const float* pw2_w, float* dpre, int B, int H, int W,
-                ksr_stream_t stream);
+                float* dx, int stem, const float* v_saved, const float* pw2_w, float* dpre, float* sums_slab,
+                float* dt_sums, float* dx_sums, int dx_row_stride, int B, int H, int W, ksr_stream_t stream);
 
 /* FFN.pointwise2 backward: ds [N,64] = (dy * pointwise2.weight) * (operand_saved > 0). */
 int ksr_pw2_bwd(const float* dy, const float* pw2_w, const float* operand_saved, float* ds, int B, int H, int W,

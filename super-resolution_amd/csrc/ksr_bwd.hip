@@ -25,6 +25,7 @@ struct BwdArgs {
     float* out1; int out1_ld, out1_c0;
     float* out2;                                // [N,64]
     const float* v; const float* p2w; float* dpre;   // STEM epilogue
+    float* sums_slab;                           // STEM, optional: [3][gridDim.x][2][64] per-workgroup column sums
     int B, H, W;
 };
 
@@ -89,6 +90,10 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     };
     if (HAHEAD && (long)blockIdx.x < ntiles) fetch_halo(blockIdx.x);
 
+    // STEM with sums_slab: sum_n d[n,c] * v[n] and sum_n d[n,c] for d = the two halves of dz and the output (lane = c)
+    float cs[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    const bool col_sums = BEPI == BEPI_STEM && a.sums_slab != nullptr;
+
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         bool live;
         long n, n0w;          // this lane's pixel; first pixel of the wave's 32-pixel run
@@ -147,6 +152,19 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             }
         }
 
+        float vs = 0.f;
+        if (BEPI == BEPI_STEM && col_sums) {
+            vs = live ? a.v[n] : 0.f;
+            if constexpr (KIN == 128) {
+                float d0[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) d0[i] = dz[i];
+                ksr_colsum32_scalar(xb, lane, d0, vs, cs[0][0], cs[0][1]);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) d0[i] = dz[32 + i];
+                ksr_colsum32_scalar(xb, lane, d0, vs, cs[1][0], cs[1][1]);
+            }
+        }
         // phase fences: keep the epilogue's loads from being hoisted above the GEMM (register pressure)
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[2];
@@ -157,7 +175,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             float t[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) t[i] = dz[(BPRO == BPRO_CONVT_G ? 32 : 0) + i];
-            ksr_store32_co<ST>(xb, a.dz_store, n0w, nvalid, a.dz_store_ld, a.dz_store_c0, lane, t);
+            if (a.dz_store) ksr_store32_co<ST>(xb, a.dz_store, n0w, nvalid, a.dz_store_ld, a.dz_store_c0, lane, t);
             __builtin_amdgcn_sched_barrier(0);
         }
         float dA[32];
@@ -204,10 +222,53 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             for (int i = 0; i < 32; ++i) s += dA[i] * sm.p2w[32 * h + i];
             s = ksr_pair_sum(s);
             if (live && h == 0) a.dpre[n] = a.v[n] > 0.f ? s : 0.f;
+            if (col_sums) ksr_colsum32_scalar(xb, lane, dA, vs, cs[2][0], cs[2][1]);
         }
-        ksr_store32_co<ST, !AHEAD>(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
+        if (a.out1) ksr_store32_co<ST, !AHEAD>(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
         if (AHEAD && tile + gridDim.x < ntiles) fetch_epi(tile + gridDim.x);
     }
+    if (BEPI == BEPI_STEM && col_sums) {
+        // the four waves' sums meet in LDS (the halo / transposer area is free once every wave has left the loop)
+        float* area = spatial ? sm.halo : sm.xpose;
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) area[wv * KSR_XPOSE_FLOATS + (2 * l + q) * 64 + lane] = cs[l][q];
+        __syncthreads();
+        for (int i = tid; i < 6 * 64; i += 256) {
+            const float v = (area[i] + area[KSR_XPOSE_FLOATS + i]) + (area[2 * KSR_XPOSE_FLOATS + i] + area[3 * KSR_XPOSE_FLOATS + i]);
+            const int l = i / 128, r = i - 128 * l;
+            a.sums_slab[((long)l * gridDim.x + blockIdx.x) * 128 + r] = v;
+        }
+    }
+}
+
+// out[l][q * stride[l] + c] = sum over workgroups of slab[l][g][q][c]  (l < 3, q < 2, c < 64), fixed order
+struct ColRedArgs { const float* slab; int G; float* out[3]; int stride[3]; };
+__global__ void __launch_bounds__(1024) colsum_reduce_kernel(ColRedArgs a) {
+    __shared__ float part[8][128];
+    const int l = blockIdx.x;
+    const int e = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const float* slab = a.slab + (long)l * a.G * 128 + e;
+    float s0 = 0.f, s1 = 0.f;
+    int g = grp;
+    for (; g + 8 < a.G; g += 16) { s0 += slab[(long)g * 128]; s1 += slab[(long)(g + 8) * 128]; }
+    if (g < a.G) s0 += slab[(long)g * 128];
+    part[grp][e] = s0 + s1;
+    __syncthreads();
+    if (grp != 0) return;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += part[r][e];
+    a.out[l][(e >> 6) * a.stride[l] + (e & 63)] = s;
+}
+
+unsigned dgrad_grid(const BwdArgs& a, bool spatial) {
+    const long N = (long)a.B * a.H * a.W;
+    const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
+    const long cap = spatial ? 512 : 768;
+    return (unsigned)(ntiles < cap ? ntiles : cap);
 }
 
 template <int PREC, int KIN, int BPRO, int BEPI>
@@ -249,10 +310,15 @@ extern "C" int ksr_gate_pw_bwd(const float* dz, const float* fn2_w, const float*
 
 // fn_1 (64 -> 128) backward: completes dt[:, 64:128] = convT(dgate) * (t[:, 64:] > 0) and computes
 // dx = dt * W.  stem = 1: the input of fn_1 is the first FFN (1 -> 64): also emits dpre [N].
+// stem with sums_slab (3 * 512 * 128 floats of workspace): the kernel also reduces, over all pixels,
+//   dt_sums[0][c] = sum dt[n,c] * v[n], dt_sums[1][c] = sum dt[n,c]   (c < 128, rows 128 floats apart) and
+//   dx_sums[c] = sum dx[n,c] * v[n], dx_sums[dx_row_stride + c] = sum dx[n,c]   (c < 64),
+// which is all the stem's parameter gradients need of dt[:, 64:128] and dx: neither is written then (dx may be NULL).
 extern "C" int ksr_fn1_bwd(float* dt, const float* dgate, const float* gate_w, const float* t_saved,
                            const float* fn1_w, float* dx, int stem, const float* v_saved, const float* pw2_w,
-                           float* dpre, int B, int H, int W, hipStream_t stream) {
-    KSR_CHECK_ARG(dt && dgate && gate_w && t_saved && fn1_w && dx, "fn1_bwd: null pointer");
+                           float* dpre, float* sums_slab, float* dt_sums, float* dx_sums, int dx_row_stride,
+                           int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dt && dgate && gate_w && t_saved && fn1_w, "fn1_bwd: null pointer");
     if (int rc = dims_ok(B, H, W, "fn1_bwd")) return rc;
     BwdArgs a{};
     a.dz = dt; a.dz_ld = 128; a.dz_store = dt; a.dz_store_ld = 128; a.dz_store_c0 = 64;
@@ -261,8 +327,23 @@ extern "C" int ksr_fn1_bwd(float* dt, const float* dgate, const float* gate_w, c
     if (stem) {
         KSR_CHECK_ARG(v_saved && pw2_w && dpre, "fn1_bwd(stem): null pointer");
         a.v = v_saved; a.p2w = pw2_w; a.dpre = dpre;
-        return launch_dgrad<128, BPRO_CONVT_G, BEPI_STEM>(a, stream);
+        if (sums_slab) {
+            KSR_CHECK_ARG(dt_sums && dx_sums && dx_row_stride >= 64, "fn1_bwd(stem): sums_slab needs dt_sums, dx_sums and a row stride >= 64");
+            a.sums_slab = sums_slab;
+            a.dz_store = nullptr;
+            a.out1 = nullptr;
+        } else {
+            KSR_CHECK_ARG(dx, "fn1_bwd: null pointer");
+        }
+        if (int rc = launch_dgrad<128, BPRO_CONVT_G, BEPI_STEM>(a, stream)) return rc;
+        if (sums_slab) {
+            ColRedArgs r{sums_slab, (int)dgrad_grid(a, true), {dt_sums, dt_sums + 64, dx_sums}, {128, 128, dx_row_stride}};
+            hipLaunchKernelGGL(colsum_reduce_kernel, dim3(3), dim3(1024), 0, stream, r);
+            KSR_LAUNCH_CHECK("fn1_bwd(column sums)");
+        }
+        return KSR_OK;
     }
+    KSR_CHECK_ARG(dx, "fn1_bwd: null pointer");
     return launch_dgrad<128, BPRO_CONVT_G, BEPI_STORE>(a, stream);
 }
 

@@ -506,4 +506,53 @@ __device__ __forceinline__ float ksr_layernorm64(const float (&x)[32], float (&x
     return rstd;
 }
 
+// Column sums over a wave's 32 tokens (LayerNorm gain / shift gradients and the like): s_gx += sum_tok g * xhat,
+// s_g += sum_tok g, for channel c = lane.  The products
+// go through the wave's transposer tile (rows of 68 floats); lane c then adds up column c in row order, so the result
+// does not depend on scheduling.  Rows past the end of the tensor hold zeros in g.
+__device__ __forceinline__ void ksr_colsum32(float* __restrict__ xb, int lane, const float (&g)[32], const float (&xh)[32],
+                                          float& s_gx, float& s_g) {
+    float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        ksr_wave_fence();
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            *reinterpret_cast<float4*>(wp + 4 * q) =
+                pass == 0 ? make_float4(g[4 * q] * xh[4 * q], g[4 * q + 1] * xh[4 * q + 1], g[4 * q + 2] * xh[4 * q + 2], g[4 * q + 3] * xh[4 * q + 3])
+                          : make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
+        ksr_wave_fence();
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; r += 4) {
+            t0 += xb[(r + 0) * KSR_XPOSE_LD + lane]; t1 += xb[(r + 1) * KSR_XPOSE_LD + lane];
+            t2 += xb[(r + 2) * KSR_XPOSE_LD + lane]; t3 += xb[(r + 3) * KSR_XPOSE_LD + lane];
+        }
+        (pass == 0 ? s_gx : s_g) += (t0 + t1) + (t2 + t3);
+    }
+}
+
+
+// The same with one multiplier per token (lane pair) instead of one per element: s_gv += sum_tok g * v, s_g += sum_tok g.
+__device__ __forceinline__ void ksr_colsum32_scalar(float* __restrict__ xb, int lane, const float (&g)[32], float v,
+                                                    float& s_gv, float& s_g) {
+    float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const float m = pass == 0 ? v : 1.f;
+        ksr_wave_fence();
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(g[4 * q] * m, g[4 * q + 1] * m, g[4 * q + 2] * m, g[4 * q + 3] * m);
+        ksr_wave_fence();
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; r += 4) {
+            t0 += xb[(r + 0) * KSR_XPOSE_LD + lane]; t1 += xb[(r + 1) * KSR_XPOSE_LD + lane];
+            t2 += xb[(r + 2) * KSR_XPOSE_LD + lane]; t3 += xb[(r + 3) * KSR_XPOSE_LD + lane];
+        }
+        (pass == 0 ? s_gv : s_g) += (t0 + t1) + (t2 + t3);
+    }
+}
+
 #endif  // __HIPCC__

@@ -45,31 +45,6 @@ __device__ __forceinline__ void ln_bwd(const float (&dy)[32], const float* __res
     for (int i = 0; i < 32; ++i) dx[i] = rstd * (dxh[i] - m1 - xhat[i] * m2);
 }
 
-// LayerNorm gain / shift gradients: sum over the wave's 32 tokens of g * xhat and of g, per channel.  The products
-// go through the wave's transposer tile (rows of 68 floats); lane c then adds up column c in row order, so the result
-// does not depend on scheduling.  Rows past the end of the tensor hold zeros in g.
-__device__ __forceinline__ void ln_colsum(float* __restrict__ xb, int lane, const float (&g)[32], const float (&xh)[32],
-                                          float& s_gx, float& s_g) {
-    float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        ksr_wave_fence();
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            *reinterpret_cast<float4*>(wp + 4 * q) =
-                pass == 0 ? make_float4(g[4 * q] * xh[4 * q], g[4 * q + 1] * xh[4 * q + 1], g[4 * q + 2] * xh[4 * q + 2], g[4 * q + 3] * xh[4 * q + 3])
-                          : make_float4(g[4 * q], g[4 * q + 1], g[4 * q + 2], g[4 * q + 3]);
-        ksr_wave_fence();
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
-#pragma unroll
-        for (int r = 0; r < 32; r += 4) {
-            t0 += xb[(r + 0) * KSR_XPOSE_LD + lane]; t1 += xb[(r + 1) * KSR_XPOSE_LD + lane];
-            t2 += xb[(r + 2) * KSR_XPOSE_LD + lane]; t3 += xb[(r + 3) * KSR_XPOSE_LD + lane];
-        }
-        (pass == 0 ? s_gx : s_g) += (t0 + t1) + (t2 + t3);
-    }
-}
-
 template <int PREC>
 __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
     using ST = typename KsrStore<PREC>::T;
@@ -117,7 +92,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
             float t[32];
             if (!EARLY) ksr_co_fetch<ST>(a.xhatf, n0w, nvalid, 64, 0, lane, t_xf);
             ksr_co_finish<ST>(xb, lane, t_xf, xh);
-            if (ln_sums) ln_colsum(xb, lane, g, xh, cs[0][0], cs[0][1]);
+            if (ln_sums) ksr_colsum32(xb, lane, g, xh, cs[0][0], cs[0][1]);
             ln_bwd(g, sm.ln[0], h, xh, rs_f, t);
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = t[i];
@@ -127,7 +102,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         float du2[32];
         if (!EARLY) ksr_co_fetch<ST>(a.xhat2, n0w, nvalid, 64, 0, lane, t_x2);
         ksr_co_finish<ST>(xb, lane, t_x2, xh);
-        if (ln_sums) ln_colsum(xb, lane, g, xh, cs[1][0], cs[1][1]);
+        if (ln_sums) ksr_colsum32(xb, lane, g, xh, cs[1][0], cs[1][1]);
         ln_bwd(g, sm.ln[1], h, xh, rs_2, du2);
         // MLP
         float dm[32];
@@ -160,7 +135,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         float du1[32];
         if (!EARLY) ksr_co_fetch<ST>(a.xhat1, n0w, nvalid, 64, 0, lane, t_x1);
         ksr_co_finish<ST>(xb, lane, t_x1, xh);
-        if (ln_sums) ln_colsum(xb, lane, ds1, xh, cs[2][0], cs[2][1]);
+        if (ln_sums) ksr_colsum32(xb, lane, ds1, xh, cs[2][0], cs[2][1]);
         ln_bwd(ds1, sm.ln[2], h, xh, rs_1, du1);
         ksr_store32_co<ST>(xb, a.du1, n0w, nvalid, 64, 0, lane, du1);
         float da[32];

@@ -34,6 +34,7 @@ class _Ws:
         self.dev = dev
         self._slab = None
         self._ln_slab = None
+        self._sums_slab = None
         self.arena = arena
 
     def new(self, *shape):
@@ -57,6 +58,11 @@ class _Ws:
         w, b = self.arena[name_w], self.arena[name_b]
         assert w.numel() == n and b.numel() == n and b.data_ptr() == w.data_ptr() + 4 * n, (name_w, name_b)
         return torch.as_strided(w, (2, n), (n, 1))
+
+    def sums_slab(self):
+        if self._sums_slab is None:
+            self._sums_slab = torch.empty(3 * 512 * 128, device=self.dev, dtype=torch.float32)
+        return self._sums_slab
 
     def ln_slab(self):
         if self._ln_slab is None:
@@ -161,10 +167,11 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
     grads[q + "fn_2.weight"], grads[q + "fn_2.bias"] = gw, gb
     grads[q + "gate.weight"], grads[q + "gate.bias"] = _dwconv_wgrad(ws, t, 128, 64, dgate, g, q + "gate.weight",
                                                                    q + "gate.bias")
-    dx = ws.act(N, 64)
     if stem_saves is None:
+        dx = ws.act(N, 64)
         check(L.ksr_fn1_bwd(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(t), ptr(p[q + "fn_1.0.weight"]), ptr(dx),
-                            c_int(0), ptr(None), ptr(None), ptr(None), *_dims(g), stream()), "ksr_fn1_bwd")
+                            c_int(0), ptr(None), ptr(None), ptr(None), ptr(None), ptr(None), ptr(None), c_int(0),
+                            *_dims(g), stream()), "ksr_fn1_bwd")
         gw, gb = ws.grad(q + "fn_1.0.weight", 128, 64, 1, 1), ws.grad(q + "fn_1.0.bias", 128)
         _wgrad(ws, dt, 128, 0, 128, x_in, 64, 0, 64, N, gw, gb)
         grads[q + "fn_1.0.weight"], grads[q + "fn_1.0.bias"] = gw, gb
@@ -173,17 +180,18 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
     v = stem_saves
     f = pre + "ffn1."
     dpre = ws.new(N)
-    check(L.ksr_fn1_bwd(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(t), ptr(p[q + "fn_1.0.weight"]), ptr(dx),
-                        c_int(1), ptr(v), ptr(p[f + "pointwise2.weight"]), ptr(dpre), *_dims(g), stream()), "ksr_fn1_bwd")
+    # the kernel reduces the column sums of dt and dx (times v) that the stem's parameter gradients need; dx and the
+    # gate half of dt, which nothing else reads, are not written
     rc = ws.new(2, 128)
-    _colreduce(ws, dt, 128, 0, v, True, N, rc, 0)
-    _colreduce(ws, dt, 128, 64, v, True, N, rc, 64)
+    r2 = ws.grad_pair(f + "pointwise2.weight", f + "pointwise2.bias", 64)
+    check(L.ksr_fn1_bwd(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(t), ptr(p[q + "fn_1.0.weight"]), ptr(None),
+                        c_int(1), ptr(v), ptr(p[f + "pointwise2.weight"]), ptr(dpre), ptr(ws.sums_slab()), ptr(rc), ptr(r2),
+                        c_int(64), *_dims(g), stream()), "ksr_fn1_bwd")
     gw, gb = ws.grad(q + "fn_1.0.weight", 128, 64, 1, 1), ws.grad(q + "fn_1.0.bias", 128)
     check(L.ksr_outer2(ptr(gw), c_void_p(rc.data_ptr()), ptr(p[f + "pointwise2.weight"]),
                        c_void_p(rc.data_ptr() + 4 * 128), ptr(p[f + "pointwise2.bias"]),
                        c_int(128), c_int(64), ptr(gb), stream()), "ksr_outer2")
     grads[q + "fn_1.0.weight"], grads[q + "fn_1.0.bias"] = gw, gb
-    r2 = _colreduce(ws, dx, 64, 0, v, True, N, ws.grad_pair(f + "pointwise2.weight", f + "pointwise2.bias", 64))
     grads[f + "pointwise2.weight"], grads[f + "pointwise2.bias"] = r2[0].reshape(64, 1, 1, 1), r2[1]
     if ws.arena is None:
         out12 = ws.new(12)
