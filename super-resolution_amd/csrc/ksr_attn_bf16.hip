@@ -27,8 +27,9 @@ __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// exp(x) for x <= 0 (or -inf) as one v_exp_f32: the arguments are differences to the row maximum
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+constexpr float LOG2E = 1.4426950408889634f;
+// exp(x - m) as one FMA and one v_exp_f32: m2 = m * log2(e) is formed once per row
+__device__ __forceinline__ float fast_exp_m(float x, float m2) { return __builtin_amdgcn_exp2f(fmaf(x, LOG2E, -m2)); }
 
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
@@ -268,11 +269,12 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
             }
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             float l = 0.f;
+            const float m2 = m * LOG2E;
 #pragma unroll
             for (int kb = 0; kb < NW; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float pj = fast_exp(sc[kb][r] - m);
+                    float pj = fast_exp_m(sc[kb][r], m2);
                     l += pj;
                     if (drop) {
                         int same, kbb;
@@ -295,7 +297,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
 struct __attribute__((aligned(16))) BwdSmem {
     __bf16 rowA[128 * 32];    // phase A: K rows  | phase B: Q rows (scaled); swizzled chunks, see sw_off
     __bf16 rowB[128 * 32];    // phase A: V rows  | phase B: dO rows
-    float stat[128 * 4];      // per query slot: m, 1/l, D, dropout base (bits)
+    float stat[128 * 4];      // per query slot: m log2(e) + log2(l), unused, D, dropout base (bits)
     float xpose[4 * KSR_XPOSE_FLOATS];
 };
 
@@ -385,11 +387,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                 }
                 m = fmaxf(m, __shfl_xor(m, 32, 64));
                 float l = 0.f;
+                const float m2 = m * LOG2E;
 #pragma unroll
                 for (int kb = 0; kb < NW; ++kb)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { st[kb][r] = fast_exp(st[kb][r] - m); l += st[kb][r]; }
+                    for (int r = 0; r < 16; ++r) { st[kb][r] = fast_exp_m(st[kb][r], m2); l += st[kb][r]; }
                 inv_l = 1.f / ksr_pair_sum(l);
+                const float ils = inv_l * scale;
                 f32x16 dq = zero16();
 #pragma unroll
                 for (int kb = 0; kb < NW; ++kb) {
@@ -403,7 +407,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                             smap.decode(base0, kb, key_of_reg(r, g), pl, same, kbb);
                             dpr = ksr_attn_keep(dbase, kbb, keep) ? dpr * inv_keep : 0.f;
                         }
-                        dp[r] = st[kb][r] * inv_l * (dpr - DX) * scale;      // dS (scaled for dq)
+                        dp[r] = st[kb][r] * ils * (dpr - DX);      // dS (scaled for dq)
                     }
                     tr_times_acc(sm.rowA, base0 + 32 * kb, lane, dp, dq);
                 }
@@ -414,7 +418,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
             __syncthreads();
             put_rows(sm.rowA, slot, g, qx);
             put_rows(sm.rowB, slot, g, dox);
-            if (g == 0) *reinterpret_cast<f32x4*>(&sm.stat[slot * 4]) = f32x4{m, inv_l, DX, __uint_as_float(dbase)};
+            // p = exp(s - m) / l = exp2(s log2(e) - (m log2(e) + log2(l)))
+            if (g == 0) *reinterpret_cast<f32x4*>(&sm.stat[slot * 4]) = f32x4{m * LOG2E - __builtin_amdgcn_logf(inv_l), 0.f, DX, __uint_as_float(dbase)};
             __syncthreads();
             {
                 f32x16 dk = zero16(), dv = zero16();
@@ -430,7 +435,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                         smap.decode(base0, qblk, key_of_reg(r, g), pl, same, qbb);
                         const bool ok = same && (qbb < S) && (p < HW);
                         const f32x4 stt = *reinterpret_cast<const f32x4*>(&sm.stat[qs * 4]);
-                        const float pij = ok ? fast_exp(sq[r] - stt[0]) * stt[1] : 0.f;
+                        const float pij = ok ? fast_exp_m(sq[r], stt[0]) : 0.f;
                         float pt = pij, dpr = dp[r];
                         if (DROP) {
                             const bool kept = ksr_attn_keep(__float_as_uint(stt[3]), b, keep);
