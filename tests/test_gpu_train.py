@@ -263,3 +263,30 @@ def test_checkpoint_resume_reproduces_the_next_step(tmp_path):
     assert l1 == l2 and ts2.steps == 4
     assert torch.equal(ts.flat_p, ts2.flat_p) and torch.equal(ts.exp_avg, ts2.exp_avg)
     ts.close(); ts2.close()
+
+
+def test_training_learns_smooth_images_in_bf16_storage_mode():
+    """200 steps of the reference loss on smooth synthetic images (bicubic-enlarged noise, LR = bicubic x1/4): the loss
+    must fall by more than 5x and stay finite in the bf16 storage mode (dropout live)."""
+    import torch.nn.functional as F
+    from kan_sr.init import init_like_training_setup
+    from kan_sr.module import ConvSepKan
+    from kan_sr.train import TrainStep
+    torch.manual_seed(0)
+    m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4)
+    init_like_training_setup(m, 0)
+    m = m.cuda().train()
+    m.precision = "bf16s"
+    ts = TrainStep(m, lr=1e-3, loss="l1+ssim")
+    g = torch.Generator().manual_seed(1)
+    first = last = None
+    for it in range(200):
+        hr = F.interpolate(torch.rand(8, 3, 16, 16, generator=g), scale_factor=8, mode="bicubic", align_corners=False).clamp(0, 1)
+        lr_img = F.interpolate(hr, scale_factor=0.25, mode="bicubic", align_corners=False).clamp(0, 1)
+        loss = ts.step(lr_img.cuda(), hr.cuda())
+        if it == 0:
+            first = float(loss)
+    last = float(loss)
+    assert last == last and last < first / 5, (first, last)
+    assert bool(torch.isfinite(ts.flat_p).all())
+    ts.close()
