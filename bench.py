@@ -240,9 +240,15 @@ def main():
     nlaunch = max(3, min(args.steps, 10))
     if rank == 0:
         _lib.PROFILE = {}
+    # the timed region above overlaps the parameter-gradient reductions with the data-gradient chain on a second
+    # stream; the per-kernel timing run keeps every launch on one stream so that each duration is the kernel's own
+    from kan_sr import autograd as _autograd
+    side_was = _autograd.SIDE_STREAM_FOR_WGRAD
+    _autograd.SIDE_STREAM_FOR_WGRAD = False
     for _ in range(nlaunch):
         step()
     sync()
+    _autograd.SIDE_STREAM_FOR_WGRAD = side_was
     if rank == 0:
         prof = {k: [s.elapsed_time(e) for s, e in v] for k, v in _lib.PROFILE.items()}
         _lib.PROFILE = None

@@ -2,6 +2,9 @@
 kernels.  PyTorch only carries the tape node and owns the buffers."""
 from __future__ import annotations
 
+import contextlib
+import os
+
 from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
 from typing import Dict, List
 
@@ -26,9 +29,24 @@ PARAM_ORDER = (
 )
 
 
+_SIDE_STREAMS: dict = {}
+SIDE_STREAM_FOR_WGRAD = os.environ.get("KSR_SIDE_WGRAD", "1") != "0"
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 class _Ws:
     """Scratch allocator for one backward pass.  With an `arena` (name -> view into a flat gradient
-    buffer) every parameter gradient is written in place by the kernels."""
+    buffer) every parameter gradient is written in place by the kernels.
+
+    The parameter-gradient reductions (wgrad, depthwise wgrad, stem sums) hang off the data-gradient chain: they
+    are enqueued on a second stream, so that they fill the ramp-up / tail of the chain's kernels instead of
+    lengthening it; `join()` makes the main stream wait for them."""
 
     def __init__(self, dev, arena=None):
         self.dev = dev
@@ -36,6 +54,24 @@ class _Ws:
         self._ln_slab = None
         self._sums_slab = None
         self.arena = arena
+        self.wstream = _side_stream(dev) if (SIDE_STREAM_FOR_WGRAD and dev.type == "cuda") else None
+
+    @contextlib.contextmanager
+    def side(self, *tensors):
+        """Runs the enclosed launches on the side stream, after everything enqueued so far on the current one."""
+        if self.wstream is None:
+            yield
+            return
+        self.wstream.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(self.wstream)       # allocated on the main stream, read / written on the side stream
+        with torch.cuda.stream(self.wstream):
+            yield
+
+    def join(self):
+        if self.wstream is not None:
+            torch.cuda.current_stream().wait_stream(self.wstream)
 
     def new(self, *shape):
         return torch.empty(*shape, device=self.dev, dtype=torch.float32)
@@ -78,9 +114,10 @@ class _Ws:
 def _wgrad(ws: _Ws, dz, dz_ld, dz_c0, J, a1, a1_ld, a1_c0, K, N, dW, db, a2=None, a2_ld=0, a2_c0=0, kan=(0, 0)):
     L = lib()
     slab = ws.slab(int(L.ksr_wgrad_slab_floats(c_int(J), c_int(K))))
-    check(L.ksr_wgrad(ptr(dz), c_int(dz_ld), c_int(dz_c0), c_int(J), ptr(a1), c_int(a1_ld), c_int(a1_c0), c_int(K),
-                      ptr(a2), c_int(a2_ld), c_int(a2_c0), c_int64(N), ptr(slab), ptr(dW), ptr(db),
-                      c_int(kan[0]), c_int(kan[1]), stream()), "ksr_wgrad")
+    with ws.side(dz, a1, a2, slab, dW, db):
+        check(L.ksr_wgrad(ptr(dz), c_int(dz_ld), c_int(dz_c0), c_int(J), ptr(a1), c_int(a1_ld), c_int(a1_c0), c_int(K),
+                          ptr(a2), c_int(a2_ld), c_int(a2_c0), c_int64(N), ptr(slab), ptr(dW), ptr(db),
+                          c_int(kan[0]), c_int(kan[1]), stream()), "ksr_wgrad")
 
 
 def _colreduce(ws: _Ws, a, a_ld, a_c0, b, b_scalar, N, out, out_c0=0):
@@ -95,8 +132,9 @@ def _dwconv_wgrad(ws: _Ws, inp, in_ld, in_c0, ds, g: Geometry, name_w, name_b):
     dW = ws.grad(name_w, 64, 1, 3, 3)
     db = ws.grad(name_b, 64)
     slab = ws.slab(512 * 640)
-    check(lib().ksr_dwconv_wgrad(ptr(inp), c_int(in_ld), c_int(in_c0), ptr(ds), c_int(64), c_int(0), ptr(slab), ptr(dW), ptr(db),
-                                 *_dims(g), stream()), "ksr_dwconv_wgrad")
+    with ws.side(inp, ds, slab, dW, db):
+        check(lib().ksr_dwconv_wgrad(ptr(inp), c_int(in_ld), c_int(in_c0), ptr(ds), c_int(64), c_int(0), ptr(slab), ptr(dW),
+                                     ptr(db), *_dims(g), stream()), "ksr_dwconv_wgrad")
     return dW, db
 
 
@@ -188,9 +226,10 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
                         c_int(1), ptr(v), ptr(p[f + "pointwise2.weight"]), ptr(dpre), ptr(ws.sums_slab()), ptr(rc), ptr(r2),
                         c_int(64), *_dims(g), stream()), "ksr_fn1_bwd")
     gw, gb = ws.grad(q + "fn_1.0.weight", 128, 64, 1, 1), ws.grad(q + "fn_1.0.bias", 128)
-    check(L.ksr_outer2(ptr(gw), c_void_p(rc.data_ptr()), ptr(p[f + "pointwise2.weight"]),
-                       c_void_p(rc.data_ptr() + 4 * 128), ptr(p[f + "pointwise2.bias"]),
-                       c_int(128), c_int(64), ptr(gb), stream()), "ksr_outer2")
+    with ws.side(rc, gw, gb):
+        check(L.ksr_outer2(ptr(gw), c_void_p(rc.data_ptr()), ptr(p[f + "pointwise2.weight"]),
+                           c_void_p(rc.data_ptr() + 4 * 128), ptr(p[f + "pointwise2.bias"]),
+                           c_int(128), c_int(64), ptr(gb), stream()), "ksr_outer2")
     grads[q + "fn_1.0.weight"], grads[q + "fn_1.0.bias"] = gw, gb
     grads[f + "pointwise2.weight"], grads[f + "pointwise2.bias"] = r2[0].reshape(64, 1, 1, 1), r2[1]
     if ws.arena is None:
@@ -204,9 +243,10 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
             off += ws.arena[nm].numel()
         out12 = torch.as_strided(base, (12,), (1,))
     slab = ws.slab(256 * 12)
-    check(L.ksr_stem_scalar_wgrad(ptr(x_img), c_int64(3 * g.H * g.W), ptr(dpre), ptr(p[f + "pointwise1.weight"]),
-                                  ptr(p[f + "pointwise1.bias"]), ptr(p[f + "depthwise.weight"]), ptr(slab), ptr(out12),
-                                  *_dims(g), stream()), "ksr_stem_scalar_wgrad")
+    with ws.side(dpre, slab, out12):
+        check(L.ksr_stem_scalar_wgrad(ptr(x_img), c_int64(3 * g.H * g.W), ptr(dpre), ptr(p[f + "pointwise1.weight"]),
+                                      ptr(p[f + "pointwise1.bias"]), ptr(p[f + "depthwise.weight"]), ptr(slab), ptr(out12),
+                                      *_dims(g), stream()), "ksr_stem_scalar_wgrad")
     grads[f + "pointwise1.weight"] = out12[0:1].reshape(1, 1, 1, 1)
     grads[f + "pointwise1.bias"] = out12[1:2]
     grads[f + "depthwise.weight"] = out12[2:11].reshape(1, 1, 3, 3)
@@ -238,6 +278,7 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
     _wgrad(ws, gparam, 2 * lane_len, 0, 2 * lane_len, sv["feat"], 64, 0, 64, N, gw, gb, kan=(g.r, g.n_coef))
     grads[pre + "feed.weight"], grads[pre + "feed.bias"] = gw, gb
     trunk_backward(ws, gfeat, x, p, pre, g, sv, p_drop, seed, grads, on_tail_done)
+    ws.join()
     return grads
 
 
@@ -251,6 +292,7 @@ def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, t
     d = _tx_layer_backward(ws, gfeat, 1, p, pre, g, sv["tx1"], p_drop, seed, grads, None)
     dz6 = _tx_layer_backward(ws, d, 0, p, pre, g, sv["tx0"], p_drop, seed, grads, sv["x6"])
     if on_tail_done is not None:
+        ws.join()                 # the first bucket's gradients include side-stream reductions
         on_tail_done()
     # ---- ffn4 (gated) ----
     dx4 = _gated_backward(ws, dz6, "ffn4", p, pre, g, sv["t5"], sv["g6"], grads, sv["x4"])
@@ -338,7 +380,9 @@ class _TrunkFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise KsrError("gradient with respect to the input image is not implemented")
         grads: Dict[str, torch.Tensor] = {}
-        trunk_backward(_Ws(ctx.x.device), gfeat.contiguous(), ctx.x, ctx.p, pre, g, ctx.sv, p_drop, seed, grads)
+        ws = _Ws(ctx.x.device)
+        trunk_backward(ws, gfeat.contiguous(), ctx.x, ctx.p, pre, g, ctx.sv, p_drop, seed, grads)
+        ws.join()
         ctx.sv = None
         out = []
         for n, t in zip(names, ctx.p.values()):
