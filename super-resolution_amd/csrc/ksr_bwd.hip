@@ -247,20 +247,25 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
 // out[l][q * stride[l] + c] = sum over workgroups of slab[l][g][q][c]  (l < 3, q < 2, c < 64), fixed order
 struct ColRedArgs { const float* slab; int G; float* out[3]; int stride[3]; };
 __global__ void __launch_bounds__(1024) colsum_reduce_kernel(ColRedArgs a) {
-    __shared__ float part[8][128];
+    // grid (3, 4): 32 of the 128 sums per workgroup x 32 slab groups, four independent partial sums per thread
+    __shared__ float part[32][33];
     const int l = blockIdx.x;
-    const int e = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.y * 32 + o;
     const float* slab = a.slab + (long)l * a.G * 128 + e;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int g = grp;
-    for (; g + 8 < a.G; g += 16) { s0 += slab[(long)g * 128]; s1 += slab[(long)(g + 8) * 128]; }
-    if (g < a.G) s0 += slab[(long)g * 128];
-    part[grp][e] = s0 + s1;
+    for (; g + 96 < a.G; g += 128) {
+        s0 += slab[(long)g * 128]; s1 += slab[(long)(g + 32) * 128];
+        s2 += slab[(long)(g + 64) * 128]; s3 += slab[(long)(g + 96) * 128];
+    }
+    for (; g < a.G; g += 32) s0 += slab[(long)g * 128];
+    part[grp][o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp != 0) return;
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) s += part[r][e];
+    for (int r = 0; r < 32; ++r) s += part[r][o];
     a.out[l][(e >> 6) * a.stride[l] + (e & 63)] = s;
 }
 
@@ -338,7 +343,7 @@ extern "C" int ksr_fn1_bwd(float* dt, const float* dgate, const float* gate_w, c
         if (int rc = launch_dgrad<128, BPRO_CONVT_G, BEPI_STEM>(a, stream)) return rc;
         if (sums_slab) {
             ColRedArgs r{sums_slab, (int)dgrad_grid(a, true), {dt_sums, dt_sums + 64, dx_sums}, {128, 128, dx_row_stride}};
-            hipLaunchKernelGGL(colsum_reduce_kernel, dim3(3), dim3(1024), 0, stream, r);
+            hipLaunchKernelGGL(colsum_reduce_kernel, dim3(3, 4), dim3(1024), 0, stream, r);
             KSR_LAUNCH_CHECK("fn1_bwd(column sums)");
         }
         return KSR_OK;

@@ -173,21 +173,26 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
 // gain / shift gradients of up to three LayerNorms from the per-workgroup sums: out[l][q * row_stride + c]
 struct LnRedArgs { const float* slab; int G; float* out[3]; int row_stride; };
 __global__ void __launch_bounds__(1024) ln_reduce_kernel(LnRedArgs a) {
-    __shared__ float part[8][128];
+    // grid (3, 4): 32 of the 128 sums per workgroup x 32 slab groups, four independent partial sums per thread
+    __shared__ float part[32][33];
     const int l = blockIdx.x;
     if (a.out[l] == nullptr) return;
-    const int e = threadIdx.x & 127, grp = threadIdx.x >> 7;
+    const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.y * 32 + o;
     const float* slab = a.slab + (long)l * a.G * 128 + e;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int g = grp;
-    for (; g + 8 < a.G; g += 16) { s0 += slab[(long)g * 128]; s1 += slab[(long)(g + 8) * 128]; }
-    if (g < a.G) s0 += slab[(long)g * 128];
-    part[grp][e] = s0 + s1;
+    for (; g + 96 < a.G; g += 128) {
+        s0 += slab[(long)g * 128]; s1 += slab[(long)(g + 32) * 128];
+        s2 += slab[(long)(g + 64) * 128]; s3 += slab[(long)(g + 96) * 128];
+    }
+    for (; g < a.G; g += 32) s0 += slab[(long)g * 128];
+    part[grp][o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp != 0) return;
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) s += part[r][e];
+    for (int r = 0; r < 32; ++r) s += part[r][o];
     a.out[l][(e >> 6) * a.row_stride + (e & 63)] = s;
 }
 
@@ -370,7 +375,7 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token");
     if (ln_slab) {
         LnRedArgs r{ln_slab, (int)(ntiles < 768 ? ntiles : 768), {a.nf_w ? ln_grads[0] : nullptr, ln_grads[1], ln_grads[2]}, ln_row_stride};
-        hipLaunchKernelGGL(ln_reduce_kernel, dim3(3), dim3(1024), 0, stream, r);
+        hipLaunchKernelGGL(ln_reduce_kernel, dim3(3, 4), dim3(1024), 0, stream, r);
         KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token(ln reduce)");
     }
     return KSR_OK;
