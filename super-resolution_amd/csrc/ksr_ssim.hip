@@ -166,18 +166,22 @@ __global__ void __launch_bounds__(256) ssim_fwd_kernel(SsimArgs a, SsimWin w) {
         a.slab[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-// One workgroup: strided partial sums in double, then a fixed-order tree (deterministic).
+// One workgroup: strided partial sums in double, a butterfly inside each wave, then the 16 wave sums in order
+// (deterministic).
 __global__ void __launch_bounds__(1024) ssim_finish_kernel(const float* slab, long G, double scale, float* out) {
-    __shared__ double part[1024];
+    __shared__ double part[16];
     double s = 0.0;
     for (long i = threadIdx.x; i < G; i += 1024) s += (double)slab[i];
-    part[threadIdx.x] = s;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    for (int w = 512; w >= 1; w >>= 1) {
-        if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w];
+        out[0] = (float)(t * scale);
     }
-    if (threadIdx.x == 0) out[0] = (float)(part[0] * scale);
 }
 
 struct SsimGradArgs {

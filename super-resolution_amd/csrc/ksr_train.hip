@@ -36,12 +36,13 @@ __global__ void __launch_bounds__(256) l1_kernel(const float* __restrict__ pred,
     if (threadIdx.x == 0) slab[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void l1_finish_kernel(const float* slab, int G, float scale, float* loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float s = 0.f;
-        for (int i = 0; i < G; ++i) s += slab[i];
-        loss[0] = s * scale;
-    }
+// one wave: strided partial sums, then a butterfly (fixed order)
+__global__ void __launch_bounds__(64) l1_finish_kernel(const float* slab, int G, float scale, float* loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < G; i += 64) s += slab[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (threadIdx.x == 0) loss[0] = s * scale;
 }
 
 // Adam (torch.optim.Adam semantics, amsgrad off, maximize off): one pass over the flat buffers.
