@@ -18,7 +18,7 @@ from .ops import bilinear_up_into, make_knots
 LN_EPS = 1e-5
 # local batch above which the transformer layer runs as QKV GEMM + MFMA attention + post kernel instead of the
 # single fused kernel (whose VALU attention is cheaper for short sequences)
-SPLIT_ATTENTION_ABOVE = 16
+SPLIT_ATTENTION_ABOVE = 8
 TX_PARAM_NAMES = ("self_attn.in_proj_weight", "self_attn.in_proj_bias", "self_attn.out_proj.weight",
                   "self_attn.out_proj.bias", "linear1.weight", "linear1.bias", "linear2.weight",
                   "linear2.bias", "norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias")
