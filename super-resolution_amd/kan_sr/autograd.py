@@ -31,6 +31,7 @@ PARAM_ORDER = (
 
 _SIDE_STREAMS: dict = {}
 SIDE_STREAM_FOR_WGRAD = os.environ.get("KSR_SIDE_WGRAD", "1") != "0"
+SIDE_STREAM_MIN_TOKENS = 1 << 19          # LR pixels per backward pass from which the second stream is used
 
 
 def _side_stream(dev):
@@ -48,13 +49,15 @@ class _Ws:
     are enqueued on a second stream, so that they fill the ramp-up / tail of the chain's kernels instead of
     lengthening it; `join()` makes the main stream wait for them."""
 
-    def __init__(self, dev, arena=None):
+    def __init__(self, dev, arena=None, n_tokens=0):
         self.dev = dev
         self._slab = None
         self._ln_slab = None
         self._sums_slab = None
         self.arena = arena
-        self.wstream = _side_stream(dev) if (SIDE_STREAM_FOR_WGRAD and dev.type == "cuda") else None
+        # small problems are bound by the host's launch rate, where the extra stream bookkeeping only costs
+        self.wstream = _side_stream(dev) if (SIDE_STREAM_FOR_WGRAD and dev.type == "cuda"
+                                             and n_tokens >= SIDE_STREAM_MIN_TOKENS) else None
 
     @contextlib.contextmanager
     def side(self, *tensors):
@@ -263,7 +266,7 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
     first all-reduce bucket), while the conv-trunk backward is still to come."""
     L = lib()
     N = g.N
-    ws = _Ws(x.device, arena)
+    ws = _Ws(x.device, arena, g.N)
     grads: Dict[str, torch.Tensor] = {}
     # ---- feed + KAN ----
     lane_len = int(L.ksr_feed_kan_lane_len(c_int(g.r), c_int(g.n_coef)))
@@ -380,7 +383,7 @@ class _TrunkFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise KsrError("gradient with respect to the input image is not implemented")
         grads: Dict[str, torch.Tensor] = {}
-        ws = _Ws(ctx.x.device)
+        ws = _Ws(ctx.x.device, None, g.N)
         trunk_backward(ws, gfeat.contiguous(), ctx.x, ctx.p, pre, g, ctx.sv, p_drop, seed, grads)
         ws.join()
         ctx.sv = None
