@@ -112,7 +112,15 @@ def ptr(t: torch.Tensor | None) -> c_void_p:
     return c_void_p(t.data_ptr())
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream() -> c_void_p:
+    """HIP stream handle of torch's current stream on the current device (called once per kernel launch: the raw
+    accessor avoids building a torch.cuda.Stream object each time)."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return c_void_p(_RAW_STREAM(_RAW_DEVICE()))
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -268,6 +268,62 @@ def gold_color():
     save("color", rgb=rgb, ycbcr=ycc, rgb_back=back, ycc2=ycc2, rgb2=mod.ycbcr_to_rgb(ycc2), T=mod.T, O=mod.O)
 
 
+# ---------------------------------------------------------------- UNet hyper-encoder
+def gold_unet():
+    """conv_sep_kan/unet.py UNet(1, P) and its SelfAttention block: eval-mode forward (running statistics),
+    train-mode forward (batch statistics + the running-statistics update) and the gradients of the train-mode pass."""
+    from conv_sep_kan.unet import UNet
+    from conv_sep_kan.unet_blocks import SelfAttention
+    out = {}
+    gen = torch.Generator().manual_seed(140)
+    torch.manual_seed(140)
+    for tag, dim, heads, (B, H, W) in [("att8", 8, 2, (2, 12, 20)), ("att32", 32, 4, (3, 4, 6))]:
+        att = SelfAttention(dim=dim, num_heads=heads)
+        with torch.no_grad():
+            att.temperature_a.copy_(1 + 0.5 * torch.randn(att.temperature_a.shape, generator=gen))
+            att.temperature_v.copy_(1 + 0.5 * torch.randn(att.temperature_v.shape, generator=gen))
+        x = torch.randn(B, dim, H, W, generator=gen).requires_grad_()
+        y = att(x)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        out.update({f"{tag}.x": x, f"{tag}.y": y, f"{tag}.gy": gy, f"{tag}.gx": x.grad})
+        for n, p in att.named_parameters():
+            out[f"{tag}.p.{n}"] = p
+            out[f"{tag}.g.{n}"] = p.grad
+    for tag, P, (B, H, W) in [("u40", 40, (2, 32, 32)), ("u160", 160, (2, 16, 32))]:
+        m = UNet(1, P)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.weight.copy_(1 + 0.2 * torch.randn(mod.weight.shape, generator=gen))
+                    mod.bias.copy_(0.2 * torch.randn(mod.bias.shape, generator=gen))
+                    mod.running_mean.copy_(0.1 * torch.randn(mod.running_mean.shape, generator=gen))
+                    mod.running_var.copy_(0.5 + torch.rand(mod.running_var.shape, generator=gen))
+                if isinstance(mod, SelfAttention):
+                    mod.temperature_a.copy_(1 + 0.5 * torch.randn(mod.temperature_a.shape, generator=gen))
+                    mod.temperature_v.copy_(1 + 0.5 * torch.randn(mod.temperature_v.shape, generator=gen))
+        for n, v in m.state_dict().items():
+            out[f"{tag}.sd.{n}"] = v.clone()
+        x = torch.rand(B, 1, H, W, generator=gen)
+        out[f"{tag}.x"] = x
+        m.eval()
+        with torch.no_grad():
+            out[f"{tag}.y_eval"] = m(x)
+        m.train()
+        y = m(x)
+        out[f"{tag}.y_train"] = y
+        if P == 40:                          # gradients for the small case only (fixture size)
+            gy = torch.randn(y.shape, generator=gen)
+            (y * gy).sum().backward()
+            out[f"{tag}.gy"] = gy
+            for n, p in m.named_parameters():
+                out[f"{tag}.g.{n}"] = p.grad
+        for n, v in m.state_dict().items():
+            if "running" in n or "num_batches" in n:
+                out[f"{tag}.after.{n}"] = v.clone()
+    save("unet", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
@@ -283,3 +339,4 @@ if __name__ == "__main__":
     gold_dropout_stats()
     gold_chan_attention()
     gold_color()
+    gold_unet()
