@@ -354,6 +354,52 @@ int ksr_allreduce_sum(float* buf, int64_t n, ksr_stream_t stream);
 int ksr_comm_nranks(void);
 int ksr_comm_destroy(void);
 
+/* ---------------------------------------------------------------------------------------------
+ * UNet hyper-encoder, forward (conv_sep_kan/unet.py:7-42; blocks conv_sep_kan/unet_blocks.py:9-178).
+ * Activations are NHWC fp32 [B,H,W,C].
+ */
+
+/* Direct convolution (nn.Conv2d of DoubleConv unet_blocks.py:17-27, the stride-2 reflect-padded projections of
+ * SelfAttention :100-127, the 1x1 convs :117,129 and OutConv :85).  Input = channel concatenation of src0 [B,Hin,Win,c0]
+ * and src1 [B,Hin,Win,c1] (torch.cat of Up.forward :77; src1 NULL with c1 = 0); with in_scale/in_shift, src0 is read
+ * as relu(x*scale[c]+shift[c]) (the BatchNorm + ReLU of the producing conv, :21-22).  weight [ks*ks][c0+c1][cout]
+ * (tap-major, cout innermost); w_image_stride != 0 selects per-image weights.  ks 1 or 3 (padding ks/2, zero or
+ * reflect), stride 1 or 2, cout % 4 == 0.  stat_partials (or NULL): ksr_unet_conv_partials(B,Hout,Wout) rows of
+ * [2][cout] floats, the per-workgroup sum and sum of squares of the output for BatchNorm's batch statistics. */
+int64_t ksr_unet_conv_partials(int B, int Hout, int Wout);
+int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, int c1, const float* in_scale,
+                      const float* in_shift, const float* weight, int64_t w_image_stride, const float* bias,
+                      float* out, int cout, float* stat_partials, int ks, int stride, int reflect, int B, int Hin,
+                      int Win, ksr_stream_t stream);
+
+/* nn.BatchNorm2d (unet_blocks.py:21,27) reduced to y = x*scale + shift.  train != 0: batch mean / biased variance from
+ * the n_partials rows written by ksr_unet_conv_fwd over `count` values per channel, and the running statistics move
+ * by `momentum` (unbiased variance), as torch does; train == 0: the running statistics are used and left alone. */
+int ksr_unet_bn_finalize(const float* stat_partials, int n_partials, int64_t count, const float* gamma,
+                         const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                         int train, float* scale, float* shift, int C, ksr_stream_t stream);
+
+/* out = relu(raw*scale + shift) (unet_blocks.py:27-28) and, with pooled != NULL, pooled [B,H/2,W/2,C] =
+ * nn.MaxPool2d(2)(out) (:40).  C % 4 == 0. */
+int ksr_unet_bn_relu_fwd(const float* raw, const float* scale, const float* shift, float* out, float* pooled,
+                         int B, int H, int W, int C, ksr_stream_t stream);
+
+/* nn.ConvTranspose2d(cin, cout, kernel_size=2, stride=2) (unet_blocks.py:59-62): in [B,h,w,cin] ->
+ * out [B,2h,2w,cout]; weight [dy*2+dx][cin][cout], bias [cout]. */
+int ksr_unet_convt_fwd(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
+                       int B, int h, int w, ksr_stream_t stream);
+
+/* SelfAttention's per-image algebra (unet_blocks.py:141-177).  z [B,n,zc] = q (c channels) | k (c) | a (c/2) at half
+ * resolution.  Computes the L2-normalised products q a^T and a k^T (:154-156,161,164), their softmaxes scaled by the
+ * per-head temperatures, attn_a attn_k (:167-169) and folds v_proj (times vscale: the reference multiplies v by the
+ * image width, :132,137-138) and project_out (:177) in: T [B][c][c] ([in][out]) with
+ * attention(x)[b,p,:] = x[b,p,:] T[b], applied by ksr_unet_conv_fwd (ks = 1, w_image_stride = c*c).
+ * slab: ksr_unet_att_slab_floats(c, B, n) floats.  c in {4, 8, 16, 32}. */
+int64_t ksr_unet_att_slab_floats(int c, int B, int64_t n);
+int ksr_unet_att_mix(const float* z, int zc, int c, int heads, int64_t n, int B, const float* temp_a,
+                     const float* temp_v, const float* wv, const float* wp, float vscale, float* slab, float* T,
+                     ksr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,9 @@ Reference map (paths relative to the reference repository root):
   gazetr               conv_sep_kan/gazetr.py:100-119
   bilinear_up          conv_sep_kan/conv_sep_kan.py:33-34 (F.interpolate bilinear)
   conv_sep_kan_forward conv_sep_kan/conv_sep_kan.py:29-42
+  double_conv          conv_sep_kan/unet_blocks.py:9-31   (conv3x3 -> BatchNorm2d -> ReLU, twice)
+  anchor_attention     conv_sep_kan/unet_blocks.py:91-178 SelfAttention
+  unet                 conv_sep_kan/unet.py:7-42, unet_blocks.py:34-88
 """
 from __future__ import annotations
 
@@ -269,16 +272,21 @@ def ycbcr_to_rgb(image: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------- whole model
 def conv_sep_kan_forward(x: torch.Tensor, p: Params, *, out_channels: Sequence[int],
                          grid_size: int, spline_order: int, grid_range: Sequence[float],
-                         upscale: int, in_channels: Sequence[int] = (1,), attention: bool = False) -> torch.Tensor:
+                         upscale: int, in_channels: Sequence[int] = (1,), attention: bool = False,
+                         backbone: str = "gazetr", train: bool = False, stats: Optional[dict] = None) -> torch.Tensor:
     """x [B,3,H,W] (Y,Cb,Cr) -> [B,3,rH,rW].  Every layer sees the Y plane; only the
     last layer's output survives (the reference's loop overwrites y).
     attention=True: the `feed` 1x1 conv is replaced by chan_attention (parameters under `...feed.`), a wiring
-    the reference itself does not contain (its ConvSepKanAttention is a stand-alone module)."""
+    the reference itself does not contain (its ConvSepKanAttention is a stand-alone module).
+    backbone="unet": the hyper-encoder is `unet` (conv_sep_kan_encoder.py:7,17 with UNet in place of GazeTR); `train`
+    and `stats` are its BatchNorm mode and running-statistics output."""
     n_layers = len(out_channels)
     li = n_layers - 1
     prefix = f"layers.{li}.encoder.encoder."
     yplane = x[:, :1]
-    if attention:
+    if backbone == "unet":
+        w = unet(yplane, p, prefix, train, stats)
+    elif attention:
         w = chan_attention(gazetr_features(yplane, p, prefix), p, prefix + "feed.")
     else:
         w = gazetr(yplane, p, prefix)
@@ -372,3 +380,74 @@ def random_params(out_dim: int, grid_size: int, spline_order: int, seed: int = 0
             v = scale * torch.randn(shp, generator=g) / math.sqrt(max(fan_in, 1))
         out[name] = v.to(dtype)
     return out
+
+
+# --------------------------------------------------------------------------- UNet hyper-encoder
+def batch_norm_relu(x: torch.Tensor, p: Params, prefix: str, train: bool, stats: Optional[dict] = None,
+                    momentum: float = 0.1, eps: float = 1e-5) -> torch.Tensor:
+    """BatchNorm2d + ReLU.  train: statistics of this batch (biased variance for the normalisation); the
+    running statistics move by `momentum` towards the batch mean and the UNBIASED batch variance and are
+    returned through `stats` (key -> new value) instead of being written in place."""
+    if train:
+        n = x.numel() // x.shape[1]
+        mean = x.mean(dim=(0, 2, 3))
+        var = ((x - mean[None, :, None, None]) ** 2).mean(dim=(0, 2, 3))
+        if stats is not None:
+            stats[prefix + "running_mean"] = (1 - momentum) * p[prefix + "running_mean"] + momentum * mean
+            stats[prefix + "running_var"] = (1 - momentum) * p[prefix + "running_var"] + momentum * var * n / max(n - 1, 1)
+            stats[prefix + "num_batches_tracked"] = p[prefix + "num_batches_tracked"] + 1
+    else:
+        mean, var = p[prefix + "running_mean"], p[prefix + "running_var"]
+    scale = p[prefix + "weight"] / torch.sqrt(var + eps)
+    shift = p[prefix + "bias"] - mean * scale
+    return torch.relu(x * scale[None, :, None, None] + shift[None, :, None, None])
+
+
+def double_conv(x: torch.Tensor, p: Params, prefix: str, train: bool, stats: Optional[dict] = None) -> torch.Tensor:
+    """prefix ends in 'double_conv.': Sequential indices 0 conv, 1 BN, 3 conv, 4 BN (unet_blocks.py:16-28)."""
+    h = F.conv2d(x, p[prefix + "0.weight"], None, padding=1)
+    h = batch_norm_relu(h, p, prefix + "1.", train, stats)
+    h = F.conv2d(h, p[prefix + "3.weight"], None, padding=1)
+    return batch_norm_relu(h, p, prefix + "4.", train, stats)
+
+
+def _reflect_conv_s2(x, w, b=None, groups=1):
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode="reflect"), w, b, stride=2, groups=groups)
+
+
+def _l2_rows(t: torch.Tensor, eps: float = 1e-12) -> torch.Tensor:
+    return t / t.norm(dim=-1, keepdim=True).clamp_min(eps)
+
+
+def anchor_attention(x: torch.Tensor, p: Params, prefix: str, heads: int) -> torch.Tensor:
+    """SelfAttention.forward (unet_blocks.py:131-178).  The line `b, c, h, w = x.shape` rebinds the optional
+    argument `w` to the image WIDTH, so the test `w is not None` always holds and v is multiplied by the width
+    (an int): that factor is part of the reference's function and is kept."""
+    B, C, H, W = x.shape
+    q = _reflect_conv_s2(x, p[prefix + "q_proj.weight"], groups=C)
+    k = _reflect_conv_s2(x, p[prefix + "k_proj.weight"])
+    v = F.conv2d(x, p[prefix + "v_proj.weight"]) * W
+    a = F.conv2d(_reflect_conv_s2(x, p[prefix + "a_proj.0.weight"], groups=C), p[prefix + "a_proj.1.weight"],
+                 p[prefix + "a_proj.1.bias"])
+    split = lambda t: t.reshape(B, heads, t.shape[1] // heads, -1)      # 'b (head c) h w -> b head c (h w)'
+    q, k, v, a = _l2_rows(split(q)), _l2_rows(split(k)), split(v), _l2_rows(split(a))
+    attn_a = torch.softmax((q @ a.transpose(-2, -1)) * p[prefix + "temperature_a"], dim=-1)
+    attn_k = torch.softmax((a @ k.transpose(-2, -1)) * p[prefix + "temperature_v"], dim=-1)
+    out = attn_a @ (attn_k @ v)
+    return F.conv2d(out.reshape(B, C, H, W), p[prefix + "project_out.weight"])
+
+
+UNET_HEADS = {"att1": 2, "att2": 2, "att3": 4, "att4": 4}                    # unet.py:23-26
+
+
+def unet(x: torch.Tensor, p: Params, prefix: str = "", train: bool = False, stats: Optional[dict] = None) -> torch.Tensor:
+    """UNet(in, P).forward (unet.py:30-42): x [B,1,H,W] -> [B,P,H,W]; H, W multiples of 16."""
+    xs = [double_conv(x, p, prefix + "proj.double_conv.", train, stats)]
+    for i in range(1, 5):
+        xs.append(double_conv(F.max_pool2d(xs[-1], 2), p, prefix + f"down{i}.maxpool_conv.1.double_conv.", train, stats))
+    y = xs[4]
+    for i in range(1, 5):
+        skip = anchor_attention(xs[4 - i], p, prefix + f"att{5 - i}.", UNET_HEADS[f"att{5 - i}"])
+        up = F.conv_transpose2d(y, p[prefix + f"up{i}.up.weight"], p[prefix + f"up{i}.up.bias"], stride=2)
+        y = double_conv(torch.cat([skip, up], dim=1), p, prefix + f"up{i}.conv.double_conv.", train, stats)
+    return F.conv2d(y, p[prefix + "reproj.conv.weight"], p[prefix + "reproj.conv.bias"])

@@ -73,6 +73,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.ksr_last_error.restype = c_char_p
     L.ksr_gram_slab_floats.restype = c_int64
     L.ksr_ssim_slab_floats.restype = c_int64
+    L.ksr_unet_conv_partials.restype = c_int64
+    L.ksr_unet_att_slab_floats.restype = c_int64
 
 
 # every symbol include/ksr.h declares (tests/test_host_logic.py compares the two lists)
@@ -92,6 +94,8 @@ EXPORTS = [
     "ksr_chan_soft_fwd", "ksr_chan_soft_bwd", "ksr_sum_entries", "ksr_chan_apply",
     "ksr_rgb_to_ycbcr", "ksr_ycbcr_to_rgb", "ksr_bilinear_up_to_rgb",
     "ksr_ssim_slab_floats", "ksr_ssim_fwd", "ksr_ssim_y_grad",
+    "ksr_unet_conv_partials", "ksr_unet_conv_fwd", "ksr_unet_bn_finalize", "ksr_unet_bn_relu_fwd", "ksr_unet_convt_fwd",
+    "ksr_unet_att_slab_floats", "ksr_unet_att_mix",
 ]
 
 

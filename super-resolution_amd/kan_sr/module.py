@@ -77,9 +77,13 @@ class GazeTR(_Container):                   # conv_sep_kan/gazetr.py:69-98
 
 
 class ConvSepKanEncoder(_Container):        # conv_sep_kan/conv_sep_kan_encoder.py:12-17
-    def __init__(self, in_channels, out_channels, attention=False):
+    def __init__(self, in_channels, out_channels, attention=False, backbone="gazetr"):
         super().__init__()
-        self.encoder = GazeTR(in_channels, out_channels, attention)
+        if backbone == "unet":              # the backbone conv_sep_kan_encoder.py:7 imports beside GazeTR
+            from .unet import UNet
+            self.encoder = UNet(in_channels, out_channels)
+        else:
+            self.encoder = GazeTR(in_channels, out_channels, attention)
 
 
 class ConvSepKanCell(_Container):           # conv_sep_kan/conv_sep_kan_cells.py:106-134 (no parameters)
@@ -91,10 +95,11 @@ class ConvSepKanCell(_Container):           # conv_sep_kan/conv_sep_kan_cells.py
 
 
 class ConvSepKanLayer(_Container):          # conv_sep_kan/conv_sep_kan_layer.py:7-15
-    def __init__(self, in_channels, out_channels, grid_size, spline_order, residual_std, grid_range, attention=False):
+    def __init__(self, in_channels, out_channels, grid_size, spline_order, residual_std, grid_range, attention=False,
+                 backbone="gazetr"):
         super().__init__()
         self.kan_cell = ConvSepKanCell(in_channels, out_channels, grid_size, spline_order, residual_std, grid_range)
-        self.encoder = ConvSepKanEncoder(in_channels, self.kan_cell.size, attention)
+        self.encoder = ConvSepKanEncoder(in_channels, self.kan_cell.size, attention, backbone)
 
 
 class ConvSepKan(nn.Module):
@@ -104,13 +109,22 @@ class ConvSepKan(nn.Module):
     attention=True (keyword only, not in the reference's constructor) is this build's wiring of the
     reference's stand-alone ConvSepKanAttention (conv_sep_kan/conv_sep_kan_attention.py) into the model: the
     `feed` 1x1 conv that maps the 64 encoder features to the per-pixel KAN parameters is replaced by
-    ConvSepKanAttention(64, 64, P) (state_dict keys `...encoder.encoder.feed.{q,k,v,a}_{proj,dw}.*`)."""
+    ConvSepKanAttention(64, 64, P) (state_dict keys `...encoder.encoder.feed.{q,k,v,a}_{proj,dw}.*`).
+
+    backbone="unet" (keyword only) selects the reference's UNet (conv_sep_kan/unet.py) as the hyper-encoder in place
+    of GazeTR, i.e. `self.encoder = UNet(in_channels, out_channels)` at conv_sep_kan_encoder.py:17; state_dict keys
+    `layers.N.encoder.encoder.{proj,down1..4,up1..4,att1..4,reproj}.*`.  Forward (inference) only."""
 
     def __init__(self, in_channels: list, out_channels: list, kernel_sizes: list, grid_size, spline_order,
-                 residual_std, grid_range, upscale, *, attention: bool = False):
+                 residual_std, grid_range, upscale, *, attention: bool = False, backbone: str = "gazetr"):
         super().__init__()
+        if backbone not in ("gazetr", "unet"):
+            raise KsrError(f"backbone must be 'gazetr' or 'unet', got {backbone!r}")
+        if backbone == "unet" and attention:
+            raise KsrError("attention=True replaces GazeTR's feed conv: it does not combine with backbone='unet'")
         self.upscale = upscale
         self.attention = attention
+        self.backbone = backbone
         self.grid_size, self.spline_order, self.grid_range = grid_size, spline_order, list(grid_range)
         # "fp32": exact fp32 MFMA (parity with the reference to fp32 round-off); "bf16": bf16 MFMA operands with
         # fp32 accumulation (separately stated tolerance).  Not part of the reference's constructor.
@@ -119,7 +133,7 @@ class ConvSepKan(nn.Module):
         self.shuffle = nn.PixelShuffle(upscale)          # kept for module-tree parity; no parameters
         for in_ch, out_ch in zip(in_channels, out_channels):
             self.layers.append(ConvSepKanLayer(in_ch, out_ch, grid_size, spline_order, residual_std, grid_range,
-                                               attention))
+                                               attention, backbone))
         if len(self.layers) == 0:
             raise KsrError("ConvSepKan needs at least one layer")
         # Every layer is fed the Y plane and only the last layer's output survives the reference's
@@ -141,6 +155,10 @@ class ConvSepKan(nn.Module):
         p = self._params()
         pre = f"layers.{len(self.layers) - 1}.encoder.encoder."
         engine.set_precision(self.precision)
+        if self.backbone == "unet":
+            from .ops import kan_head
+            w = self.layers[-1].encoder.encoder.forward_nhwc(x[:, :1])
+            return kan_head(x, w, self.grid_size, self.spline_order, self.grid_range, self.upscale)
         needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in p.values())
         p_drop = self.layers[-1].encoder.encoder.encoder.layers[0].p_drop if self.training else 0.0
         seed = engine.new_seed() if p_drop > 0 else 0

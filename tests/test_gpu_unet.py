@@ -1,0 +1,130 @@
+"""UNet hyper-encoder (forward) on the HIP path against the reference goldens and the CPU oracle."""
+import pytest
+import torch
+
+from conftest import load_golden, rel_l2, t
+from oracle import convsepkan_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+# fp32 against the reference's fp32: the network is 18 convolutions deep with BatchNorm rescaling in between, so the
+# bound is stated on the whole tensor (relative L2) plus a loose element-wise one
+REL_L2, ATOL, RTOL = 2e-5, 2e-4, 1e-3
+
+
+def assert_close(a, ref, what=""):
+    a, ref = a.detach().cpu(), ref.detach().cpu()
+    assert a.shape == ref.shape, (a.shape, ref.shape)
+    assert rel_l2(a, ref) <= REL_L2, f"{what}: rel L2 {rel_l2(a, ref):.3e}"
+    err = (a - ref).abs()
+    assert bool((err <= ATOL + RTOL * ref.abs()).all()), f"{what}: max err {float(err.max()):.3e}"
+
+
+def _unet(P, sd=None):
+    from kan_sr.unet import UNet
+    m = UNet(1, P)
+    if sd is not None:
+        m.load_state_dict({k: v.clone() for k, v in sd.items()})
+    return m.cuda()
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("tag,name", [("att8", "att2"), ("att32", "att4")])
+def test_anchor_attention_golden(tag, name):
+    """SelfAttention alone (dim 8 / 2 heads and dim 32 / 4 heads), including the factor `width` on v."""
+    g = load_golden("unet")
+    m = _unet(40)
+    att = getattr(m, name)
+    att.load_state_dict({k[len(tag) + 3:]: t(v) for k, v in g.items() if k.startswith(tag + ".p.")})
+    att.cuda()
+    x = t(g[tag + ".x"]).cuda()
+    B, C, H, W = x.shape
+    with torch.no_grad():
+        y = m._attention(name, _nhwc(x), B, H, W)
+    assert_close(y, _nhwc(t(g[tag + ".y"])), tag)
+
+
+@pytest.mark.parametrize("tag,P", [("u40", 40), ("u160", 160)])
+def test_unet_golden_eval_and_train(tag, P):
+    g = load_golden("unet")
+    sd = {k[len(tag) + 4:]: t(v) for k, v in g.items() if k.startswith(tag + ".sd.")}
+    m = _unet(P, sd)
+    x = t(g[tag + ".x"]).cuda()
+    with torch.no_grad():
+        m.eval()
+        assert_close(m(x), t(g[tag + ".y_eval"]), "eval")
+        for k, v in m.state_dict().items():                       # eval leaves the running statistics alone
+            if "running" in k or "num_batches" in k:
+                assert torch.equal(v.cpu().reshape(-1), sd[k].reshape(-1)), k
+        m.train()
+        assert_close(m(x), t(g[tag + ".y_train"]), "train")
+    after = m.state_dict()
+    for k, v in g.items():
+        if k.startswith(tag + ".after."):
+            n = k[len(tag) + 7:]
+            if "num_batches" in n:
+                assert int(after[n]) == int(v), n
+            else:
+                assert rel_l2(after[n].cpu(), t(v)) <= 1e-5, n
+
+
+@pytest.mark.parametrize("B,H,W,P,train", [(1, 16, 16, 40, False), (3, 48, 80, 160, True), (2, 64, 32, 336, True),
+                                           (5, 16, 112, 64, False), (2, 256, 256, 160, True)])
+def test_unet_vs_oracle(B, H, W, P, train):
+    """Other sizes: a single image with a 1x1 bottleneck, non-square sizes, sizes with partial 256-pixel workgroups,
+    attention inputs longer than one Gram slab (256x256), every supported head size."""
+    torch.manual_seed(B * 100 + H)
+    m = _unet(P)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.uniform_(0.5, 1.5); mod.bias.normal_(0, 0.2)
+                mod.running_mean.normal_(0, 0.1); mod.running_var.uniform_(0.5, 1.5)
+            if hasattr(mod, "temperature_a"):
+                mod.temperature_a.normal_(1, 0.5); mod.temperature_v.normal_(1, 0.5)
+    p = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(B, 1, H, W)
+    stats = {}
+    ref = orc.unet(x, p, "", train, stats)
+    m.train(train)
+    with torch.no_grad():
+        y = m(x.cuda())
+    assert_close(y, ref, "forward")
+    if train:
+        after = m.state_dict()
+        for k, v in stats.items():
+            if "num_batches" in k:
+                assert int(after[k]) == int(v)
+            else:
+                assert rel_l2(after[k].cpu(), v) <= 1e-5, k
+
+
+def test_model_with_unet_backbone_vs_oracle():
+    """ConvSepKan(backbone='unet'): UNet -> KAN cell -> pixel shuffle, chroma bilinear; state_dict keys of the reference's
+    UNet under layers.0.encoder.encoder."""
+    from kan_sr.module import ConvSepKan
+    torch.manual_seed(3)
+    m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4, backbone="unet").cuda().eval()
+    g = load_golden("unet")
+    ref_keys = [k[len("u160.sd."):] for k in g if k.startswith("u160.sd.")]
+    assert [k[len("layers.0.encoder.encoder."):] for k in m.state_dict()] == ref_keys
+    p = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(2, 3, 32, 48)
+    ref = orc.conv_sep_kan_forward(x, p, out_channels=[16], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=4,
+                                   backbone="unet")
+    with torch.no_grad():
+        y = m(x.cuda())
+    assert y.shape == (2, 3, 128, 192)
+    assert_close(y, ref, "model")
+
+
+def test_unet_refuses_gradients_and_bad_sizes():
+    from kan_sr._lib import KsrError
+    m = _unet(40)
+    with pytest.raises(KsrError, match="forward kernels only"):
+        m(torch.rand(1, 1, 16, 16, device="cuda"))
+    with torch.no_grad(), pytest.raises(KsrError, match="multiples of 16"):
+        m(torch.rand(1, 1, 24, 16, device="cuda"))

@@ -183,3 +183,43 @@ def test_color_conversion():
     assert (ycc[0, :, 0, 0] - torch.tensor([16., 128., 128.]) / 255).abs().max() <= 1e-6      # black
     assert (ycc[0, :, 0, 1] - torch.tensor([235., 128., 128.]) / 255).abs().max() <= 2e-6     # white
     assert (t(g["rgb_back"]) - t(g["rgb"])).abs().max() <= 1e-5
+
+
+@pytest.mark.parametrize("tag,heads", [("att8", 2), ("att32", 4)])
+def test_unet_anchor_attention(tag, heads):
+    """SelfAttention (conv_sep_kan/unet_blocks.py:91-178) forward and gradients."""
+    g = load_golden("unet")
+    p = {k[len(tag) + 3:]: t(v).requires_grad_() for k, v in g.items() if k.startswith(tag + ".p.")}
+    x = t(g[tag + ".x"]).requires_grad_()
+    y = orc.anchor_attention(x, p, "", heads)
+    assert_fwd(y.detach(), t(g[tag + ".y"]))
+    (y * t(g[tag + ".gy"])).sum().backward()
+    assert rel_l2(x.grad, t(g[tag + ".gx"])) <= GRAD_REL
+    for n, v in p.items():
+        assert rel_l2(v.grad, t(g[f"{tag}.g.{n}"])) <= GRAD_REL, n
+
+
+@pytest.mark.parametrize("tag", ["u40", "u160"])
+def test_unet(tag):
+    """UNet (conv_sep_kan/unet.py:7-42): eval forward, train forward with the running-statistics update and, for the
+    small case, the parameter gradients of the train-mode pass."""
+    g = load_golden("unet")
+    p = {k[len(tag) + 4:]: t(v) for k, v in g.items() if k.startswith(tag + ".sd.")}
+    p = {k: (v.requires_grad_() if v.dtype == torch.float32 and "running" not in k else v) for k, v in p.items()}
+    x = t(g[tag + ".x"])
+    with torch.no_grad():
+        assert_fwd(orc.unet(x, p, "", False), t(g[tag + ".y_eval"]))
+    stats = {}
+    y = orc.unet(x, p, "", True, stats)
+    assert_fwd(y.detach(), t(g[tag + ".y_train"]))
+    for k, v in stats.items():
+        ref = t(g[f"{tag}.after.{k}"])
+        if "num_batches" in k:
+            assert int(v) == int(ref)
+        else:
+            assert rel_l2(v.detach(), ref) <= 1e-6, k
+    if tag + ".gy" in g:
+        (y * t(g[tag + ".gy"])).sum().backward()
+        for n, v in p.items():
+            if v.requires_grad:
+                assert rel_l2(v.grad, t(g[f"{tag}.g.{n}"])) <= 5e-4, n
