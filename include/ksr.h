@@ -374,10 +374,12 @@ int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, int c1, cons
 
 /* nn.BatchNorm2d (unet_blocks.py:21,27) reduced to y = x*scale + shift.  train != 0: batch mean / biased variance from
  * the n_partials rows written by ksr_unet_conv_fwd over `count` values per channel, and the running statistics move
- * by `momentum` (unbiased variance), as torch does; train == 0: the running statistics are used and left alone. */
+ * by `momentum` (unbiased variance), as torch does; train == 0: the running statistics are used and left alone.
+ * saved_mean_invstd (or NULL): [2][C], the mean and 1/sqrt(var+eps) that were used, for the backward. */
 int ksr_unet_bn_finalize(const float* stat_partials, int n_partials, int64_t count, const float* gamma,
                          const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                         int train, float* scale, float* shift, int C, ksr_stream_t stream);
+                         int train, float* scale, float* shift, float* saved_mean_invstd, int C,
+                         ksr_stream_t stream);
 
 /* out = relu(raw*scale + shift) (unet_blocks.py:27-28) and, with pooled != NULL, pooled [B,H/2,W/2,C] =
  * nn.MaxPool2d(2)(out) (:40).  C % 4 == 0. */
@@ -398,7 +400,49 @@ int ksr_unet_convt_fwd(const float* in, const float* weight, const float* bias, 
 int64_t ksr_unet_att_slab_floats(int c, int B, int64_t n);
 int ksr_unet_att_mix(const float* z, int zc, int c, int heads, int64_t n, int B, const float* temp_a,
                      const float* temp_v, const float* wv, const float* wp, float vscale, float* slab, float* T,
-                     ksr_stream_t stream);
+                     float* g_saved, ksr_stream_t stream);
+
+/* ---- UNet backward.  Data gradients of the stride-1 / 1x1 convs and of the transposed conv are ksr_unet_conv_fwd
+ * calls on re-laid-out weights (3x3: taps reversed, in/out swapped; ConvTranspose2d: ks = 2, stride = 2). */
+
+/* Weight gradient, reduced over pixels and (unless per_image) images, in the forward weight layout:
+ * mode 0: out[tap][ci][co] = sum a[b, map(p, tap)][ci] g[b,p][co] for the conv ks/stride/reflect of
+ *         ksr_unet_conv_fwd (a = a0 | a1 concatenated, a0 optionally read as relu(x*a_scale+a_shift));
+ * mode 1: ConvTranspose2d 2x2: out[dy*2+dx][ci][co] = sum a[b,y,x][ci] g[b,2y+dy,2x+dx][co];
+ * mode 2: out[co] = sum g[b,p][co] (bias gradients).
+ * a [B,Ha,Wa,ca0(+ca1)], g [B,Hg,Wg,cg]; slab: ksr_unet_wgrad_slab_floats(...) floats; per_image: out gets a
+ * leading [B] axis (the per-image matrices of the attention backward). */
+int64_t ksr_unet_wgrad_slab_floats(int mode, int ks, int ca, int cg, int B, int Ha, int Wa, int Hg, int Wg);
+int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1, const float* a_scale, const float* a_shift,
+                   const float* g, int cg, float* slab, float* out, int per_image, int mode, int ks, int stride,
+                   int reflect, int B, int Ha, int Wa, int Hg, int Wg, ksr_stream_t stream);
+
+/* Backward of relu(BatchNorm2d(raw)) (unet_blocks.py:21-22,27-28): dout = gradient of the activated output;
+ * writes dgamma, dbeta [C] and dx = gradient of raw.  train != 0 differentiates through the batch statistics.
+ * scale/shift/saved_mean_invstd as produced by ksr_unet_bn_finalize; partials: ksr_unet_bn_bwd_partials(npix)
+ * rows of [2][C]; coef: 3*C floats of workspace. */
+int64_t ksr_unet_bn_bwd_partials(int64_t npix);
+int ksr_unet_bn_relu_bwd(const float* dout, const float* raw, const float* scale, const float* shift,
+                         const float* gamma, const float* saved_mean_invstd, int train, float* partials,
+                         float* coef, float* dgamma, float* dbeta, float* dx, int64_t npix, int C,
+                         ksr_stream_t stream);
+
+/* Sum of the gradients that meet at an encoder level: out = g0 + g1 (optional) + MaxPool2d(2) backward of
+ * g_pooled (optional; routed to the first maximum of each window of act, the activated output). */
+int ksr_unet_grad_merge(const float* g0, const float* g1, const float* g_pooled, const float* act, float* out,
+                        int B, int H, int W, int C, ksr_stream_t stream);
+
+/* Data gradient of the 3x3 stride-2 reflect-padded projections (unet_blocks.py:100-127): dz [B,Ho,Wo,cz] ->
+ * dx [B,H,W,cin]; weight [9][cz][cin]. */
+int ksr_unet_s2_dgrad(const float* dz, int cz, const float* weight, float* dx, int cin, int B, int H, int W,
+                      ksr_stream_t stream);
+
+/* Backward of ksr_unet_att_mix from dT [B][c][c]: D [B][zc][zc] with dz[b,n,:] = z[b,n,:] D[b] (applied by
+ * ksr_unet_conv_fwd, ks = 1) and dparams [B][2c^2 + 2 heads] = per-image gradients of v_proj | project_out |
+ * temperature_a | temperature_v (to be summed over images). */
+int ksr_unet_att_mix_bwd(const float* g_saved, const float* dT, int c, int heads, int zc, int B,
+                         const float* temp_a, const float* temp_v, const float* wv, const float* wp, float vscale,
+                         float* D, float* dparams, ksr_stream_t stream);
 
 #ifdef __cplusplus
 }

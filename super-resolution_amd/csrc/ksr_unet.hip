@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) unet_conv_kernel(ConvArgs a) {
     float acc[CT];
 #pragma unroll
     for (int co = 0; co < CT; ++co) acc[co] = a.bias ? a.bias[cz + co] : 0.f;
-    const int pad = a.ks >> 1;
+    const int pad = a.ks == 3 ? 1 : 0;
     for (int ky = 0; ky < a.ks; ++ky) {
         int iy = oy * a.stride + ky - pad;
         bool oky = true;
@@ -113,7 +113,7 @@ struct BnArgs {
     const float* partials; int nparts; long count;
     const float* gamma; const float* beta; float* rmean; float* rvar;
     float momentum, eps; int train;
-    float* scale; float* shift; int C;
+    float* scale; float* shift; float* saved; int C;
 };
 
 // one workgroup per channel: batch statistics (train) or running statistics (eval) -> y = x*scale + shift
@@ -148,6 +148,7 @@ __global__ void __launch_bounds__(256) unet_bn_finalize_kernel(BnArgs a) {
         const float sc = a.gamma[c] * (float)(1.0 / sqrt(var + (double)a.eps));
         a.scale[c] = sc;
         a.shift[c] = a.beta[c] - (float)mean * sc;
+        if (a.saved) { a.saved[c] = (float)mean; a.saved[a.C + c] = (float)(1.0 / sqrt(var + (double)a.eps)); }
     }
 }
 
@@ -263,6 +264,7 @@ struct MixArgs {
     const float* wv; const float* wp;           // v_proj, project_out weights [c][c] (out, in)
     float vscale;
     float* T;                                   // [B][c (in)][c (out)]: per-image 1x1 weights, x -> attention output
+    float* g_out;                               // null or [B][E]: the reduced products, kept for the backward
 };
 
 // one workgroup per image: softmaxes of the two anchor products, their product per head, folded with v_proj and
@@ -276,6 +278,7 @@ __global__ void __launch_bounds__(256) unet_att_mix_kernel(MixArgs a) {
         float s = 0.f;
         for (int i = 0; i < a.nslab; ++i) s += a.partials[((long)b * a.nslab + i) * E + e];
         g[e] = s;
+        if (a.g_out) a.g_out[(long)b * E + e] = s;
     }
     __syncthreads();
     const float* nrm2 = g + 2 * nqa;              // squared norms: q [0,c), k [c,2c), a [2c,2c+ca)
@@ -352,13 +355,13 @@ extern "C" int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, i
     KSR_CHECK_ARG(src0 && weight && out && B > 0 && Hin > 0 && Win > 0 && c0 > 0 && c1 >= 0 && cout > 0, "unet_conv: bad argument");
     KSR_CHECK_ARG((src1 != nullptr) == (c1 > 0), "unet_conv: src1 and c1 disagree");
     KSR_CHECK_ARG((in_scale != nullptr) == (in_shift != nullptr), "unet_conv: in_scale and in_shift go together");
-    KSR_UNSUPPORTED(ks != 1 && ks != 3, "unet_conv: kernel size %d (1 or 3)", ks);
+    KSR_UNSUPPORTED(ks < 1 || ks > 3, "unet_conv: kernel size %d (1, 2 or 3)", ks);
     KSR_UNSUPPORTED(stride != 1 && stride != 2, "unet_conv: stride %d (1 or 2)", stride);
     KSR_UNSUPPORTED(cout % 4 != 0, "unet_conv: cout = %d must be a multiple of 4", cout);
     KSR_UNSUPPORTED(c1 > 0 && ((c0 & 3) || (c1 & 3)), "unet_conv: concatenated inputs need channel counts that are multiples of 4");
     KSR_UNSUPPORTED(reflect && (Hin < 2 || Win < 2), "unet_conv: reflect padding needs at least 2 pixels per side");
     KSR_UNSUPPORTED(B > 65535 || cout / 4 > 65535, "unet_conv: batch %d too large for one launch", B);
-    const int pad = ks / 2;
+    const int pad = ks == 3 ? 1 : 0;
     ConvArgs a{src0, src1, c0, c1, in_scale, in_shift, weight, (long)w_image_stride, bias, out, cout, stat_partials, ks, stride, reflect,
                Hin, Win, (Hin + 2 * pad - ks) / stride + 1, (Win + 2 * pad - ks) / stride + 1};
     if (cout % 16 == 0) return launch_conv<16>(a, B, stream);
@@ -368,10 +371,10 @@ extern "C" int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, i
 
 extern "C" int ksr_unet_bn_finalize(const float* stat_partials, int n_partials, int64_t count, const float* gamma, const float* beta,
                                     float* running_mean, float* running_var, float momentum, float eps, int train, float* scale,
-                                    float* shift, int C, hipStream_t stream) {
+                                    float* shift, float* saved_mean_invstd, int C, hipStream_t stream) {
     KSR_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "unet_bn_finalize: bad argument");
     KSR_CHECK_ARG(!train || (stat_partials && n_partials > 0 && count > 0), "unet_bn_finalize: training mode needs the partial sums");
-    BnArgs a{stat_partials, n_partials, (long)count, gamma, beta, running_mean, running_var, momentum, eps, train, scale, shift, C};
+    BnArgs a{stat_partials, n_partials, (long)count, gamma, beta, running_mean, running_var, momentum, eps, train, scale, shift, saved_mean_invstd, C};
     hipLaunchKernelGGL(unet_bn_finalize_kernel, dim3((unsigned)C), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("unet_bn_finalize");
     return KSR_OK;
@@ -415,7 +418,8 @@ extern "C" int64_t ksr_unet_att_slab_floats(int c, int B, int64_t n) {
 }
 
 extern "C" int ksr_unet_att_mix(const float* z, int zc, int c, int heads, int64_t n, int B, const float* temp_a, const float* temp_v,
-                                const float* wv, const float* wp, float vscale, float* slab, float* T, hipStream_t stream) {
+                                const float* wv, const float* wp, float vscale, float* slab, float* T, float* g_saved,
+                                hipStream_t stream) {
     KSR_CHECK_ARG(z && temp_a && temp_v && wv && wp && slab && T && B > 0 && n > 0, "unet_att_mix: bad argument");
     KSR_UNSUPPORTED(c < 4 || c > 32 || (c & (c - 1)), "unet_att_mix: dim = %d (4, 8, 16 or 32)", c);
     KSR_UNSUPPORTED(heads < 1 || (c / 2) % heads != 0, "unet_att_mix: %d heads do not divide dim/2 = %d", heads, c / 2);
@@ -425,7 +429,7 @@ extern "C" int ksr_unet_att_mix(const float* z, int zc, int c, int heads, int64_
     GramArgs g{z, zc, c, (long)n, KSR_ATT_SLAB, nslab, slab};
     hipLaunchKernelGGL(unet_att_gram_kernel, dim3((unsigned)nslab, (unsigned)B), dim3(256), 0, stream, g);
     KSR_LAUNCH_CHECK("unet_att_gram");
-    MixArgs m{slab, nslab, c, heads, temp_a, temp_v, wv, wp, vscale, T};
+    MixArgs m{slab, nslab, c, heads, temp_a, temp_v, wv, wp, vscale, T, g_saved};
     hipLaunchKernelGGL(unet_att_mix_kernel, dim3((unsigned)B), dim3(256), 0, stream, m);
     KSR_LAUNCH_CHECK("unet_att_mix");
     return KSR_OK;

@@ -75,6 +75,8 @@ def _declare(L: ctypes.CDLL) -> None:
     L.ksr_ssim_slab_floats.restype = c_int64
     L.ksr_unet_conv_partials.restype = c_int64
     L.ksr_unet_att_slab_floats.restype = c_int64
+    L.ksr_unet_wgrad_slab_floats.restype = c_int64
+    L.ksr_unet_bn_bwd_partials.restype = c_int64
 
 
 # every symbol include/ksr.h declares (tests/test_host_logic.py compares the two lists)
@@ -96,6 +98,8 @@ EXPORTS = [
     "ksr_ssim_slab_floats", "ksr_ssim_fwd", "ksr_ssim_y_grad",
     "ksr_unet_conv_partials", "ksr_unet_conv_fwd", "ksr_unet_bn_finalize", "ksr_unet_bn_relu_fwd", "ksr_unet_convt_fwd",
     "ksr_unet_att_slab_floats", "ksr_unet_att_mix",
+    "ksr_unet_wgrad_slab_floats", "ksr_unet_wgrad", "ksr_unet_bn_bwd_partials", "ksr_unet_bn_relu_bwd", "ksr_unet_grad_merge",
+    "ksr_unet_s2_dgrad", "ksr_unet_att_mix_bwd",
 ]
 
 
