@@ -391,16 +391,14 @@ int ksr_unet_bn_relu_fwd(const float* raw, const float* scale, const float* shif
 int ksr_unet_convt_fwd(const float* in, const float* weight, const float* bias, float* out, int cin, int cout,
                        int B, int h, int w, ksr_stream_t stream);
 
-/* SelfAttention's per-image algebra (unet_blocks.py:141-177).  z [B,n,zc] = q (c channels) | k (c) | a (c/2) at half
- * resolution.  Computes the L2-normalised products q a^T and a k^T (:154-156,161,164), their softmaxes scaled by the
- * per-head temperatures, attn_a attn_k (:167-169) and folds v_proj (times vscale: the reference multiplies v by the
- * image width, :132,137-138) and project_out (:177) in: T [B][c][c] ([in][out]) with
- * attention(x)[b,p,:] = x[b,p,:] T[b], applied by ksr_unet_conv_fwd (ks = 1, w_image_stride = c*c).
- * slab: ksr_unet_att_slab_floats(c, B, n) floats.  c in {4, 8, 16, 32}. */
-int64_t ksr_unet_att_slab_floats(int c, int B, int64_t n);
-int ksr_unet_att_mix(const float* z, int zc, int c, int heads, int64_t n, int B, const float* temp_a,
-                     const float* temp_v, const float* wv, const float* wp, float vscale, float* slab, float* T,
-                     float* g_saved, ksr_stream_t stream);
+/* SelfAttention's per-image algebra (unet_blocks.py:141-177).  gram [B][zc][zc] = z^T z per image for z [B,n,zc] =
+ * q (c channels) | k (c) | a (c/2) at half resolution (computed by ksr_unet_wgrad: ks = 1, a = g = z, per_image).
+ * Forms the L2-normalised products q a^T and a k^T (:154-156,161,164), their softmaxes scaled by the per-head
+ * temperatures, attn_a attn_k (:167-169) and folds v_proj (times vscale: the reference multiplies v by the image
+ * width, :132,137-138) and project_out (:177) in: T [B][c][c] ([in][out]) with attention(x)[b,p,:] = x[b,p,:] T[b],
+ * applied by ksr_unet_conv_fwd (ks = 1, w_image_stride = c*c).  c in {4, 8, 16, 32}. */
+int ksr_unet_att_mix(const float* gram, int zc, int c, int heads, int B, const float* temp_a, const float* temp_v,
+                     const float* wv, const float* wp, float vscale, float* T, ksr_stream_t stream);
 
 /* ---- UNet backward.  Data gradients of the stride-1 / 1x1 convs and of the transposed conv are ksr_unet_conv_fwd
  * calls on re-laid-out weights (3x3: taps reversed, in/out swapped; ConvTranspose2d: ks = 2, stride = 2). */
@@ -440,7 +438,7 @@ int ksr_unet_s2_dgrad(const float* dz, int cz, const float* weight, float* dx, i
 /* Backward of ksr_unet_att_mix from dT [B][c][c]: D [B][zc][zc] with dz[b,n,:] = z[b,n,:] D[b] (applied by
  * ksr_unet_conv_fwd, ks = 1) and dparams [B][2c^2 + 2 heads] = per-image gradients of v_proj | project_out |
  * temperature_a | temperature_v (to be summed over images). */
-int ksr_unet_att_mix_bwd(const float* g_saved, const float* dT, int c, int heads, int zc, int B,
+int ksr_unet_att_mix_bwd(const float* gram, const float* dT, int c, int heads, int zc, int B,
                          const float* temp_a, const float* temp_v, const float* wv, const float* wp, float vscale,
                          float* D, float* dparams, ksr_stream_t stream);
 

@@ -228,10 +228,10 @@ __global__ void __launch_bounds__(256) unet_convt_kernel(ConvTArgs a) {
     }
 }
 
-// ---- anchor attention (unet_blocks.py:131-178).  z [B,n,zc] holds q (c channels) | k (c) | a (c/2) at half resolution.
-// Per image: QA[i][j] = sum_n q_i a_j, AK[j][i] = sum_n a_j k_i and the squared norms of all 2.5c channels.
-struct GramArgs { const float* z; int zc, c; long n; int slab, nslab; float* partials; };
-
+// ---- anchor attention (unet_blocks.py:131-178).  z [B,n,zc] holds q (c channels) | k (c) | a (c/2) at half resolution;
+// its per-image Gram matrix z^T z [zc][zc] (the weight-gradient kernel computes it) holds q_i.a_j, a_j.k_i and the
+// squared norms.
+// entry e of the packed products -> the pair of channels of z: q_i a_j, then a_j k_i, then the squared norms
 __device__ __forceinline__ void gram_entry(int e, int c, int& A, int& Bc) {
     const int ca = c >> 1, nqa = c * ca;
     if (e < nqa) { A = e / ca; Bc = 2 * c + e % ca; }
@@ -239,32 +239,12 @@ __device__ __forceinline__ void gram_entry(int e, int c, int& A, int& Bc) {
     else { A = Bc = e - 2 * nqa; }
 }
 
-__global__ void __launch_bounds__(256) unet_att_gram_kernel(GramArgs a) {
-    const int b = blockIdx.y, s = blockIdx.x;
-    const long p0 = (long)s * a.slab;
-    const long p1 = p0 + a.slab < a.n ? p0 + a.slab : a.n;
-    const int E = a.c * a.c + (5 * a.c) / 2;
-    int L = 1;
-    while (L * 2 * E <= 256) L *= 2;              // lanes that share one entry (a power of two, at most 8)
-    const int l = threadIdx.x % L, e0 = threadIdx.x / L, estride = 256 / L;
-    const float* zb = a.z + (long)b * a.n * a.zc;
-    for (int e = e0; e < E; e += estride) {
-        int A, Bc;
-        gram_entry(e, a.c, A, Bc);
-        float acc = 0.f;
-        for (long p = p0 + l; p < p1; p += L) acc = fmaf(zb[p * a.zc + A], zb[p * a.zc + Bc], acc);
-        for (int m = L >> 1; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
-        if (l == 0) a.partials[((long)b * a.nslab + s) * E + e] = acc;
-    }
-}
-
 struct MixArgs {
-    const float* partials; int nslab, c, heads;
+    const float* gram; int zc, c, heads;       // [B][zc][zc]
     const float* temp_a; const float* temp_v;   // [heads]
     const float* wv; const float* wp;           // v_proj, project_out weights [c][c] (out, in)
     float vscale;
     float* T;                                   // [B][c (in)][c (out)]: per-image 1x1 weights, x -> attention output
-    float* g_out;                               // null or [B][E]: the reduced products, kept for the backward
 };
 
 // one workgroup per image: softmaxes of the two anchor products, their product per head, folded with v_proj and
@@ -275,10 +255,9 @@ __global__ void __launch_bounds__(256) unet_att_mix_kernel(MixArgs a) {
     const int ch = c / a.heads, cah = ca / a.heads;
     __shared__ float g[32 * 32 + 80], at_a[32 * 16], at_k[16 * 32], M[32 * 32], T1[32 * 32];
     for (int e = threadIdx.x; e < E; e += 256) {
-        float s = 0.f;
-        for (int i = 0; i < a.nslab; ++i) s += a.partials[((long)b * a.nslab + i) * E + e];
-        g[e] = s;
-        if (a.g_out) a.g_out[(long)b * E + e] = s;
+        int A, Bc;
+        gram_entry(e, c, A, Bc);
+        g[e] = a.gram[((long)b * a.zc + A) * a.zc + Bc];
     }
     __syncthreads();
     const float* nrm2 = g + 2 * nqa;              // squared norms: q [0,c), k [c,2c), a [2c,2c+ca)
@@ -410,26 +389,13 @@ extern "C" int ksr_unet_convt_fwd(const float* in, const float* weight, const fl
     return KSR_OK;
 }
 
-#define KSR_ATT_SLAB 2048
-
-extern "C" int64_t ksr_unet_att_slab_floats(int c, int B, int64_t n) {
-    const int64_t nslab = (n + KSR_ATT_SLAB - 1) / KSR_ATT_SLAB;
-    return (int64_t)B * nslab * (c * c + (5 * c) / 2);
-}
-
-extern "C" int ksr_unet_att_mix(const float* z, int zc, int c, int heads, int64_t n, int B, const float* temp_a, const float* temp_v,
-                                const float* wv, const float* wp, float vscale, float* slab, float* T, float* g_saved,
-                                hipStream_t stream) {
-    KSR_CHECK_ARG(z && temp_a && temp_v && wv && wp && slab && T && B > 0 && n > 0, "unet_att_mix: bad argument");
+extern "C" int ksr_unet_att_mix(const float* gram, int zc, int c, int heads, int B, const float* temp_a, const float* temp_v,
+                                const float* wv, const float* wp, float vscale, float* T, hipStream_t stream) {
+    KSR_CHECK_ARG(gram && temp_a && temp_v && wv && wp && T && B > 0, "unet_att_mix: bad argument");
     KSR_UNSUPPORTED(c < 4 || c > 32 || (c & (c - 1)), "unet_att_mix: dim = %d (4, 8, 16 or 32)", c);
     KSR_UNSUPPORTED(heads < 1 || (c / 2) % heads != 0, "unet_att_mix: %d heads do not divide dim/2 = %d", heads, c / 2);
     KSR_CHECK_ARG(zc >= 2 * c + c / 2, "unet_att_mix: z needs at least 2.5*dim channels");
-    const int nslab = (int)((n + KSR_ATT_SLAB - 1) / KSR_ATT_SLAB);
-    KSR_UNSUPPORTED(B > 65535, "unet_att_mix: batch %d too large for one launch", B);
-    GramArgs g{z, zc, c, (long)n, KSR_ATT_SLAB, nslab, slab};
-    hipLaunchKernelGGL(unet_att_gram_kernel, dim3((unsigned)nslab, (unsigned)B), dim3(256), 0, stream, g);
-    KSR_LAUNCH_CHECK("unet_att_gram");
-    MixArgs m{slab, nslab, c, heads, temp_a, temp_v, wv, wp, vscale, T, g_saved};
+    MixArgs m{gram, zc, c, heads, temp_a, temp_v, wv, wp, vscale, T};
     hipLaunchKernelGGL(unet_att_mix_kernel, dim3((unsigned)B), dim3(256), 0, stream, m);
     KSR_LAUNCH_CHECK("unet_att_mix");
     return KSR_OK;

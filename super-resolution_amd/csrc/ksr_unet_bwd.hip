@@ -9,79 +9,152 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ weight gradients
+#define WG_TILE_FLOATS 12288      // LDS tile: gradient row segment + activation rows (48 KB)
+#define WG_ENTRIES4 1024          // groups of 4 output channels per workgroup (4 per lane)
+
 struct WgArgs {
     const float* a0; const float* a1; int ca0, ca1;   // A side: activations (two concatenated sources), or none (mode 2)
     const float* a_scale; const float* a_shift;       // optional relu(x*scale+shift) on a0
     const float* g; int cg;                           // gradient side [B,Hg,Wg,cg]
-    float* partials;                                  // [B][chunks][E]
+    float* partials;                                  // [B][nwg][E]
     int ks, stride, reflect, mode;                    // mode 0: conv (rows of g), 1: transposed conv 2x2 (rows of A), 2: column sums of g
     int Ha, Wa, Hg, Wg;
-    int rows, chunks, E;
+    int cols, segs, nwg, E;                           // tile = one row segment of `cols` pixels; nwg workgroups per image
 };
 
-// grid (chunks, ceil(E/256), B): lane = one entry (tap, ci, co) of the weight gradient, summed over `rows` image rows
+// grid (nwg, ceil(E/4 / WG_ENTRIES4), B).  A workgroup walks over row segments of one image; each is staged in LDS
+// (activation rows with the padding materialised, BatchNorm + ReLU of the producer applied) and every lane
+// accumulates groups of 4 neighbouring output channels of one (tap, ci) entry.  With few entries the lanes split the
+// pixels of a segment between them and the slices are summed through LDS at the end.
 __global__ void __launch_bounds__(256) unet_wgrad_kernel(WgArgs a) {
-    const int e = blockIdx.y * 256 + threadIdx.x;
-    if (e >= a.E) return;
-    const int b = blockIdx.z;
-    const int ca = a.mode == 2 ? 1 : a.ca0 + a.ca1;
-    const int co = e % a.cg, ci = (e / a.cg) % ca, tap = e / (a.cg * ca);
-    const int Hi = a.mode == 1 ? a.Ha : a.Hg, Wi = a.mode == 1 ? a.Wa : a.Wg;     // iteration space
-    const int y0 = blockIdx.x * a.rows, y1 = y0 + a.rows < Hi ? y0 + a.rows : Hi;
-    const int ky = tap / a.ks, kx = tap % a.ks, pad = a.ks == 3 ? 1 : 0;
-    const bool second = ci >= a.ca0;
-    const float* asrc = second ? a.a1 : a.a0;
-    const int acs = second ? a.ca1 : a.ca0, aci = second ? ci - a.ca0 : ci;
-    const bool xform = a.a_scale && !second;
-    const float sc = xform ? a.a_scale[aci] : 1.f, sh = xform ? a.a_shift[aci] : 0.f;
-    float acc = 0.f;
-    for (int y = y0; y < y1; ++y) {
-        int ay, gy;
-        bool oky = true;
-        if (a.mode == 1) { ay = y; gy = 2 * y + ky; }
-        else {
-            gy = y; ay = y * a.stride + ky - pad;
-            if (a.reflect) ay = ay < 0 ? -ay : (ay >= a.Ha ? 2 * a.Ha - 2 - ay : ay);
-            else oky = ay >= 0 && ay < a.Ha;
+    __shared__ __attribute__((aligned(16))) float tile[WG_TILE_FLOATS];
+    __shared__ float red[1024];
+    const int b = blockIdx.z, t = threadIdx.x;
+    const int ca = a.mode == 2 ? 1 : a.ca0 + a.ca1, cg4 = a.cg >> 2;
+    const int E4 = a.E >> 2;
+    const int Hi = a.mode == 1 ? a.Ha : a.Hg, Wi = a.mode == 1 ? a.Wa : a.Wg;
+    const int pad = a.ks == 3 ? 1 : 0;
+    // tile geometry
+    const int a_rows = a.mode == 0 ? a.ks : 1, g_rows = a.mode == 1 ? 2 : 1;
+    const int as = a.mode == 0 ? a.stride : 1, gs = a.mode == 1 ? 2 : 1;
+    const int a_w = a.mode == 0 ? (a.cols - 1) * a.stride + a.ks : a.cols, g_w = a.cols * gs;
+    const int g_floats = g_rows * g_w * a.cg;
+    float* gl = tile;
+    float* al = tile + g_floats;
+    // lane -> entries
+    const int nsl = E4 >= 256 ? 1 : 256 / E4;
+    const int slice = nsl == 1 ? 0 : t / E4;
+    const bool idle = nsl > 1 && slice >= nsl;
+    int a_off[4], g_off[4];
+    bool live[4];
+    float acc[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e4 = nsl == 1 ? blockIdx.y * WG_ENTRIES4 + k * 256 + t : (k == 0 ? t % E4 : E4);
+        live[k] = e4 < E4 && !idle;
+        const int ec = live[k] ? e4 : 0;
+        const int co4 = ec % cg4, ci = (ec / cg4) % ca, tap = ec / (cg4 * ca);
+        const int ky = tap / a.ks, kx = tap % a.ks;
+        a_off[k] = a.mode == 0 ? (ky * a_w + kx) * ca + ci : ci;
+        g_off[k] = (a.mode == 1 ? (ky * g_w + kx) * a.cg : 0) + co4 * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[k][i] = 0.f;
+    }
+    const int tiles = Hi * a.segs;
+    for (int tl = blockIdx.x; tl < tiles; tl += a.nwg) {
+        const int y = tl / a.segs, x0 = (tl - y * a.segs) * a.cols;
+        const int cols = x0 + a.cols <= Wi ? a.cols : Wi - x0;
+        __syncthreads();
+        // ---- gradient rows: g[b][y*gs + r][x0*gs .. (x0+cols)*gs)[cg]
+        for (int r = 0; r < g_rows; ++r) {
+            const float4* src = reinterpret_cast<const float4*>(a.g + (((long)b * a.Hg + y * gs + r) * a.Wg + (long)x0 * gs) * a.cg);
+            float4* dst = reinterpret_cast<float4*>(gl + r * g_w * a.cg);
+            for (int i = t; i < cols * gs * cg4; i += 256) dst[i] = src[i];
         }
-        if (!oky) continue;
-        const float* grow = a.g + ((long)b * a.Hg + gy) * a.Wg * a.cg + co;
-        const float* arow = a.mode == 2 ? nullptr : asrc + ((long)b * a.Ha + ay) * a.Wa * acs + aci;
-        for (int x = 0; x < Wi; ++x) {
-            int ax, gx;
-            bool ok = true;
-            if (a.mode == 1) { ax = x; gx = 2 * x + kx; }
-            else {
-                gx = x; ax = x * a.stride + kx - pad;
-                if (a.reflect) ax = ax < 0 ? -ax : (ax >= a.Wa ? 2 * a.Wa - 2 - ax : ax);
-                else ok = ax >= 0 && ax < a.Wa;
+        // ---- activation rows, padding and the producer's BatchNorm + ReLU materialised
+        if (a.mode != 2) {
+            const int wcols = a.mode == 0 ? (cols - 1) * a.stride + a.ks : cols;
+            for (int i = t; i < a_rows * wcols * ca; i += 256) {
+                const int ch = i % ca, j = (i / ca) % wcols, r = i / (ca * wcols);
+                int iy = a.mode == 0 ? y * a.stride + r - pad : y;
+                int ix = a.mode == 0 ? x0 * a.stride + j - pad : x0 + j;
+                bool ok = true;
+                if (a.reflect) {
+                    iy = iy < 0 ? -iy : (iy >= a.Ha ? 2 * a.Ha - 2 - iy : iy);
+                    ix = ix < 0 ? -ix : (ix >= a.Wa ? 2 * a.Wa - 2 - ix : ix);
+                } else ok = iy >= 0 && iy < a.Ha && ix >= 0 && ix < a.Wa;
+                float v = 0.f;
+                if (ok) {
+                    const long pix = ((long)b * a.Ha + iy) * a.Wa + ix;
+                    if (ch < a.ca0) {
+                        v = a.a0[pix * a.ca0 + ch];
+                        if (a.a_scale) v = fmaxf(fmaf(v, a.a_scale[ch], a.a_shift[ch]), 0.f);
+                    } else v = a.a1[pix * a.ca1 + ch - a.ca0];
+                }
+                al[(r * a_w + j) * ca + ch] = v;
             }
-            if (!ok) continue;
-            float av = 1.f;
-            if (a.mode != 2) {
-                av = arow[(long)ax * acs];
-                if (xform) av = fmaxf(fmaf(av, sc, sh), 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!live[k]) continue;
+            for (int x = slice; x < cols; x += nsl) {
+                const float av = a.mode == 2 ? 1.f : al[a_off[k] + x * as * ca];
+                const float4 gv = *reinterpret_cast<const float4*>(gl + g_off[k] + x * gs * a.cg);
+                acc[k][0] = fmaf(av, gv.x, acc[k][0]); acc[k][1] = fmaf(av, gv.y, acc[k][1]);
+                acc[k][2] = fmaf(av, gv.z, acc[k][2]); acc[k][3] = fmaf(av, gv.w, acc[k][3]);
             }
-            acc = fmaf(av, grow[(long)gx * a.cg], acc);
         }
     }
-    a.partials[((long)b * a.chunks + blockIdx.x) * a.E + e] = acc;
+    float* out = a.partials + ((long)b * a.nwg + blockIdx.x) * a.E;
+    if (nsl == 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e4 = blockIdx.y * WG_ENTRIES4 + k * 256 + t;
+            if (e4 < E4) *reinterpret_cast<float4*>(out + 4 * e4) = make_float4(acc[k][0], acc[k][1], acc[k][2], acc[k][3]);
+        }
+    } else {
+        __syncthreads();
+        if (!idle) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[slice * a.E + 4 * (t % E4) + i] = acc[0][i];
+        }
+        __syncthreads();
+        for (int e = t; e < a.E; e += 256) {
+            float s = 0.f;
+            for (int k = 0; k < nsl; ++k) s += red[k * a.E + e];
+            out[e] = s;
+        }
+    }
 }
 
 struct WgRedArgs { const float* partials; float* out; int B, chunks, E, per_image; };
 
+// 16 entries x 16 slices of the partial rows per workgroup; fixed summation order
 __global__ void __launch_bounds__(256) unet_wgrad_reduce_kernel(WgRedArgs a) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= a.E) return;
-    if (a.per_image) {
-        const int b = blockIdx.y;
-        double s = 0.0;
-        for (int k = 0; k < a.chunks; ++k) s += (double)a.partials[((long)b * a.chunks + k) * a.E + e];
-        a.out[(long)b * a.E + e] = (float)s;
-    } else {
-        double s = 0.0;
-        for (long k = 0; k < (long)a.B * a.chunks; ++k) s += (double)a.partials[k * a.E + e];
-        a.out[e] = (float)s;
+    const int le = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + le;
+    const long K = a.per_image ? a.chunks : (long)a.B * a.chunks;
+    const long base = a.per_image ? (long)blockIdx.y * a.chunks : 0;
+    __shared__ double red[16][16];
+    double s = 0.0;
+    if (e < a.E) {
+        const float* p = a.partials + base * a.E + e;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long k = sl;
+        for (; k + 48 < K; k += 64) {
+            s0 += p[k * a.E]; s1 += p[(k + 16) * a.E]; s2 += p[(k + 32) * a.E]; s3 += p[(k + 48) * a.E];
+        }
+        for (; k < K; k += 16) s0 += p[k * a.E];
+        s = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+    }
+    red[sl][le] = s;
+    __syncthreads();
+    if (sl == 0 && e < a.E) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][le];
+        a.out[(a.per_image ? (long)blockIdx.y * a.E : 0) + e] = (float)tot;
     }
 }
 
@@ -273,8 +346,16 @@ __global__ void __launch_bounds__(256) unet_s2_dgrad_kernel(S2Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------ anchor attention algebra
+// entry e of the packed products -> the pair of channels of z = (q | k | a): q_i a_j, then a_j k_i, then the squared norms
+__device__ __forceinline__ void gram_entry(int e, int c, int& A, int& Bc) {
+    const int ca = c >> 1, nqa = c * ca;
+    if (e < nqa) { A = e / ca; Bc = 2 * c + e % ca; }
+    else if (e < 2 * nqa) { const int f = e - nqa; A = 2 * c + f / c; Bc = c + f % c; }
+    else { A = Bc = e - 2 * nqa; }
+}
+
 struct MixBwdArgs {
-    const float* g; const float* dT; int c, heads;
+    const float* g; const float* dT; int c, heads;      // g: Gram matrix z^T z [B][zc][zc]
     const float* temp_a; const float* temp_v; const float* wv; const float* wp; float vscale;
     float* D;        // [B][zc][zc]: dz[n] = z[n] D (symmetric), zero outside the 2.5c live channels
     int zc;
@@ -288,7 +369,11 @@ __global__ void __launch_bounds__(256) unet_att_mix_bwd_kernel(MixBwdArgs a) {
     const int t = threadIdx.x;
     __shared__ float g[32 * 32 + 80], at_a[32 * 16], at_k[16 * 32], M[32 * 32], T1[32 * 32], dTs[32 * 32], dT1[32 * 32], dM[32 * 32];
     __shared__ float s_a[32 * 16], s_k[16 * 32], da[32 * 16], dk[16 * 32], dN[80], dtemp[2][32 + 16];
-    for (int e = t; e < E; e += 256) g[e] = a.g[(long)b * E + e];
+    for (int e = t; e < E; e += 256) {
+        int A, Bc;
+        gram_entry(e, c, A, Bc);
+        g[e] = a.g[((long)b * a.zc + A) * a.zc + Bc];
+    }
     for (int i = t; i < cc; i += 256) dTs[i] = a.dT[(long)b * cc + i];       // [ci][co]
     for (int i = t; i < 80; i += 256) dN[i] = 0.f;
     __syncthreads();
@@ -457,20 +542,32 @@ __global__ void __launch_bounds__(256) unet_att_mix_bwd_kernel(MixBwdArgs a) {
 
 }  // namespace
 
-#define KSR_WG_TARGET_PIX 1024
+struct WgPlan { int cols, segs, nwg, E; };
 
-static int wgrad_rows(int Hi, int Wi) {
-    int rows = KSR_WG_TARGET_PIX / (Wi > 0 ? Wi : 1);
-    if (rows < 1) rows = 1;
-    if (rows > Hi) rows = Hi;
-    return rows;
+static bool wgrad_plan(int mode, int ks, int stride, int ca, int cg, int B, int Ha, int Wa, int Hg, int Wg, WgPlan& p) {
+    const int Hi = mode == 1 ? Ha : Hg, Wi = mode == 1 ? Wa : Wg;
+    const int a_rows = mode == 0 ? ks : 1, g_rows = mode == 1 ? 2 : 1, gs = mode == 1 ? 2 : 1;
+    const int a_ch = mode == 2 ? 0 : ca;
+    const int fixed = mode == 0 ? a_rows * (ks - stride) * a_ch : 0;
+    const int per_col = a_rows * (mode == 0 ? stride : 1) * a_ch + g_rows * gs * cg;
+    int cols_max = (WG_TILE_FLOATS - 4 - fixed) / per_col;
+    if (cols_max < 1) return false;
+    if (cols_max > Wi) cols_max = Wi;
+    p.segs = (Wi + cols_max - 1) / cols_max;
+    p.cols = (Wi + p.segs - 1) / p.segs;
+    const int tiles = Hi * p.segs;
+    int per_image = 512 / B;
+    if (per_image < 1) per_image = 1;
+    p.nwg = tiles < per_image ? tiles : per_image;
+    p.E = (mode == 2 ? 1 : ks * ks * ca) * cg;
+    return true;
 }
 
 extern "C" int64_t ksr_unet_wgrad_slab_floats(int mode, int ks, int ca, int cg, int B, int Ha, int Wa, int Hg, int Wg) {
-    const int Hi = mode == 1 ? Ha : Hg, Wi = mode == 1 ? Wa : Wg;
-    const int rows = wgrad_rows(Hi, Wi), chunks = (Hi + rows - 1) / rows;
-    const int64_t E = (int64_t)(mode == 2 ? 1 : ks * ks * ca) * cg;
-    return (int64_t)B * chunks * E;
+    const int taps = mode == 0 ? ks * ks : (mode == 1 ? 4 : 1);
+    const int64_t E = (int64_t)taps * (mode == 2 ? 1 : ca) * cg;
+    const int per_image = 1024 / B > 0 ? 1024 / B : 1;      // upper bound of the workgroups per image
+    return (int64_t)B * per_image * E;
 }
 
 extern "C" int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1, const float* a_scale, const float* a_shift,
@@ -481,22 +578,25 @@ extern "C" int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1
     KSR_CHECK_ARG((a1 != nullptr) == (ca1 > 0), "unet_wgrad: a1 and ca1 disagree");
     KSR_UNSUPPORTED(mode < 0 || mode > 2, "unet_wgrad: mode %d", mode);
     KSR_UNSUPPORTED(mode == 0 && (ks < 1 || ks > 3 || (stride != 1 && stride != 2)), "unet_wgrad: kernel %d stride %d", ks, stride);
+    KSR_UNSUPPORTED(cg % 4 != 0, "unet_wgrad: cg = %d must be a multiple of 4", cg);
     KSR_UNSUPPORTED(B > 65535, "unet_wgrad: batch %d too large for one launch", B);
     if (mode == 1) { ks = 2; stride = 2; reflect = 0; KSR_CHECK_ARG(Hg == 2 * Ha && Wg == 2 * Wa, "unet_wgrad: transposed conv sizes"); }
     if (mode == 2) { ks = 1; stride = 1; reflect = 0; Ha = Hg; Wa = Wg; }
     if (mode == 0) {
         const int pad = ks == 3 ? 1 : 0;
         KSR_CHECK_ARG(Hg == (Ha + 2 * pad - ks) / stride + 1 && Wg == (Wa + 2 * pad - ks) / stride + 1, "unet_wgrad: conv sizes disagree");
+        KSR_UNSUPPORTED(reflect && (Ha < 2 || Wa < 2), "unet_wgrad: reflect padding needs at least 2 pixels per side");
     }
-    const int Hi = mode == 1 ? Ha : Hg, Wi = mode == 1 ? Wa : Wg;
-    const int rows = wgrad_rows(Hi, Wi), chunks = (Hi + rows - 1) / rows;
     const int ca = mode == 2 ? 1 : ca0 + ca1;
-    const int E = ks * ks * ca * cg;
-    WgArgs a{a0, a1, ca0, ca1, a_scale, a_shift, g, cg, slab, ks, stride, reflect, mode, Ha, Wa, Hg, Wg, rows, chunks, E};
-    hipLaunchKernelGGL(unet_wgrad_kernel, dim3((unsigned)chunks, (unsigned)((E + 255) / 256), (unsigned)B), dim3(256), 0, stream, a);
+    WgPlan p;
+    KSR_UNSUPPORTED(!wgrad_plan(mode, ks, stride, ca, cg, B, Ha, Wa, Hg, Wg, p), "unet_wgrad: %d + %d channels do not fit the LDS tile", ca, cg);
+    WgArgs a{a0, a1, ca0, ca1, a_scale, a_shift, g, cg, slab, ks, stride, reflect, mode, Ha, Wa, Hg, Wg, p.cols, p.segs, p.nwg, p.E};
+    const int E4 = p.E / 4;
+    hipLaunchKernelGGL(unet_wgrad_kernel, dim3((unsigned)p.nwg, (unsigned)((E4 + WG_ENTRIES4 - 1) / WG_ENTRIES4), (unsigned)B), dim3(256), 0,
+                       stream, a);
     KSR_LAUNCH_CHECK("unet_wgrad");
-    WgRedArgs r{slab, out, B, chunks, E, per_image};
-    hipLaunchKernelGGL(unet_wgrad_reduce_kernel, dim3((unsigned)((E + 255) / 256), (unsigned)(per_image ? B : 1)), dim3(256), 0, stream, r);
+    WgRedArgs r{slab, out, B, p.nwg, p.E, per_image};
+    hipLaunchKernelGGL(unet_wgrad_reduce_kernel, dim3((unsigned)((p.E + 15) / 16), (unsigned)(per_image ? B : 1)), dim3(256), 0, stream, r);
     KSR_LAUNCH_CHECK("unet_wgrad_reduce");
     return KSR_OK;
 }
@@ -547,14 +647,14 @@ extern "C" int ksr_unet_s2_dgrad(const float* dz, int cz, const float* weight, f
     return KSR_OK;
 }
 
-extern "C" int ksr_unet_att_mix_bwd(const float* g_saved, const float* dT, int c, int heads, int zc, int B, const float* temp_a,
+extern "C" int ksr_unet_att_mix_bwd(const float* gram, const float* dT, int c, int heads, int zc, int B, const float* temp_a,
                                     const float* temp_v, const float* wv, const float* wp, float vscale, float* D, float* dparams,
                                     hipStream_t stream) {
-    KSR_CHECK_ARG(g_saved && dT && temp_a && temp_v && wv && wp && D && dparams && B > 0, "unet_att_mix_bwd: bad argument");
+    KSR_CHECK_ARG(gram && dT && temp_a && temp_v && wv && wp && D && dparams && B > 0, "unet_att_mix_bwd: bad argument");
     KSR_UNSUPPORTED(c < 4 || c > 32 || (c & (c - 1)), "unet_att_mix_bwd: dim = %d (4, 8, 16 or 32)", c);
     KSR_UNSUPPORTED(heads < 1 || (c / 2) % heads != 0, "unet_att_mix_bwd: %d heads do not divide dim/2 = %d", heads, c / 2);
     KSR_CHECK_ARG(zc >= 2 * c + c / 2, "unet_att_mix_bwd: zc too small");
-    MixBwdArgs a{g_saved, dT, c, heads, temp_a, temp_v, wv, wp, vscale, D, zc, dparams};
+    MixBwdArgs a{gram, dT, c, heads, temp_a, temp_v, wv, wp, vscale, D, zc, dparams};
     hipLaunchKernelGGL(unet_att_mix_bwd_kernel, dim3((unsigned)B), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("unet_att_mix_bwd");
     return KSR_OK;

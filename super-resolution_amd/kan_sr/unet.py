@@ -232,17 +232,15 @@ class UNet(nn.Module):
         c = att.dim
         zc, wz, bz, wv, wp, ta, tv = self._att_weights(name)
         z, _ = self._conv(x, c, wz, zc, B, H, W, bias=bz, ks=3, stride=2, reflect=True)
-        n = z.shape[1] * z.shape[2]
-        slab = _new(x.device, int(L.ksr_unet_att_slab_floats(c_int(c), c_int(B), c_int64(n))))
+        Ho, Wo = z.shape[1], z.shape[2]
+        gram = self._wgrad(z, zc, B, Ho, Wo, a0=z, ca0=zc, Ha=Ho, Wa=Wo, ks=1, per_image=True)      # z^T z per image
         T = _new(x.device, B, c, c)
-        g_saved = _new(x.device, B, c * c + 5 * c // 2) if tape is not None else None
         # v is multiplied by the image width in the reference (unet_blocks.py:132,137-138: `w` is rebound to the width)
-        check(L.ksr_unet_att_mix(ptr(z), c_int(zc), c_int(c), c_int(att.num_heads), c_int64(n), c_int(B), ptr(ta), ptr(tv),
-                                 ptr(wv), ptr(wp), c_float(float(W)), ptr(slab), ptr(T), ptr(g_saved), stream()),
-              "ksr_unet_att_mix")
+        check(L.ksr_unet_att_mix(ptr(gram), c_int(zc), c_int(c), c_int(att.num_heads), c_int(B), ptr(ta), ptr(tv), ptr(wv),
+                                 ptr(wp), c_float(float(W)), ptr(T), stream()), "ksr_unet_att_mix")
         out, _ = self._conv(x, c, T, c, B, H, W, ks=1, w_image_stride=c * c)
         if tape is not None:
-            tape[name] = dict(x=x, z=z, T=T, g=g_saved, dims=(B, H, W))
+            tape[name] = dict(x=x, z=z, T=T, g=gram, dims=(B, H, W))
         return out
 
     def _attention_bwd(self, name, dout, grads):
