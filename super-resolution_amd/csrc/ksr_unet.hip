@@ -59,7 +59,7 @@ template <int CT>
 __global__ void __launch_bounds__(256) unet_conv_kernel(ConvArgs a) {
     const int b = blockIdx.y, cz = blockIdx.z * CT;
     const int npix = a.Hout * a.Wout;
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = p < npix;
     const int pc = live ? p : 0;
     const int oy = pc / a.Wout, ox = pc - oy * a.Wout;
@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(256) unet_conv_kernel(ConvArgs a) {
         __syncthreads();
         if (threadIdx.x < 2 * CT) {
             const int t = threadIdx.x;
-            const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+            const float v = blockDim.x == 64 ? red[0][t] : (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
             const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
             a.partials[(wg * 2 + t / CT) * a.cout + cz + t % CT] = v;
         }
@@ -314,18 +314,22 @@ __global__ void __launch_bounds__(256) unet_att_mix_kernel(MixArgs a) {
 }
 
 template <int CT>
-int launch_conv(const ConvArgs& a, int B, hipStream_t stream) {
+int launch_conv(const ConvArgs& a, int B, int block, hipStream_t stream) {
     const int npix = a.Hout * a.Wout;
-    hipLaunchKernelGGL(unet_conv_kernel<CT>, dim3((unsigned)((npix + 255) / 256), (unsigned)B, (unsigned)(a.cout / CT)), dim3(256), 0,
-                       stream, a);
+    hipLaunchKernelGGL(unet_conv_kernel<CT>, dim3((unsigned)((npix + block - 1) / block), (unsigned)B, (unsigned)(a.cout / CT)),
+                       dim3(block), 0, stream, a);
     KSR_LAUNCH_CHECK("unet_conv");
     return KSR_OK;
 }
 
 }  // namespace
 
+// Lanes per workgroup: small images get one-wave workgroups so that the deep, narrow levels still fill the chip.
+static int conv_block(int B, int npix) { return (long)B * npix <= 16384 ? 64 : 256; }
+
 extern "C" int64_t ksr_unet_conv_partials(int B, int Hout, int Wout) {
-    return (int64_t)B * ((Hout * Wout + 255) / 256);
+    const int block = conv_block(B, Hout * Wout);
+    return (int64_t)B * ((Hout * Wout + block - 1) / block);
 }
 
 extern "C" int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, int c1, const float* in_scale, const float* in_shift,
@@ -343,9 +347,13 @@ extern "C" int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, i
     const int pad = ks == 3 ? 1 : 0;
     ConvArgs a{src0, src1, c0, c1, in_scale, in_shift, weight, (long)w_image_stride, bias, out, cout, stat_partials, ks, stride, reflect,
                Hin, Win, (Hin + 2 * pad - ks) / stride + 1, (Win + 2 * pad - ks) / stride + 1};
-    if (cout % 16 == 0) return launch_conv<16>(a, B, stream);
-    if (cout % 8 == 0) return launch_conv<8>(a, B, stream);
-    return launch_conv<4>(a, B, stream);
+    // output channels per lane: as many as keep at least 512 workgroups in flight (the weights are uniform loads, the
+    // input is re-read from L1/L2 once per channel group)
+    const int npix = a.Hout * a.Wout, block = conv_block(B, npix);
+    const long wgs = (long)B * ((npix + block - 1) / block);
+    if (cout % 16 == 0 && wgs * (cout / 16) >= 512) return launch_conv<16>(a, B, block, stream);
+    if (cout % 8 == 0 && wgs * (cout / 8) >= 512) return launch_conv<8>(a, B, block, stream);
+    return launch_conv<4>(a, B, block, stream);
 }
 
 extern "C" int ksr_unet_bn_finalize(const float* stat_partials, int n_partials, int64_t count, const float* gamma, const float* beta,
