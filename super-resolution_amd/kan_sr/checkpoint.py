@@ -20,7 +20,7 @@ from typing import Dict, Optional
 import torch
 
 from ._lib import KsrError
-from .train import FLAT_ORDER, TrainStep, cosine_warm_restarts_lr
+from .train import TrainStep, cosine_warm_restarts_lr
 
 PREFIX = "model."
 
@@ -32,10 +32,10 @@ def _strip(key: str) -> str:
 def adam_state_dict(ts: TrainStep) -> dict:
     """The TrainStep's optimiser state in torch.optim.Adam.state_dict() form (parameters numbered in
     model.parameters() order; parameters outside the trained layer have no entry, as in torch)."""
-    flat_index = {ts.pre + n: i for i, n in enumerate(FLAT_ORDER)}
+    flat_index = {ts.pre + n: i for i, n in enumerate(ts.order)}
     offsets, off = {}, 0
     named = dict(ts.model.named_parameters())
-    for n in FLAT_ORDER:
+    for n in ts.order:
         k = named[ts.pre + n].numel()
         offsets[ts.pre + n] = (off, k)
         off += k
@@ -60,7 +60,7 @@ def load_adam_state(ts: TrainStep, opt_state: dict) -> None:
     named = dict(ts.model.named_parameters())
     off = 0
     steps = 0
-    for n in FLAT_ORDER:
+    for n in ts.order:
         full = ts.pre + n
         k = named[full].numel()
         st = opt_state["state"].get(names.index(full))

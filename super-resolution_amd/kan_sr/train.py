@@ -112,14 +112,26 @@ class TrainStep:
         layer = model.layers[li].encoder.encoder
         named = dict(layer.named_parameters())
         dev = next(model.parameters()).device
-        table, self.tail_end, total = flat_layout({n: named[n].shape for n in FLAT_ORDER})
+        # The GazeTR encoder has a hand-scheduled backward that writes into the flat gradient buffer in completion
+        # order.  Any other backbone (UNet) runs its backward through the autograd tape; its parameters are laid out in
+        # module order and their .grad tensors are views of the flat buffer, exchanged in one bucket.
+        self.tape_backward = getattr(model, "backbone", "gazetr") != "gazetr"
+        self.order = [n for n, _ in layer.named_parameters()] if self.tape_backward else FLAT_ORDER
+        if self.tape_backward:
+            table, off = {}, 0
+            for n in self.order:
+                table[n] = (off, named[n].numel())
+                off += named[n].numel()
+            self.tail_end = total = off
+        else:
+            table, self.tail_end, total = flat_layout({n: named[n].shape for n in FLAT_ORDER})
         self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
         self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
         self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
         self.p: Dict[str, torch.Tensor] = {}
         self.arena: Dict[str, torch.Tensor] = {}
-        for n in FLAT_ORDER:
+        for n in self.order:
             off, k = table[n]
             prm = named[n]
             view = self.flat_p[off:off + k].view(prm.shape)
@@ -127,6 +139,8 @@ class TrainStep:
             prm.data = view                       # the module's parameters now live in the flat buffer
             self.p[self.pre + n] = prm.data
             self.arena[self.pre + n] = self.flat_g[off:off + k].view(prm.shape)
+            if self.tape_backward:
+                prm.grad = self.arena[self.pre + n]   # autograd accumulates into the flat buffer in place
         self.steps = 0
         self.comm = comm
         if world_size > 1 and comm is None:
@@ -143,6 +157,8 @@ class TrainStep:
         m = self.model
         engine.set_precision(m.precision)
         x = x.contiguous()
+        if self.tape_backward:
+            return self._step_on_tape(x, tgt)
         g = engine.Geometry(x, m.upscale, m.grid_size, m.spline_order, m.grid_range)
         p_drop = m.layers[-1].encoder.encoder.encoder.layers[0].p_drop if m.training else 0.0
         seed = engine.new_seed() if p_drop > 0 else 0
@@ -184,10 +200,49 @@ class TrainStep:
         self.out = out
         return self.loss
 
-    def _add_ssim_term(self, out, tgt, gy, g, plane):
-        """loss += 0.15 (1 - SSIM(out, tgt)); gy += the luma gradient of that term."""
+    def _step_on_tape(self, x: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
+        """Same step with the backward driven by the autograd tape (backbones other than GazeTR): forward through the
+        module, loss kernels write dL/dY' into plane 0 of a [B,3,rH,rW] gradient (the chroma planes carry no gradient
+        to the parameters and are never read), tape backward into the flat buffer, one all-reduce, Adam."""
         L = lib()
-        B, Hh, Wh = g.B, g.H * g.r, g.W * g.r
+        m = self.model
+        with torch.enable_grad():
+            out = m(x)
+        B, _, Hh, Wh = out.shape
+        plane = Hh * Wh
+        if getattr(self, "_gfull", None) is None or self._gfull.shape != out.shape:
+            self._gfull = torch.empty_like(out)
+        gfull = self._gfull
+        outd = out.detach()
+        check(L.ksr_l1_y_loss(ptr(outd), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gfull),
+                              c_int64(3 * plane), c_int(B), c_int64(plane), c_float(1.0), ptr(self.slab), ptr(self._l1),
+                              stream()), "ksr_l1_y_loss")
+        self.loss = self._l1
+        if self.loss_kind == "l1+ssim":
+            self._add_ssim_term(outd, tgt, gfull, None, plane, dims=(B, Hh, Wh), gy_stride=3 * plane)
+        self.flat_g.zero_()
+        out.backward(gfull)
+        if self.side is not None:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            self.comm.allreduce_sum(self.flat_g, c_void_p(self.side.cuda_stream))
+            main.wait_stream(self.side)
+        self.steps += 1
+        check(L.ksr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                              c_int64(self.flat_p.numel()), c_float(self.lr), c_float(self.betas[0]),
+                              c_float(self.betas[1]), c_float(self.eps), c_float(self.wd), c_int(self.steps),
+                              c_float(1.0 / self.world_size), stream()), "ksr_adam_step")
+        encoder = m.layers[-1].encoder.encoder
+        if hasattr(encoder, "invalidate_prepared"):
+            encoder.invalidate_prepared()         # the weights changed under the cached kernel layouts
+        self.out = outd
+        return self.loss
+
+    def _add_ssim_term(self, out, tgt, gy, g, plane, dims=None, gy_stride=None):
+        """loss += 0.15 (1 - SSIM(out, tgt)); gy += the luma gradient of that term (gy rows gy_stride elements apart)."""
+        L = lib()
+        B, Hh, Wh = dims if dims is not None else (g.B, g.H * g.r, g.W * g.r)
+        gy_stride = plane if gy_stride is None else gy_stride
         C = 3
         nslab = int(L.ksr_ssim_slab_floats(c_int(C), c_int(B), c_int(Hh), c_int(Wh)))
         if getattr(self, "_ssim_ws", None) is None or self._ssim_ws[0].numel() < nslab or self._ssim_ws[1].numel() < 3 * B * (Hh - 10) * (Wh - 10):
@@ -198,7 +253,7 @@ class TrainStep:
                              c_int(Hh), c_int(Wh), ptr(maps), ptr(slab), ptr(val), stream()), "ksr_ssim_fwd")
         scale = -0.15 / (B * C * (Hh - 10) * (Wh - 10))
         check(L.ksr_ssim_y_grad(ptr(maps), ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
-                                c_int64(plane), c_int(B), c_int(Hh), c_int(Wh), c_float(scale), stream()), "ksr_ssim_y_grad")
+                                c_int64(gy_stride), c_int(B), c_int(Hh), c_int(Wh), c_float(scale), stream()), "ksr_ssim_y_grad")
         self.ssim = val
         self.loss = self._l1 + (1.0 - val) * 0.15           # one-element tensors
 

@@ -92,6 +92,12 @@ class UNet(nn.Module):
         self._prepared: dict = {}
 
     # ------------------------------------------------------------------ weight layouts (cached per parameter version)
+    def invalidate_prepared(self):
+        """Drops the cached kernel-layout copies of the weights.  Needed after the parameters were changed behind
+        torch's back (a kernel writing through their storage, as TrainStep's Adam does): torch-side updates
+        (optimizers, load_state_dict, copy_) bump the version counters the cache is keyed on and need no call."""
+        self._prepared.clear()
+
     def _prep(self, key, params, make):
         ver = tuple((t.data_ptr(), t._version) for t in params)
         hit = self._prepared.get(key)

@@ -218,6 +218,58 @@ def test_model_with_unet_backbone_trains():
     _check_grads({n: q.grad for n, q in m.named_parameters()}, {n: p[n].grad for n, _ in m.named_parameters()})
 
 
+@pytest.mark.parametrize("loss", ["l1", "l1+ssim"])
+def test_unet_train_step_vs_oracle_adam(loss):
+    """TrainStep on the UNet backbone (tape backward into the flat buffer, fused Adam): loss value, gradients of the
+    first step and the parameters after three steps against oracle + autograd + torch.optim.Adam on the CPU."""
+    from kan_sr.module import ConvSepKan
+    from kan_sr.train import TrainStep
+    torch.manual_seed(21)
+    m = ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2, backbone="unet").train()
+    p0 = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    pr = {n: (v.clone().requires_grad_() if v.is_floating_point() and "running" not in n else v.clone()) for n, v in p0.items()}
+    opt = torch.optim.Adam([v for v in pr.values() if v.requires_grad], lr=1e-3)
+    ts = TrainStep(m.cuda(), lr=1e-3, loss=loss)
+    assert ts.tape_backward and ts.flat_p.numel() == sum(q.numel() for q in m.parameters())
+    for it in range(3):
+        x, tgt = torch.rand(2, 3, 32, 48), torch.rand(2, 3, 64, 96)
+        opt.zero_grad()
+        stats = {}
+        y = orc.conv_sep_kan_forward(x, pr, out_channels=[4], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=2,
+                                     backbone="unet", train=True, stats=stats)
+        loss_ref = orc.training_loss(y, tgt) if loss == "l1+ssim" else (y[:, :1] - tgt[:, :1]).abs().mean()
+        loss_ref.backward()
+        got = ts.step(x.cuda(), tgt.cuda())
+        assert abs(float(got) - float(loss_ref.detach())) <= 1e-5 + 1e-4 * abs(float(loss_ref.detach()))
+        if it == 0:
+            _check_grads({n: ts.arena[n] for n, v in pr.items() if v.requires_grad}, {n: v.grad for n, v in pr.items() if v.requires_grad})
+        opt.step()
+        with torch.no_grad():
+            for k, v in stats.items():
+                pr[k] = v.detach().clone()
+    for n, prm in m.named_parameters():
+        want, have = pr[n].detach() - p0[n], prm.detach().cpu() - p0[n]
+        assert float((have - want).abs().max()) <= 2.1e-3, n          # at most ~2/3 of a 3-step swing of lr per step
+        assert rel_l2(prm.detach().cpu(), pr[n].detach()) <= 5e-3, n
+    for n, v in m.state_dict().items():
+        if "running" in n:
+            assert rel_l2(v.cpu(), pr[n]) <= 1e-4, n
+
+
+def test_unet_training_reduces_the_loss():
+    from kan_sr.module import ConvSepKan
+    from kan_sr.init import init_like_training_setup
+    from kan_sr.train import TrainStep
+    torch.manual_seed(2)
+    m = init_like_training_setup(ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4, backbone="unet")).cuda().train()
+    ts = TrainStep(m, lr=2e-3, loss="l1+ssim")
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, 128), torch.linspace(0, 1, 128), indexing="ij")
+    hr = torch.stack([0.5 + 0.4 * torch.sin(6 * xx + 3 * yy), 0.5 + 0.1 * xx, 0.5 - 0.1 * yy])[None].repeat(4, 1, 1, 1).cuda()
+    lr = torch.nn.functional.avg_pool2d(hr, 4)
+    losses = [float(ts.step(lr, hr)) for _ in range(60)]
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+
+
 def test_unet_refuses_bad_sizes():
     from kan_sr._lib import KsrError
     m = _unet(40)
