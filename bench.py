@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X-native ConvSepKAN hot path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload infer|train]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload infer|train|train-unet]
 
 One JSON line on stdout (rank 0).  Workloads (synthetic data, random-init weights, seeds fixed):
   train : (default) x4 SR training step (forward + L1(Y) + backward + RCCL gradient all-reduce when N>1 +
@@ -10,6 +10,8 @@ One JSON line on stdout (rank 0).  Workloads (synthetic data, random-init weight
           960x540 -> 3840x2160 frame rate, the second half of BASELINE.json's metric.
   infer : x4 SR inference, fp32, eval, one 960x540 YCbCr frame -> 3840x2160 per step and GPU
           (BASELINE config "x4 SR inference, 1xMI355X, fp32, 1080p->4K"); N>1 = N independent replicas.
+  train-unet : the same training step with the reference's UNet as the hyper-encoder (backbone="unet"), exact fp32,
+          8 patches of 256x256 per GPU.  Not the headline configuration: a side workload for that backbone.
 `value` = whole-job output megapixels per second with inputs resident in HBM.
 """
 import argparse
@@ -105,11 +107,23 @@ def measured_traffic(entry: str):
         return json.load(fh).get(ENTRY_KERNEL[entry])
 
 
-def build_model(upscale=4, G=5, k=3, seed=0):
+def unet_kernel_models(P: int):
+    """Algorithmic HBM bytes per LR pixel and training step of the two entry points that carry the UNet backbone
+    (every launch reads its inputs and writes its output once, fp32; level l of the pyramid has 4^-l pixels):
+    convolutions (forward, data gradients, per-image 1x1 applications) and weight gradients."""
+    dc = 52 + 28 + 14 + 7 + 3.5 + 10 + 20 + 40 + 80            # the nine DoubleConv blocks, forward
+    att_z, att_apply, att_dz = 50.75, 60.0, 41.5                # stride-2 projections, T application, D application
+    reproj = 4 * (4 + P)
+    conv = (dc + att_z + att_apply + reproj) + ((dc - 20 + 30) + 45 + att_apply + att_dz + reproj)
+    wgrad = dc + reproj + 4 * P + 45 + 30 + att_apply + att_z + 2 * 20.75
+    return {"ksr_unet_conv_fwd": ("hbm", 0, conv, PEAK_MFMA_F32_TFLOPS), "ksr_unet_wgrad": ("hbm", 0, wgrad, PEAK_MFMA_F32_TFLOPS)}
+
+
+def build_model(upscale=4, G=5, k=3, seed=0, backbone="gazetr"):
     from kan_sr.module import ConvSepKan
     from kan_sr.init import init_like_training_setup
     torch.manual_seed(seed)
-    m = ConvSepKan([1], [upscale * upscale], [3], G, k, 0.1, [-1, 1], upscale)
+    m = ConvSepKan([1], [upscale * upscale], [3], G, k, 0.1, [-1, 1], upscale, backbone=backbone)
     init_like_training_setup(m, seed)
     return m
 
@@ -122,7 +136,18 @@ def cpu_baseline(workload: str, seconds_budget: float = 12.0):
     torch.manual_seed(1234)
     p = orc.init_like_training_setup(orc.random_params(16, 5, 3, seed=0), seed=0)
     kw = dict(out_channels=[16], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=4)
-    if workload == "infer":
+    if workload == "train-unet":
+        from kan_sr.module import ConvSepKan
+        ref = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4, backbone="unet")
+        p = {n: (v.detach().clone().requires_grad_() if v.is_floating_point() and "running" not in n else v.clone())
+             for n, v in ref.state_dict().items()}
+        x = torch.rand(1, 3, 256, 256)
+        sample = "1 patch of 256x256 (1/8 of the per-GPU batch), UNet backbone, train-mode BatchNorm, fwd+bwd"
+
+        def step():
+            y = orc.conv_sep_kan_forward(x, p, backbone="unet", train=True, **kw)
+            y[:, :1].mean().backward()
+    elif workload == "infer":
         x = torch.rand(1, 3, 270, 480)
         sample = "one 270x480 LR tile (1/4 of the 960x540 frame), eval, no_grad"
 
@@ -156,7 +181,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train"])
+    ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train", "train-unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--loss", default=os.environ.get("KSR_BENCH_LOSS", "l1+ssim"), choices=["l1", "l1+ssim"],
                     help="training loss: the reference's training_step loss L1(Y) + 0.15 (1 - SSIM) (default) or L1(Y) only")
@@ -183,7 +208,10 @@ def main():
     from kan_sr import _lib, engine
     _lib.lib()   # fail loudly if the HIP library is missing
 
-    model = build_model().to(dev)
+    unet = args.workload == "train-unet"
+    if unet:
+        args.workload, args.precision = "train", "fp32"
+    model = build_model(backbone="unet" if unet else "gazetr").to(dev)
     torch.manual_seed(1234 + rank)
     if args.workload == "infer":
         B, H, W = 1, 540, 960
@@ -196,7 +224,7 @@ def main():
                 return model(x)
     else:
         from kan_sr.train import TrainStep
-        B, H, W = 64, 128, 128
+        B, H, W = (8, 256, 256) if unet else (64, 128, 128)
         model.train()
         model.precision = args.precision
         x = torch.rand(B, 3, H, W, device=dev)
@@ -206,6 +234,9 @@ def main():
                 "bf16s": "bf16 MFMA operands and activation storage / fp32 accumulate"}[args.precision]
         wl = (f"x4 SR training step, {mode} (fwd + loss {args.loss} + bwd + RCCL gradient all-reduce + Adam), 64 patches of 128x128 per "
               "GPU (BASELINE configs[2], per-rank batch), dropout live")
+        if unet:
+            wl = (f"x4 SR training step with the UNet hyper-encoder, exact fp32 (fwd + loss {args.loss} + bwd + RCCL gradient "
+                  "all-reduce + Adam), 8 patches of 256x256 per GPU, BatchNorm on per-rank batch statistics")
 
         def step():
             return ts.step(x, tgt)
@@ -258,6 +289,8 @@ def main():
         P = 16 * (5 + 3 + 2)
         bf16 = args.workload == "train" and args.precision != "fp32"
         models = kernel_models(B, P, bf16, 2 if (args.workload == "train" and args.precision == "bf16s") else 4)
+        if unet:
+            models.update(unet_kernel_models(P))
         kmodel = models.get(dom)
         npx = B * H * W
         roofline = {"kernel": dom, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
@@ -282,8 +315,8 @@ def main():
         roofline["ms_per_step_by_entry_point"] = {k: round(v, 4) for k, v in sorted(totals.items())}
         roofline["frac_by_entry_point"] = {k: [price(k)["bound"], price(k)["frac"]] for k in sorted(totals) if k in models}
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.workload)
-        if world == 1 and args.workload == "train":
+            cpu = cpu_baseline("train-unet" if unet else args.workload)
+        if world == 1 and args.workload == "train" and not unet:
             # second half of the headline metric: 1-GPU x4 inference of one 960x540 -> 3840x2160 frame
             model.eval()
             model.precision = "fp32"
