@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(256) unet_wgrad_reduce_kernel(WgRedArgs a) {
 // ------------------------------------------------------------------------------------------------ BatchNorm + ReLU
 struct BnRedArgs { const float* dout; const float* raw; const float* scale; const float* shift; float* partials; long npix; int C; };
 
-#define BN_PIX_PER_WG 2048
+#define BN_PIX_PER_WG 512
 
 // partial sums over pixels of dy and dy*raw with dy = dout * (raw*scale+shift > 0): [wg][2][C]
 __global__ void __launch_bounds__(256) unet_bn_bwd_reduce_kernel(BnRedArgs a) {

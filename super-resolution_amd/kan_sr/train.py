@@ -140,7 +140,10 @@ class TrainStep:
             self.p[self.pre + n] = prm.data
             self.arena[self.pre + n] = self.flat_g[off:off + k].view(prm.shape)
             if self.tape_backward:
-                prm.grad = self.arena[self.pre + n]   # autograd accumulates into the flat buffer in place
+                prm.grad = self.arena[self.pre + n]   # .grad is a view of the flat buffer
+        if self.tape_backward and hasattr(layer, "grad_sink"):
+            # the backbone's backward writes each parameter gradient straight into its view (no accumulation pass)
+            layer.grad_sink = {n: self.arena[self.pre + n] for n in self.order}
         self.steps = 0
         self.comm = comm
         if world_size > 1 and comm is None:
@@ -220,7 +223,8 @@ class TrainStep:
         self.loss = self._l1
         if self.loss_kind == "l1+ssim":
             self._add_ssim_term(outd, tgt, gfull, None, plane, dims=(B, Hh, Wh), gy_stride=3 * plane)
-        self.flat_g.zero_()
+        if getattr(m.layers[-1].encoder.encoder, "grad_sink", None) is None:
+            self.flat_g.zero_()                   # autograd accumulates into the views
         out.backward(gfull)
         if self.side is not None:
             main = torch.cuda.current_stream()

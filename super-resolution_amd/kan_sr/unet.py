@@ -90,6 +90,9 @@ class UNet(nn.Module):
         self.reproj = OutConv(4, out_channels)
         self.in_channels, self.out_channels = in_channels, out_channels
         self._prepared: dict = {}
+        # name -> preallocated gradient tensor: when set (TrainStep does), the backward writes every parameter gradient
+        # there and hands autograd no gradients, instead of returning fresh tensors for autograd to accumulate
+        self.grad_sink = None
 
     # ------------------------------------------------------------------ weight layouts (cached per parameter version)
     def invalidate_prepared(self):
@@ -176,14 +179,25 @@ class UNet(nn.Module):
                                          ptr(scale), ptr(shift), ptr(saved), c_int(C), stream()), "ksr_unet_bn_finalize")
         return scale, shift, saved
 
-    @staticmethod
-    def _bn_bwd(bn: nn.BatchNorm2d, dout, raw, aff, train, npix):
-        """-> (gradient of raw, dgamma, dbeta)."""
+    def _emit(self, grads, name, value):
+        """Hands one parameter gradient over: into the sink when there is one, else into the dict for autograd."""
+        if self.grad_sink is not None:
+            dst = self.grad_sink[name]
+            if dst.data_ptr() != value.data_ptr():
+                dst.copy_(value)
+        else:
+            grads[name] = value
+
+    def _bn_bwd(self, bn: nn.BatchNorm2d, dout, raw, aff, train, npix, names):
+        """-> gradient of raw; dgamma, dbeta go to names = (weight name, bias name)."""
         L = lib()
         C = bn.num_features
         dev = raw.device
         nparts = int(L.ksr_unet_bn_bwd_partials(c_int64(npix)))
-        partials, coef, dgamma, dbeta, dx = _new(dev, nparts, 2, C), _new(dev, 3, C), _new(dev, C), _new(dev, C), torch.empty_like(raw)
+        partials, coef, dx = _new(dev, nparts, 2, C), _new(dev, 3, C), torch.empty_like(raw)
+        sink = self.grad_sink
+        dgamma = sink[names[0]] if sink is not None else _new(dev, C)      # the kernel writes straight into the sink
+        dbeta = sink[names[1]] if sink is not None else _new(dev, C)
         check(L.ksr_unet_bn_relu_bwd(ptr(dout), ptr(raw), ptr(aff[0]), ptr(aff[1]), ptr(bn.weight.detach()), ptr(aff[2]),
                                      c_int(int(train)), ptr(partials), ptr(coef), ptr(dgamma), ptr(dbeta), ptr(dx),
                                      c_int64(npix), c_int(C), stream()), "ksr_unet_bn_relu_bwd")
@@ -214,15 +228,16 @@ class UNet(nn.Module):
         B, H, W = t["dims"]
         c, c0, c1, train = t["cout"], t["c0"], t["c1"], t["train"]
         npix = B * H * W
-        draw2, dg2, db2 = self._bn_bwd(seq[4], dout, t["raw2"], t["aff2"], train, npix)
+        n1, n2 = (key + ".double_conv.1.weight", key + ".double_conv.1.bias"), (key + ".double_conv.4.weight", key + ".double_conv.4.bias")
+        draw2, dg2, db2 = self._bn_bwd(seq[4], dout, t["raw2"], t["aff2"], train, npix, n2)
         dw2 = self._wgrad(draw2, c, B, H, W, a0=t["raw1"], ca0=c, affine=t["aff1"][:2], Ha=H, Wa=W)
         dmid, _ = self._conv(draw2, c, t["w2"].flip(0).transpose(1, 2).contiguous(), c, B, H, W)
-        draw1, dg1, db1 = self._bn_bwd(seq[1], dmid, t["raw1"], t["aff1"], train, npix)
+        draw1, dg1, db1 = self._bn_bwd(seq[1], dmid, t["raw1"], t["aff1"], train, npix, n1)
         dw1 = self._wgrad(draw1, c, B, H, W, a0=t["src0"], ca0=c0, a1=t["src1"], ca1=c1, Ha=H, Wa=W)
-        grads[key + ".double_conv.0.weight"] = dw1.view(9, c0 + c1, c).permute(2, 1, 0).reshape(c, c0 + c1, 3, 3)
-        grads[key + ".double_conv.1.weight"], grads[key + ".double_conv.1.bias"] = dg1, db1
-        grads[key + ".double_conv.3.weight"] = dw2.view(9, c, c).permute(2, 1, 0).reshape(c, c, 3, 3)
-        grads[key + ".double_conv.4.weight"], grads[key + ".double_conv.4.bias"] = dg2, db2
+        self._emit(grads, key + ".double_conv.0.weight", dw1.view(9, c0 + c1, c).permute(2, 1, 0).unflatten(2, (3, 3)))
+        self._emit(grads, n1[0], dg1), self._emit(grads, n1[1], db1)
+        self._emit(grads, key + ".double_conv.3.weight", dw2.view(9, c, c).permute(2, 1, 0).unflatten(2, (3, 3)))
+        self._emit(grads, n2[0], dg2), self._emit(grads, n2[1], db2)
         if not need_input_grad:
             return None, None
         wf = t["w1"].flip(0).transpose(1, 2)                      # [9][c][c0+c1]
@@ -275,15 +290,15 @@ class UNet(nn.Module):
         adw = att.a_proj[0].weight.detach().reshape(c, 9)                           # [ci][tap]
         a1 = att.a_proj[1].weight.detach().reshape(ca, c)                            # [co][ci]
         dwa = dwz[:, :, 2 * c:2 * c + ca]                                            # [tap][ci][co]
-        grads[name + ".q_proj.weight"] = torch.diagonal(dwz[:, :, 0:c], dim1=1, dim2=2).t().reshape(c, 1, 3, 3)
-        grads[name + ".k_proj.weight"] = dwz[:, :, c:2 * c].permute(2, 1, 0).reshape(c, c, 3, 3)
-        grads[name + ".a_proj.0.weight"] = (dwa * a1.t()[None]).sum(2).t().reshape(c, 1, 3, 3)
-        grads[name + ".a_proj.1.weight"] = (dwa * adw.t()[:, :, None]).sum(0).t().reshape(ca, c, 1, 1)
-        grads[name + ".a_proj.1.bias"] = dbz[2 * c:2 * c + ca]
-        grads[name + ".v_proj.weight"] = dsum[:c * c].reshape(c, c, 1, 1)
-        grads[name + ".project_out.weight"] = dsum[c * c:2 * c * c].reshape(c, c, 1, 1)
-        grads[name + ".temperature_a"] = dsum[2 * c * c:2 * c * c + heads].reshape(heads, 1, 1)
-        grads[name + ".temperature_v"] = dsum[2 * c * c + heads:].reshape(heads, 1, 1)
+        self._emit(grads, name + ".q_proj.weight", torch.diagonal(dwz[:, :, 0:c], dim1=1, dim2=2).t().reshape(c, 1, 3, 3))
+        self._emit(grads, name + ".k_proj.weight", dwz[:, :, c:2 * c].permute(2, 1, 0).unflatten(2, (3, 3)))
+        self._emit(grads, name + ".a_proj.0.weight", (dwa * a1.t()[None]).sum(2).t().reshape(c, 1, 3, 3))
+        self._emit(grads, name + ".a_proj.1.weight", (dwa * adw.t()[:, :, None]).sum(0).t().reshape(ca, c, 1, 1))
+        self._emit(grads, name + ".a_proj.1.bias", dbz[2 * c:2 * c + ca])
+        self._emit(grads, name + ".v_proj.weight", dsum[:c * c].reshape(c, c, 1, 1))
+        self._emit(grads, name + ".project_out.weight", dsum[c * c:2 * c * c].reshape(c, c, 1, 1))
+        self._emit(grads, name + ".temperature_a", dsum[2 * c * c:2 * c * c + heads].reshape(heads, 1, 1))
+        self._emit(grads, name + ".temperature_v", dsum[2 * c * c + heads:].reshape(heads, 1, 1))
         return dx_direct, dx_z
 
     def _up(self, i, y, cy, skip, B, h, w, train, tape=None):
@@ -307,8 +322,8 @@ class UNet(nn.Module):
         B, h, w = t["dims"]
         cy, cu = t["cy"], t["cy"] // 2
         dwt = self._wgrad(du, cu, B, 2 * h, 2 * w, a0=t["y"], ca0=cy, Ha=h, Wa=w, mode=1)          # [4][cy][cu]
-        grads[f"up{i}.up.weight"] = dwt.view(2, 2, cy, cu).permute(2, 3, 0, 1).contiguous()
-        grads[f"up{i}.up.bias"] = self._wgrad(du, cu, B, 2 * h, 2 * w, mode=2)
+        self._emit(grads, f"up{i}.up.weight", dwt.view(2, 2, cy, cu).permute(2, 3, 0, 1))
+        self._emit(grads, f"up{i}.up.bias", self._wgrad(du, cu, B, 2 * h, 2 * w, mode=2))
         dy, _ = self._conv(du, cu, t["wt"].transpose(1, 2).contiguous(), cy, B, 2 * h, 2 * w, ks=2, stride=2)
         return dskip, dy
 
@@ -346,8 +361,8 @@ class UNet(nn.Module):
         B, H, W = tape["reproj"]["dims"]
         P = self.out_channels
         y = tape["reproj"]["y"]
-        grads["reproj.conv.weight"] = self._wgrad(dw, P, B, H, W, a0=y, ca0=4, Ha=H, Wa=W, ks=1).view(4, P).t().reshape(P, 4, 1, 1)
-        grads["reproj.conv.bias"] = self._wgrad(dw, P, B, H, W, mode=2)
+        self._emit(grads, "reproj.conv.weight", self._wgrad(dw, P, B, H, W, a0=y, ca0=4, Ha=H, Wa=W, ks=1).view(4, P).t()[:, :, None, None])
+        self._emit(grads, "reproj.conv.bias", self._wgrad(dw, P, B, H, W, mode=2))
         dy, _ = self._conv(dw, P, self.reproj.conv.weight.detach().reshape(P, 4), 4, B, H, W, ks=1)
         att_grads = {}
         for i in range(4, 0, -1):
@@ -409,4 +424,6 @@ class _UNetFn(torch.autograd.Function):
     def backward(ctx, dw):
         grads = ctx.net._backward(ctx.tape, dw.contiguous())
         ctx.tape = None
+        if ctx.net.grad_sink is not None:
+            return (None,) * (3 + len(ctx.names))
         return (None, None, None) + tuple(grads[n].contiguous() for n in ctx.names)
