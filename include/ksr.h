@@ -364,9 +364,9 @@ int ksr_comm_destroy(void);
  * and src1 [B,Hin,Win,c1] (torch.cat of Up.forward :77; src1 NULL with c1 = 0); with in_scale/in_shift, src0 is read
  * as relu(x*scale[c]+shift[c]) (the BatchNorm + ReLU of the producing conv, :21-22).  weight [ks*ks][c0+c1][cout]
  * (tap-major, cout innermost); w_image_stride != 0 selects per-image weights.  ks 1 or 3 (padding ks/2, zero or
- * reflect), stride 1 or 2, cout % 4 == 0.  stat_partials (or NULL): ksr_unet_conv_partials(B,Hout,Wout) rows of
+ * reflect), stride 1 or 2, cout % 4 == 0.  stat_partials (or NULL): ksr_unet_conv_partials(B,Hout,Wout,c0+c1,cout) rows of
  * [2][cout] floats, the per-workgroup sum and sum of squares of the output for BatchNorm's batch statistics. */
-int64_t ksr_unet_conv_partials(int B, int Hout, int Wout);
+int64_t ksr_unet_conv_partials(int B, int Hout, int Wout, int cin, int cout);
 int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, int c1, const float* in_scale,
                       const float* in_shift, const float* weight, int64_t w_image_stride, const float* bias,
                       float* out, int cout, float* stat_partials, int ks, int stride, int reflect, int B, int Hin,

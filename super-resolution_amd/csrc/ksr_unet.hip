@@ -30,7 +30,27 @@ template <int CT>
 __device__ __forceinline__ void conv_taps(const float* __restrict__ src, int cs, long pix, bool ok, const float* __restrict__ sc,
                                           const float* __restrict__ sh, const float* __restrict__ wt, int cout, float (&acc)[CT]) {
     if ((cs & 3) == 0) {
-        for (int ci = 0; ci < cs; ci += 4) {
+        int ci = 0;
+        // 16 channels at a time: the four loads are issued together, then their 16 x CT products
+        for (; ci + 16 <= cs; ci += 16) {
+            float4 q[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) q[j] = *reinterpret_cast<const float4*>(src + pix * cs + ci + 4 * j);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v[4] = {q[j].x, q[j].y, q[j].z, q[j].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = ci + 4 * j + e;
+                    if (sc) v[e] = fmaxf(fmaf(v[e], sc[c], sh[c]), 0.f);
+                    v[e] = ok ? v[e] : 0.f;
+                    const float* w = wt + (long)c * cout;
+#pragma unroll
+                    for (int co = 0; co < CT; ++co) acc[co] = fmaf(v[e], w[co], acc[co]);
+                }
+            }
+        }
+        for (; ci < cs; ci += 4) {
             const float4 v4 = *reinterpret_cast<const float4*>(src + pix * cs + ci);
             float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
@@ -105,6 +125,97 @@ __global__ void __launch_bounds__(256) unet_conv_kernel(ConvArgs a) {
             const float v = blockDim.x == 64 ? red[0][t] : (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
             const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
             a.partials[(wg * 2 + t / CT) * a.cout + cz + t % CT] = v;
+        }
+    }
+}
+
+// Small images with many channels (the deep levels: 32x32 ... 1x1 pixels, 16..128 input channels): one pixel per lane
+// would leave a few thousand lanes with serial dot products of up to 1152 terms whose weights (each used once per wave)
+// miss the scalar cache one by one.  Here LPP lanes share a pixel and split its input channels, the weights of one
+// kernel row are staged in LDS ([kx][e][co4][g][4] for channel 4g+e: the lanes of a pixel read consecutive 16-byte
+// words), and the partial sums meet in a butterfly.  16 output channels per lane group; grid (ceil(npix/PPW), B, cout/16).
+template <int LPP>
+__global__ void __launch_bounds__(256) unet_conv_ksplit_kernel(ConvArgs a) {
+    constexpr int CT = 16, PPW = 256 / LPP;
+    __shared__ __attribute__((aligned(16))) float wl[3 * 128 * CT];
+    __shared__ float sred[PPW][CT];
+    const int b = blockIdx.y, cz = blockIdx.z * CT;
+    const int npix = a.Hout * a.Wout;
+    const int l = threadIdx.x % LPP, pslot = threadIdx.x / LPP;
+    const int p = blockIdx.x * PPW + pslot;
+    const bool live = p < npix;
+    const int pc = live ? p : 0;
+    const int oy = pc / a.Wout, ox = pc - oy * a.Wout;
+    const int cin = a.c0 + a.c1, G = cin >> 2;
+    const int pad = a.ks == 3 ? 1 : 0;
+    float acc[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) acc[i] = 0.f;
+    for (int ky = 0; ky < a.ks; ++ky) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.ks * cin * 4; i += 256) {
+            const int co4 = i & 3, r = i >> 2, kx = r / cin, c = r - kx * cin;
+            const float4 w4 = *reinterpret_cast<const float4*>(a.weight + ((long)(ky * a.ks) * cin + r) * a.cout + cz + co4 * 4);
+            *reinterpret_cast<float4*>(wl + ((((kx * 4 + (c & 3)) * 4 + co4) * G + (c >> 2)) << 2)) = w4;
+        }
+        __syncthreads();
+        int iy = oy * a.stride + ky - pad;
+        bool oky = true;
+        if (a.reflect) iy = iy < 0 ? -iy : (iy >= a.Hin ? 2 * a.Hin - 2 - iy : iy);
+        else oky = iy >= 0 && iy < a.Hin;
+        for (int kx = 0; kx < a.ks; ++kx) {
+            int ix = ox * a.stride + kx - pad;
+            bool ok = oky;
+            if (a.reflect) ix = ix < 0 ? -ix : (ix >= a.Win ? 2 * a.Win - 2 - ix : ix);
+            else ok = ok && ix >= 0 && ix < a.Win;
+            const long pix = ((long)b * a.Hin + (ok ? iy : 0)) * a.Win + (ok ? ix : 0);
+            for (int c = 4 * l; c < cin; c += 4 * LPP) {
+                const bool second = c >= a.c0;
+                const float* src = second ? a.src1 + pix * a.c1 + (c - a.c0) : a.src0 + pix * a.c0 + c;
+                const float4 v4 = *reinterpret_cast<const float4*>(src);
+                float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                if (a.in_scale && !second) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + c), t4 = *reinterpret_cast<const float4*>(a.in_shift + c);
+                    v[0] = fmaxf(fmaf(v[0], s4.x, t4.x), 0.f); v[1] = fmaxf(fmaf(v[1], s4.y, t4.y), 0.f);
+                    v[2] = fmaxf(fmaf(v[2], s4.z, t4.z), 0.f); v[3] = fmaxf(fmaf(v[3], s4.w, t4.w), 0.f);
+                }
+                const int g = c >> 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ve = ok ? v[e] : 0.f;
+#pragma unroll
+                    for (int co4 = 0; co4 < 4; ++co4) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(wl + ((((kx * 4 + e) * 4 + co4) * G + g) << 2));
+                        acc[4 * co4 + 0] = fmaf(ve, w4.x, acc[4 * co4 + 0]); acc[4 * co4 + 1] = fmaf(ve, w4.y, acc[4 * co4 + 1]);
+                        acc[4 * co4 + 2] = fmaf(ve, w4.z, acc[4 * co4 + 2]); acc[4 * co4 + 3] = fmaf(ve, w4.w, acc[4 * co4 + 3]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CT; ++i) {
+#pragma unroll
+        for (int m = LPP >> 1; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m, 64);
+        if (a.bias) acc[i] += a.bias[cz + i];
+    }
+    if (live && l == 0) {
+        float* o = a.out + ((long)b * npix + p) * a.cout + cz;
+#pragma unroll
+        for (int i = 0; i < CT; i += 4) *reinterpret_cast<float4*>(o + i) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
+    }
+    if (a.partials) {
+        if (l == 0) {
+#pragma unroll
+            for (int i = 0; i < CT; ++i) sred[pslot][i] = live ? acc[i] : 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * CT) {
+            const int k = threadIdx.x / CT, c = threadIdx.x % CT;
+            float s = 0.f;
+            for (int q = 0; q < PPW; ++q) { const float v = sred[q][c]; s += k ? v * v : v; }
+            const long wg = (long)blockIdx.y * gridDim.x + blockIdx.x;
+            a.partials[(wg * 2 + k) * a.cout + cz + c] = s;
         }
     }
 }
@@ -327,9 +438,19 @@ int launch_conv(const ConvArgs& a, int B, int block, hipStream_t stream) {
 // Lanes per workgroup: small images get one-wave workgroups so that the deep, narrow levels still fill the chip.
 static int conv_block(int B, int npix) { return (long)B * npix <= 16384 ? 64 : 256; }
 
-extern "C" int64_t ksr_unet_conv_partials(int B, int Hout, int Wout) {
-    const int block = conv_block(B, Hout * Wout);
-    return (int64_t)B * ((Hout * Wout + block - 1) / block);
+// Lanes per pixel of the channel-split kernel, or 0 when the pixel-per-lane kernel is the one to use.
+static int conv_ksplit_lanes(int B, int npix, int c0, int c1, int cout, int64_t w_image_stride) {
+    const int cin = c0 + c1;
+    if (w_image_stride != 0 || cout % 16 != 0 || (long)B * npix > 16384 || (c0 & 3) || (c1 & 3)) return 0;
+    if (cin != 16 && cin != 32 && cin != 64 && cin != 128) return 0;
+    return cin == 16 ? 4 : (cin == 32 ? 8 : 16);
+}
+
+extern "C" int64_t ksr_unet_conv_partials(int B, int Hout, int Wout, int cin, int cout) {
+    const int npix = Hout * Wout;
+    const int lpp = conv_ksplit_lanes(B, npix, cin, 0, cout, 0);
+    const int per_wg = lpp ? 256 / lpp : conv_block(B, npix);
+    return (int64_t)B * ((npix + per_wg - 1) / per_wg);
 }
 
 extern "C" int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, int c1, const float* in_scale, const float* in_shift,
@@ -347,6 +468,15 @@ extern "C" int ksr_unet_conv_fwd(const float* src0, int c0, const float* src1, i
     const int pad = ks == 3 ? 1 : 0;
     ConvArgs a{src0, src1, c0, c1, in_scale, in_shift, weight, (long)w_image_stride, bias, out, cout, stat_partials, ks, stride, reflect,
                Hin, Win, (Hin + 2 * pad - ks) / stride + 1, (Win + 2 * pad - ks) / stride + 1};
+    if (const int lpp = conv_ksplit_lanes(B, a.Hout * a.Wout, c0, c1, cout, w_image_stride)) {
+        const int ppw = 256 / lpp;
+        const dim3 grid((unsigned)((a.Hout * a.Wout + ppw - 1) / ppw), (unsigned)B, (unsigned)(cout / 16));
+        if (lpp == 4) hipLaunchKernelGGL(unet_conv_ksplit_kernel<4>, grid, dim3(256), 0, stream, a);
+        else if (lpp == 8) hipLaunchKernelGGL(unet_conv_ksplit_kernel<8>, grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(unet_conv_ksplit_kernel<16>, grid, dim3(256), 0, stream, a);
+        KSR_LAUNCH_CHECK("unet_conv_ksplit");
+        return KSR_OK;
+    }
     // output channels per lane: as many as keep at least 512 workgroups in flight (the weights are uniform loads, the
     // input is re-read from L1/L2 once per channel group)
     const int npix = a.Hout * a.Wout, block = conv_block(B, npix);

@@ -139,7 +139,7 @@ class UNet(nn.Module):
         pad = 1 if ks == 3 else 0
         Ho, Wo = (H + 2 * pad - ks) // stride + 1, (W + 2 * pad - ks) // stride + 1
         out = _new(src0.device, B, Ho, Wo, cout)
-        nparts = int(L.ksr_unet_conv_partials(c_int(B), c_int(Ho), c_int(Wo)))
+        nparts = int(L.ksr_unet_conv_partials(c_int(B), c_int(Ho), c_int(Wo), c_int(c0 + c1), c_int(cout)))
         partials = _new(src0.device, nparts, 2, cout) if stats else None
         sc, sh = affine if affine is not None else (None, None)
         check(L.ksr_unet_conv_fwd(ptr(src0), c_int(c0), ptr(src1), c_int(c1), ptr(sc), ptr(sh), ptr(weight),
