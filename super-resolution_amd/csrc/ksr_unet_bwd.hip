@@ -74,6 +74,37 @@ __global__ void __launch_bounds__(256) unet_wgrad_kernel(WgArgs a) {
         // ---- activation rows, padding and the producer's BatchNorm + ReLU materialised
         if (a.mode != 2) {
             const int wcols = a.mode == 0 ? (cols - 1) * a.stride + a.ks : cols;
+            if (((a.ca0 | a.ca1) & 3) == 0) {                 // 4 channels per load
+                const int ca4 = ca >> 2;
+                const bool pow2 = (ca4 & (ca4 - 1)) == 0;
+                const int sh = 31 - __builtin_clz(ca4);
+                for (int r = 0; r < a_rows; ++r) {
+                    int iy = a.mode == 0 ? y * a.stride + r - pad : y;
+                    bool oky = true;
+                    if (a.reflect) iy = iy < 0 ? -iy : (iy >= a.Ha ? 2 * a.Ha - 2 - iy : iy);
+                    else oky = iy >= 0 && iy < a.Ha;
+                    for (int i = t; i < wcols * ca4; i += 256) {
+                        const int j = pow2 ? i >> sh : i / ca4, ch = (i - j * ca4) << 2;
+                        int ix = a.mode == 0 ? x0 * a.stride + j - pad : x0 + j;
+                        bool ok = oky;
+                        if (a.reflect) ix = ix < 0 ? -ix : (ix >= a.Wa ? 2 * a.Wa - 2 - ix : ix);
+                        else ok = ok && ix >= 0 && ix < a.Wa;
+                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (ok) {
+                            const long pix = ((long)b * a.Ha + iy) * a.Wa + ix;
+                            if (ch < a.ca0) {
+                                v = *reinterpret_cast<const float4*>(a.a0 + pix * a.ca0 + ch);
+                                if (a.a_scale) {
+                                    const float4 s4 = *reinterpret_cast<const float4*>(a.a_scale + ch), t4 = *reinterpret_cast<const float4*>(a.a_shift + ch);
+                                    v = make_float4(fmaxf(fmaf(v.x, s4.x, t4.x), 0.f), fmaxf(fmaf(v.y, s4.y, t4.y), 0.f),
+                                                    fmaxf(fmaf(v.z, s4.z, t4.z), 0.f), fmaxf(fmaf(v.w, s4.w, t4.w), 0.f));
+                                }
+                            } else v = *reinterpret_cast<const float4*>(a.a1 + pix * a.ca1 + ch - a.ca0);
+                        }
+                        *reinterpret_cast<float4*>(al + (r * a_w + j) * ca + ch) = v;
+                    }
+                }
+            } else
             for (int i = t; i < a_rows * wcols * ca; i += 256) {
                 const int ch = i % ca, j = (i / ca) % wcols, r = i / (ca * wcols);
                 int iy = a.mode == 0 ? y * a.stride + r - pad : y;
