@@ -409,11 +409,13 @@ int ksr_unet_att_mix(const float* gram, int zc, int c, int heads, int B, const f
  * mode 1: ConvTranspose2d 2x2: out[dy*2+dx][ci][co] = sum a[b,y,x][ci] g[b,2y+dy,2x+dx][co];
  * mode 2: out[co] = sum g[b,p][co] (bias gradients).
  * a [B,Ha,Wa,ca0(+ca1)], g [B,Hg,Wg,cg]; slab: ksr_unet_wgrad_slab_floats(...) floats; per_image: out gets a
- * leading [B] axis (the per-image matrices of the attention backward). */
+ * leading [B] axis (the per-image matrices of the attention backward).  add_ones (modes 0, 1): a channel of ones is
+ * appended to a, i.e. out is [tap][ca+1][cg] and row ca of every tap holds sum g (the bias gradient of that tap's
+ * pixels) - pass ca+1 as `ca` to ksr_unet_wgrad_slab_floats. */
 int64_t ksr_unet_wgrad_slab_floats(int mode, int ks, int ca, int cg, int B, int Ha, int Wa, int Hg, int Wg);
 int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1, const float* a_scale, const float* a_shift,
-                   const float* g, int cg, float* slab, float* out, int per_image, int mode, int ks, int stride,
-                   int reflect, int B, int Ha, int Wa, int Hg, int Wg, ksr_stream_t stream);
+                   const float* g, int cg, float* slab, float* out, int per_image, int add_ones, int mode, int ks,
+                   int stride, int reflect, int B, int Ha, int Wa, int Hg, int Wg, ksr_stream_t stream);
 
 /* Backward of relu(BatchNorm2d(raw)) (unet_blocks.py:21-22,27-28): dout = gradient of the activated output;
  * writes dgamma, dbeta [C] and dx = gradient of raw.  train != 0 differentiates through the batch statistics.

@@ -20,6 +20,7 @@ struct WgArgs {
     int ks, stride, reflect, mode;                    // mode 0: conv (rows of g), 1: transposed conv 2x2 (rows of A), 2: column sums of g
     int Ha, Wa, Hg, Wg;
     int cols, segs, nwg, E;                           // tile = one row segment of `cols` pixels; nwg workgroups per image
+    int ones;                                         // 1: a virtual activation channel of ones is appended (bias gradient)
 };
 
 // grid (nwg, ceil(E/4 / WG_ENTRIES4), B).  A workgroup walks over row segments of one image; each is staged in LDS
@@ -45,17 +46,19 @@ __global__ void __launch_bounds__(256) unet_wgrad_kernel(WgArgs a) {
     const int nsl = E4 >= 256 ? 1 : 256 / E4;
     const int slice = nsl == 1 ? 0 : t / E4;
     const bool idle = nsl > 1 && slice >= nsl;
+    const int cae = ca + a.ones;                      // entries per tap on the activation side
     int a_off[4], g_off[4];
-    bool live[4];
+    bool live[4], one[4];
     float acc[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int e4 = nsl == 1 ? blockIdx.y * WG_ENTRIES4 + k * 256 + t : (k == 0 ? t % E4 : E4);
         live[k] = e4 < E4 && !idle;
         const int ec = live[k] ? e4 : 0;
-        const int co4 = ec % cg4, ci = (ec / cg4) % ca, tap = ec / (cg4 * ca);
+        const int co4 = ec % cg4, ci = (ec / cg4) % cae, tap = ec / (cg4 * cae);
         const int ky = tap / a.ks, kx = tap % a.ks;
-        a_off[k] = a.mode == 0 ? (ky * a_w + kx) * ca + ci : ci;
+        one[k] = a.mode == 2 || ci == ca;
+        a_off[k] = one[k] ? 0 : (a.mode == 0 ? (ky * a_w + kx) * ca + ci : ci);
         g_off[k] = (a.mode == 1 ? (ky * g_w + kx) * a.cg : 0) + co4 * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[k][i] = 0.f;
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256) unet_wgrad_kernel(WgArgs a) {
         for (int k = 0; k < 4; ++k) {
             if (!live[k]) continue;
             for (int x = slice; x < cols; x += nsl) {
-                const float av = a.mode == 2 ? 1.f : al[a_off[k] + x * as * ca];
+                const float av = one[k] ? 1.f : al[a_off[k] + x * as * ca];
                 const float4 gv = *reinterpret_cast<const float4*>(gl + g_off[k] + x * gs * a.cg);
                 acc[k][0] = fmaf(av, gv.x, acc[k][0]); acc[k][1] = fmaf(av, gv.y, acc[k][1]);
                 acc[k][2] = fmaf(av, gv.z, acc[k][2]); acc[k][3] = fmaf(av, gv.w, acc[k][3]);
@@ -602,8 +605,8 @@ extern "C" int64_t ksr_unet_wgrad_slab_floats(int mode, int ks, int ca, int cg, 
 }
 
 extern "C" int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1, const float* a_scale, const float* a_shift,
-                              const float* g, int cg, float* slab, float* out, int per_image, int mode, int ks, int stride, int reflect,
-                              int B, int Ha, int Wa, int Hg, int Wg, hipStream_t stream) {
+                              const float* g, int cg, float* slab, float* out, int per_image, int add_ones, int mode, int ks, int stride,
+                              int reflect, int B, int Ha, int Wa, int Hg, int Wg, hipStream_t stream) {
     KSR_CHECK_ARG(g && slab && out && B > 0 && cg > 0 && Hg > 0 && Wg > 0, "unet_wgrad: bad argument");
     KSR_CHECK_ARG(mode == 2 || (a0 && ca0 > 0 && Ha > 0 && Wa > 0), "unet_wgrad: activations missing");
     KSR_CHECK_ARG((a1 != nullptr) == (ca1 > 0), "unet_wgrad: a1 and ca1 disagree");
@@ -619,9 +622,11 @@ extern "C" int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1
         KSR_UNSUPPORTED(reflect && (Ha < 2 || Wa < 2), "unet_wgrad: reflect padding needs at least 2 pixels per side");
     }
     const int ca = mode == 2 ? 1 : ca0 + ca1;
+    add_ones = (add_ones && mode != 2) ? 1 : 0;
     WgPlan p;
     KSR_UNSUPPORTED(!wgrad_plan(mode, ks, stride, ca, cg, B, Ha, Wa, Hg, Wg, p), "unet_wgrad: %d + %d channels do not fit the LDS tile", ca, cg);
-    WgArgs a{a0, a1, ca0, ca1, a_scale, a_shift, g, cg, slab, ks, stride, reflect, mode, Ha, Wa, Hg, Wg, p.cols, p.segs, p.nwg, p.E};
+    p.E = (mode == 2 ? 1 : ks * ks * (ca + add_ones)) * cg;
+    WgArgs a{a0, a1, ca0, ca1, a_scale, a_shift, g, cg, slab, ks, stride, reflect, mode, Ha, Wa, Hg, Wg, p.cols, p.segs, p.nwg, p.E, add_ones};
     const int E4 = p.E / 4;
     hipLaunchKernelGGL(unet_wgrad_kernel, dim3((unsigned)p.nwg, (unsigned)((E4 + WG_ENTRIES4 - 1) / WG_ENTRIES4), (unsigned)B), dim3(256), 0,
                        stream, a);

@@ -150,10 +150,11 @@ class UNet(nn.Module):
 
     @staticmethod
     def _wgrad(g, cg, B, Hg, Wg, *, a0=None, ca0=0, a1=None, ca1=0, affine=None, Ha=0, Wa=0, mode=0, ks=3, stride=1,
-               reflect=False, per_image=False):
-        """Weight gradient in the kernels' layout [taps][ca][cg] (leading [B] with per_image); mode 2: column sums [cg]."""
+               reflect=False, per_image=False, ones=False):
+        """Weight gradient in the kernels' layout [taps][ca][cg] (leading [B] with per_image); mode 2: column sums [cg].
+        ones: [taps][ca+1][cg], the extra row of each tap being the sum of g over that tap's pixels."""
         L = lib()
-        ca = ca0 + ca1
+        ca = ca0 + ca1 + int(ones)
         taps = {0: ks * ks, 1: 4, 2: 1}[mode]
         E = taps * (1 if mode == 2 else ca) * cg
         nslab = int(L.ksr_unet_wgrad_slab_floats(c_int(mode), c_int(ks), c_int(ca), c_int(cg), c_int(B), c_int(Ha), c_int(Wa),
@@ -162,7 +163,7 @@ class UNet(nn.Module):
         out = _new(g.device, *((B, E) if per_image else (E,)))
         sc, sh = affine if affine is not None else (None, None)
         check(L.ksr_unet_wgrad(ptr(a0), c_int(ca0), ptr(a1), c_int(ca1), ptr(sc), ptr(sh), ptr(g), c_int(cg), ptr(slab),
-                               ptr(out), c_int(int(per_image)), c_int(mode), c_int(ks), c_int(stride), c_int(int(reflect)),
+                               ptr(out), c_int(int(per_image)), c_int(int(ones)), c_int(mode), c_int(ks), c_int(stride), c_int(int(reflect)),
                                c_int(B), c_int(Ha), c_int(Wa), c_int(Hg), c_int(Wg), stream()), "ksr_unet_wgrad")
         return out
 
@@ -280,8 +281,8 @@ class UNet(nn.Module):
         check(L.ksr_unet_att_mix_bwd(ptr(t["g"]), ptr(dT), c_int(c), c_int(heads), c_int(zc), c_int(B), ptr(ta), ptr(tv),
                                      ptr(wv), ptr(wp), c_float(float(W)), ptr(D), ptr(dpar), stream()), "ksr_unet_att_mix_bwd")
         dz, _ = self._conv(z, zc, D, zc, B, Ho, Wo, ks=1, w_image_stride=zc * zc)
-        dwz = self._wgrad(dz, zc, B, Ho, Wo, a0=x, ca0=c, Ha=H, Wa=W, ks=3, stride=2, reflect=True).view(9, c, zc)
-        dbz = self._wgrad(dz, zc, B, Ho, Wo, mode=2)
+        dwzb = self._wgrad(dz, zc, B, Ho, Wo, a0=x, ca0=c, Ha=H, Wa=W, ks=3, stride=2, reflect=True, ones=True).view(9, c + 1, zc)
+        dwz, dbz = dwzb[:, :c], dwzb[0, c]                                           # any tap's row of ones sums all of dz
         dx_z = _new(x.device, B, H, W, c)
         check(L.ksr_unet_s2_dgrad(ptr(dz), c_int(zc), ptr(wz.transpose(1, 2).contiguous()), ptr(dx_z), c_int(c), c_int(B),
                                   c_int(H), c_int(W), stream()), "ksr_unet_s2_dgrad")
@@ -321,9 +322,9 @@ class UNet(nn.Module):
         t = self._tape[f"up{i}.up"]
         B, h, w = t["dims"]
         cy, cu = t["cy"], t["cy"] // 2
-        dwt = self._wgrad(du, cu, B, 2 * h, 2 * w, a0=t["y"], ca0=cy, Ha=h, Wa=w, mode=1)          # [4][cy][cu]
-        self._emit(grads, f"up{i}.up.weight", dwt.view(2, 2, cy, cu).permute(2, 3, 0, 1))
-        self._emit(grads, f"up{i}.up.bias", self._wgrad(du, cu, B, 2 * h, 2 * w, mode=2))
+        dwt = self._wgrad(du, cu, B, 2 * h, 2 * w, a0=t["y"], ca0=cy, Ha=h, Wa=w, mode=1, ones=True).view(4, cy + 1, cu)
+        self._emit(grads, f"up{i}.up.weight", dwt[:, :cy].unflatten(0, (2, 2)).permute(2, 3, 0, 1))
+        self._emit(grads, f"up{i}.up.bias", dwt[:, cy].sum(0))           # the four output positions of every input pixel
         dy, _ = self._conv(du, cu, t["wt"].transpose(1, 2).contiguous(), cy, B, 2 * h, 2 * w, ks=2, stride=2)
         return dskip, dy
 
@@ -361,8 +362,9 @@ class UNet(nn.Module):
         B, H, W = tape["reproj"]["dims"]
         P = self.out_channels
         y = tape["reproj"]["y"]
-        self._emit(grads, "reproj.conv.weight", self._wgrad(dw, P, B, H, W, a0=y, ca0=4, Ha=H, Wa=W, ks=1).view(4, P).t()[:, :, None, None])
-        self._emit(grads, "reproj.conv.bias", self._wgrad(dw, P, B, H, W, mode=2))
+        dwb = self._wgrad(dw, P, B, H, W, a0=y, ca0=4, Ha=H, Wa=W, ks=1, ones=True).view(5, P)       # weight rows | bias row
+        self._emit(grads, "reproj.conv.weight", dwb[:4].t()[:, :, None, None])
+        self._emit(grads, "reproj.conv.bias", dwb[4])
         dy, _ = self._conv(dw, P, self.reproj.conv.weight.detach().reshape(P, 4), 4, B, H, W, ks=1)
         att_grads = {}
         for i in range(4, 0, -1):
