@@ -151,14 +151,15 @@ class ConvSepKan(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = x.contiguous()
+        if self.backbone == "unet":
+            from .ops import kan_head
+            engine.set_precision(self.precision)
+            w = self.layers[-1].encoder.encoder.forward_nhwc(x[:, :1])
+            return kan_head(x, w, self.grid_size, self.spline_order, self.grid_range, self.upscale)
         g = engine.Geometry(x, self.upscale, self.grid_size, self.spline_order, self.grid_range)
         p = self._params()
         pre = f"layers.{len(self.layers) - 1}.encoder.encoder."
         engine.set_precision(self.precision)
-        if self.backbone == "unet":
-            from .ops import kan_head
-            w = self.layers[-1].encoder.encoder.forward_nhwc(x[:, :1])
-            return kan_head(x, w, self.grid_size, self.spline_order, self.grid_range, self.upscale)
         needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in p.values())
         p_drop = self.layers[-1].encoder.encoder.encoder.layers[0].p_drop if self.training else 0.0
         seed = engine.new_seed() if p_drop > 0 else 0

@@ -93,6 +93,14 @@ class UNet(nn.Module):
         # name -> preallocated gradient tensor: when set (TrainStep does), the backward writes every parameter gradient
         # there and hands autograd no gradients, instead of returning fresh tensors for autograd to accumulate
         self.grad_sink = None
+        self._counters = None          # the 18 num_batches_tracked buffers, listed once
+        self._named = None             # (names, parameters), listed once: the module tree is fixed
+
+    def _apply(self, fn, *args, **kwargs):
+        # .to() / .cuda() / .float() replace the buffer tensors: forget everything that was listed or derived from them
+        self._counters, self._named = None, None
+        self._prepared.clear()
+        return super()._apply(fn, *args, **kwargs)
 
     # ------------------------------------------------------------------ weight layouts (cached per parameter version)
     def invalidate_prepared(self):
@@ -352,7 +360,9 @@ class UNet(nn.Module):
         if tape is not None:
             tape["reproj"] = dict(y=y, dims=(B, H, W))
         if train:
-            torch._foreach_add_([m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)], 1)
+            if self._counters is None:
+                self._counters = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+            torch._foreach_add_(self._counters, 1)
         return out.view(B * H * W, self.out_channels)
 
     def _backward(self, tape, dw):
@@ -398,7 +408,9 @@ class UNet(nn.Module):
         if H % 16 or W % 16:
             raise KsrError(f"UNet needs H and W to be multiples of 16, got {H}x{W}")
         x = y_plane.contiguous()
-        names, params = zip(*self.named_parameters())
+        if self._named is None:
+            self._named = tuple(zip(*self.named_parameters()))
+        names, params = self._named
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
             return _UNetFn.apply(x, self, names, *params)
         with torch.no_grad():
