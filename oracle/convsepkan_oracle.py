@@ -441,7 +441,8 @@ UNET_HEADS = {"att1": 2, "att2": 2, "att3": 4, "att4": 4}                    # u
 
 
 def unet(x: torch.Tensor, p: Params, prefix: str = "", train: bool = False, stats: Optional[dict] = None) -> torch.Tensor:
-    """UNet(in, P).forward (unet.py:30-42): x [B,1,H,W] -> [B,P,H,W]; H, W multiples of 16."""
+    """UNet(in, P).forward (unet.py:30-42): x [B,1,H,W] -> [B,P,H,W]; H, W >= 16 (sizes that are not multiples of 16:
+    the pooling floors and the upsampled tensor is zero-padded to the skip's size)."""
     xs = [double_conv(x, p, prefix + "proj.double_conv.", train, stats)]
     for i in range(1, 5):
         xs.append(double_conv(F.max_pool2d(xs[-1], 2), p, prefix + f"down{i}.maxpool_conv.1.double_conv.", train, stats))
@@ -449,5 +450,7 @@ def unet(x: torch.Tensor, p: Params, prefix: str = "", train: bool = False, stat
     for i in range(1, 5):
         skip = anchor_attention(xs[4 - i], p, prefix + f"att{5 - i}.", UNET_HEADS[f"att{5 - i}"])
         up = F.conv_transpose2d(y, p[prefix + f"up{i}.up.weight"], p[prefix + f"up{i}.up.bias"], stride=2)
+        dy, dx = skip.shape[2] - up.shape[2], skip.shape[3] - up.shape[3]          # unet_blocks.py:68-73
+        up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
         y = double_conv(torch.cat([skip, up], dim=1), p, prefix + f"up{i}.conv.double_conv.", train, stats)
     return F.conv2d(y, p[prefix + "reproj.conv.weight"], p[prefix + "reproj.conv.bias"])

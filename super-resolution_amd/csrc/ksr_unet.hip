@@ -279,28 +279,30 @@ __global__ void __launch_bounds__(256) unet_bn_relu_kernel(ActArgs a) {
     reinterpret_cast<float4*>(a.out)[idx] = bn_relu4(reinterpret_cast<const float4*>(a.in)[idx], s, t);
 }
 
-// one 2x2 block of pixels and 4 channels per lane: activated tensor at full size plus its 2x2 maximum
+// one 2x2 block of pixels and 4 channels per lane: activated tensor at full size plus its 2x2 maximum.  Odd sizes: the
+// last row / column belongs to no pooling window (MaxPool2d floors) and only gets its activation written.
 __global__ void __launch_bounds__(256) unet_bn_relu_pool_kernel(ActArgs a) {
-    const int c4n = a.C >> 2, Hp = a.H >> 1, Wp = a.W >> 1;
+    const int c4n = a.C >> 2, Hb = (a.H + 1) >> 1, Wb = (a.W + 1) >> 1, Hp = a.H >> 1, Wp = a.W >> 1;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)a.B * Hp * Wp * c4n) return;
+    if (idx >= (long)a.B * Hb * Wb * c4n) return;
     const int c = (int)(idx % c4n) * 4;
     long r = idx / c4n;
-    const int px = (int)(r % Wp); r /= Wp;
-    const int py = (int)(r % Hp);
-    const int b = (int)(r / Hp);
+    const int px = (int)(r % Wb); r /= Wb;
+    const int py = (int)(r % Hb);
+    const int b = (int)(r / Hb);
     const float4 s = *reinterpret_cast<const float4*>(a.scale + c), t = *reinterpret_cast<const float4*>(a.shift + c);
     float4 m = make_float4(0.f, 0.f, 0.f, 0.f);      // activations are >= 0
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
+            if (2 * py + dy >= a.H || 2 * px + dx >= a.W) continue;
             const long o = (((long)b * a.H + 2 * py + dy) * a.W + 2 * px + dx) * a.C + c;
             const float4 v = bn_relu4(*reinterpret_cast<const float4*>(a.in + o), s, t);
             *reinterpret_cast<float4*>(a.out + o) = v;
             m = make_float4(fmaxf(m.x, v.x), fmaxf(m.y, v.y), fmaxf(m.z, v.z), fmaxf(m.w, v.w));
         }
-    *reinterpret_cast<float4*>(a.pooled + (((long)b * Hp + py) * Wp + px) * a.C + c) = m;
+    if (py < Hp && px < Wp) *reinterpret_cast<float4*>(a.pooled + (((long)b * Hp + py) * Wp + px) * a.C + c) = m;
 }
 
 struct ConvTArgs { const float* in; const float* weight; const float* bias; float* out; int cin, cout, h, w; };
@@ -501,10 +503,10 @@ extern "C" int ksr_unet_bn_relu_fwd(const float* raw, const float* scale, const 
                                     int W, int C, hipStream_t stream) {
     KSR_CHECK_ARG(raw && scale && shift && out && B > 0 && H > 0 && W > 0 && C > 0, "unet_bn_relu: bad argument");
     KSR_UNSUPPORTED(C % 4 != 0, "unet_bn_relu: C = %d must be a multiple of 4", C);
-    KSR_UNSUPPORTED(pooled && ((H & 1) || (W & 1)), "unet_bn_relu: 2x2 pooling needs even H and W");
+    KSR_UNSUPPORTED(pooled && (H < 2 || W < 2), "unet_bn_relu: 2x2 pooling needs at least 2x2 pixels");
     ActArgs a{raw, scale, shift, out, pooled, B, H, W, C};
     if (pooled) {
-        const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+        const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
         hipLaunchKernelGGL(unet_bn_relu_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     } else {
         const long total = (long)B * H * W * (C / 4);

@@ -286,24 +286,28 @@ struct MergeArgs { const float* g0; const float* g1; const float* gp; const floa
 // out = g0 + g1 + maxpool2x2 backward of gp (to the first maximum of each window, as torch routes it); one 2x2 block
 // of pixels and 4 channels per lane.  g1, gp optional.
 __global__ void __launch_bounds__(256) unet_grad_merge_kernel(MergeArgs a) {
-    const int c4n = a.C >> 2, Hp = a.H >> 1, Wp = a.W >> 1;
+    const int c4n = a.C >> 2, Hb = (a.H + 1) >> 1, Wb = (a.W + 1) >> 1, Hp = a.H >> 1, Wp = a.W >> 1;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)a.B * Hp * Wp * c4n) return;
+    if (idx >= (long)a.B * Hb * Wb * c4n) return;
     const int c = (int)(idx % c4n) * 4;
     long r = idx / c4n;
-    const int px = (int)(r % Wp); r /= Wp;
-    const int py = (int)(r % Hp);
-    const int b = (int)(r / Hp);
+    const int px = (int)(r % Wb); r /= Wb;
+    const int py = (int)(r % Hb);
+    const int b = (int)(r / Hb);
+    const bool window = py < Hp && px < Wp;          // odd sizes: the last row / column is in no pooling window
     long off[4];
+    bool in[4];
     float v[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        in[k] = 2 * py + (k >> 1) < a.H && 2 * px + (k & 1) < a.W;
         off[k] = (((long)b * a.H + 2 * py + (k >> 1)) * a.W + 2 * px + (k & 1)) * a.C + c;
-        const float4 t = *reinterpret_cast<const float4*>(a.act + off[k]);
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in[k]) t = *reinterpret_cast<const float4*>(a.act + off[k]);
         v[k][0] = t.x; v[k][1] = t.y; v[k][2] = t.z; v[k][3] = t.w;
     }
     float gpv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.gp) {
+    if (a.gp && window) {
         const float4 t = *reinterpret_cast<const float4*>(a.gp + (((long)b * Hp + py) * Wp + px) * a.C + c);
         gpv[0] = t.x; gpv[1] = t.y; gpv[2] = t.z; gpv[3] = t.w;
     }
@@ -318,6 +322,7 @@ __global__ void __launch_bounds__(256) unet_grad_merge_kernel(MergeArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+        if (!in[k]) continue;
         const float4 t0 = *reinterpret_cast<const float4*>(a.g0 + off[k]);
         float o[4] = {t0.x, t0.y, t0.z, t0.w};
         if (a.g1) {
@@ -662,9 +667,9 @@ extern "C" int ksr_unet_bn_relu_bwd(const float* dout, const float* raw, const f
 extern "C" int ksr_unet_grad_merge(const float* g0, const float* g1, const float* g_pooled, const float* act, float* out, int B, int H,
                                    int W, int C, hipStream_t stream) {
     KSR_CHECK_ARG(g0 && act && out && B > 0 && H > 0 && W > 0, "unet_grad_merge: bad argument");
-    KSR_UNSUPPORTED(C % 4 != 0 || (H & 1) || (W & 1), "unet_grad_merge: C %% 4 == 0 and even H, W needed (C=%d, %dx%d)", C, H, W);
+    KSR_UNSUPPORTED(C % 4 != 0, "unet_grad_merge: C = %d must be a multiple of 4", C);
     MergeArgs a{g0, g1, g_pooled, act, out, B, H, W, C};
-    const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+    const long total = (long)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
     hipLaunchKernelGGL(unet_grad_merge_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("unet_grad_merge");
     return KSR_OK;

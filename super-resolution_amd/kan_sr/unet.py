@@ -5,8 +5,8 @@ the luma plane [B,1,H,W] to the per-pixel KAN parameters [B,P,H,W].  The classes
 the reference's attribute names, so `state_dict()` carries the same keys (`proj.double_conv.0.weight`,
 `down1.maxpool_conv.1.double_conv.4.running_var`, `att3.a_proj.1.bias`, `up2.up.weight`, `reproj.conv.bias`, ...);
 forward and backward are sequences of libksr kernels over NHWC activations (the weight re-layouts and the chain rule
-through them are torch ops on the tiny weight tensors).  H and W must be multiples of 16 (the reference's F.pad branch for other sizes, unet_blocks.py:68-73,
-is not built).
+through them are torch ops on the tiny weight tensors).  Any H, W >= 16: for sizes that are not multiples of 16 the
+upsampled tensors are zero-padded to their skip's size as the reference does (unet_blocks.py:68-73).
 """
 from __future__ import annotations
 
@@ -318,9 +318,16 @@ class UNet(nn.Module):
         u = _new(y.device, B, 2 * h, 2 * w, cu)
         check(lib().ksr_unet_convt_fwd(ptr(y), ptr(wt), ptr(up.up.bias.detach()), ptr(u), c_int(cy), c_int(cu), c_int(B),
                                        c_int(h), c_int(w), stream()), "ksr_unet_convt_fwd")
-        out, _ = self._double_conv(f"up{i}.conv", up.conv, skip, cu, B, 2 * h, 2 * w, train, src1=u, c1=cu, tape=tape)
+        hs, ws = skip.shape[1], skip.shape[2]
+        oy, ox = (hs - 2 * h) // 2, (ws - 2 * w) // 2
+        if (hs, ws) != (2 * h, 2 * w):
+            # sizes that are not multiples of 16: MaxPool2d floored on the way down, so the upsampled tensor is zero-padded
+            # to the skip's size (F.pad of Up.forward, unet_blocks.py:68-73); a torch copy, taken on this path only
+            up_small, u = u, torch.zeros(B, hs, ws, cu, device=y.device, dtype=torch.float32)
+            u[:, oy:oy + 2 * h, ox:ox + 2 * w] = up_small
+        out, _ = self._double_conv(f"up{i}.conv", up.conv, skip, cu, B, hs, ws, train, src1=u, c1=cu, tape=tape)
         if tape is not None:
-            tape[f"up{i}.up"] = dict(y=y, cy=cy, wt=wt, dims=(B, h, w))
+            tape[f"up{i}.up"] = dict(y=y, cy=cy, wt=wt, dims=(B, h, w), pad=(oy, ox, hs, ws))
         return out
 
     def _up_bwd(self, i, dout, grads):
@@ -330,6 +337,9 @@ class UNet(nn.Module):
         t = self._tape[f"up{i}.up"]
         B, h, w = t["dims"]
         cy, cu = t["cy"], t["cy"] // 2
+        oy, ox, hs, ws = t["pad"]
+        if (hs, ws) != (2 * h, 2 * w):
+            du = du[:, oy:oy + 2 * h, ox:ox + 2 * w].contiguous()       # backward of the zero padding
         dwt = self._wgrad(du, cu, B, 2 * h, 2 * w, a0=t["y"], ca0=cy, Ha=h, Wa=w, mode=1, ones=True).view(4, cy + 1, cu)
         self._emit(grads, f"up{i}.up.weight", dwt[:, :cy].unflatten(0, (2, 2)).permute(2, 3, 0, 1))
         self._emit(grads, f"up{i}.up.bias", dwt[:, cy].sum(0))           # the four output positions of every input pixel
@@ -405,8 +415,8 @@ class UNet(nn.Module):
         if not y_plane.is_cuda or y_plane.dtype != torch.float32:
             raise KsrError("UNet needs fp32 GPU tensors (the HIP path is the only path)")
         B, _, H, W = y_plane.shape
-        if H % 16 or W % 16:
-            raise KsrError(f"UNet needs H and W to be multiples of 16, got {H}x{W}")
+        if H < 16 or W < 16:
+            raise KsrError(f"UNet needs at least 16x16 pixels (four 2x2 poolings), got {H}x{W}")
         x = y_plane.contiguous()
         if self._named is None:
             self._named = tuple(zip(*self.named_parameters()))

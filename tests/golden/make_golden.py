@@ -290,7 +290,8 @@ def gold_unet():
         for n, p in att.named_parameters():
             out[f"{tag}.p.{n}"] = p
             out[f"{tag}.g.{n}"] = p.grad
-    for tag, P, (B, H, W) in [("u40", 40, (2, 32, 32)), ("u160", 160, (2, 16, 32))]:
+    # "odd": 40 / 8 = 5 and 52 / 4 = 13 are odd, so two poolings floor and two Up blocks pad
+    for tag, P, (B, H, W) in [("u40", 40, (2, 32, 32)), ("u160", 160, (2, 16, 32)), ("odd", 40, (2, 40, 52))]:
         m = UNet(1, P)
         with torch.no_grad():
             for mod in m.modules():
@@ -312,7 +313,7 @@ def gold_unet():
         m.train()
         y = m(x)
         out[f"{tag}.y_train"] = y
-        if P == 40:                          # gradients for the small case only (fixture size)
+        if P == 40 and tag != "odd":         # gradients for the small case only (fixture size)
             gy = torch.randn(y.shape, generator=gen)
             (y * gy).sum().backward()
             out[f"{tag}.gy"] = gy

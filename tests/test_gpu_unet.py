@@ -47,8 +47,9 @@ def test_anchor_attention_golden(tag, name):
     assert_close(y, _nhwc(t(g[tag + ".y"])), tag)
 
 
-@pytest.mark.parametrize("tag,P", [("u40", 40), ("u160", 160)])
+@pytest.mark.parametrize("tag,P", [("u40", 40), ("u160", 160), ("odd", 40)])
 def test_unet_golden_eval_and_train(tag, P):
+    """"odd" is the reference's output on a 40x52 image (not a multiple of 16: poolings floor, Up blocks zero-pad)."""
     g = load_golden("unet")
     sd = {k[len(tag) + 4:]: t(v) for k, v in g.items() if k.startswith(tag + ".sd.")}
     m = _unet(P, sd)
@@ -72,10 +73,12 @@ def test_unet_golden_eval_and_train(tag, P):
 
 
 @pytest.mark.parametrize("B,H,W,P,train", [(1, 16, 16, 40, False), (3, 48, 80, 160, True), (2, 64, 32, 336, True),
-                                           (5, 16, 112, 64, False), (2, 256, 256, 160, True)])
+                                           (5, 16, 112, 64, False), (2, 256, 256, 160, True), (2, 17, 31, 40, True),
+                                           (1, 135, 240, 160, False), (3, 23, 16, 64, True)])
 def test_unet_vs_oracle(B, H, W, P, train):
     """Other sizes: a single image with a 1x1 bottleneck, non-square sizes, sizes with partial 256-pixel workgroups,
-    attention inputs longer than one Gram slab (256x256), every supported head size."""
+    attention inputs longer than one Gram slab (256x256), every supported head size, sizes that are not multiples of
+    16 (odd at every level: 17x31; a 1080p frame's 1/8 tile: 135x240)."""
     torch.manual_seed(B * 100 + H)
     m = _unet(P)
     with torch.no_grad():
@@ -170,7 +173,8 @@ def test_unet_golden_train_gradients():
 
 
 @pytest.mark.parametrize("B,H,W,P,train", [(1, 16, 32, 40, True), (3, 48, 80, 160, True), (2, 64, 32, 336, False),
-                                           (2, 256, 256, 160, True)])
+                                           (2, 256, 256, 160, True), (2, 40, 52, 40, True), (3, 37, 67, 64, True),
+                                           (2, 135, 120, 160, True), (1, 45, 35, 40, False)])
 def test_unet_gradients_vs_oracle(B, H, W, P, train):
     """Against the oracle evaluated in fp64: at 256x256 the fp32 CPU evaluation itself is off by up to 1e-2 on some
     BatchNorm gradients (sums over 10^5 pixels), so fp32-vs-fp32 would measure the checker, not the kernels."""
@@ -273,5 +277,5 @@ def test_unet_training_reduces_the_loss():
 def test_unet_refuses_bad_sizes():
     from kan_sr._lib import KsrError
     m = _unet(40)
-    with torch.no_grad(), pytest.raises(KsrError, match="multiples of 16"):
-        m(torch.rand(1, 1, 24, 16, device="cuda"))
+    with torch.no_grad(), pytest.raises(KsrError, match="at least 16x16"):
+        m(torch.rand(1, 1, 24, 15, device="cuda"))

@@ -199,10 +199,11 @@ def test_unet_anchor_attention(tag, heads):
         assert rel_l2(v.grad, t(g[f"{tag}.g.{n}"])) <= GRAD_REL, n
 
 
-@pytest.mark.parametrize("tag", ["u40", "u160"])
+@pytest.mark.parametrize("tag", ["u40", "u160", "odd"])
 def test_unet(tag):
     """UNet (conv_sep_kan/unet.py:7-42): eval forward, train forward with the running-statistics update and, for the
-    small case, the parameter gradients of the train-mode pass."""
+    small case, the parameter gradients of the train-mode pass.  "odd" is a 40x52 image: two poolings floor and two Up
+    blocks zero-pad (unet_blocks.py:68-73)."""
     g = load_golden("unet")
     p = {k[len(tag) + 4:]: t(v) for k, v in g.items() if k.startswith(tag + ".sd.")}
     p = {k: (v.requires_grad_() if v.dtype == torch.float32 and "running" not in k else v) for k, v in p.items()}
