@@ -183,6 +183,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train", "train-unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="train-unet: launch every kernel from the host instead of replaying the step's HIP graph")
     ap.add_argument("--loss", default=os.environ.get("KSR_BENCH_LOSS", "l1+ssim"), choices=["l1", "l1+ssim"],
                     help="training loss: the reference's training_step loss L1(Y) + 0.15 (1 - SSIM) (default) or L1(Y) only")
     ap.add_argument("--precision", default=os.environ.get("KSR_BENCH_PRECISION", "bf16s"), choices=["fp32", "bf16", "bf16s"],
@@ -229,14 +230,18 @@ def main():
         model.precision = args.precision
         x = torch.rand(B, 3, H, W, device=dev)
         tgt = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
-        ts = TrainStep(model, world_size=world, rank=rank, loss=args.loss)
+        # UNet step: forward + loss + backward replayed from a HIP graph (recorded on the third step; the step is bound by
+        # the host's launch rate otherwise).  The per-kernel timing run further down runs uncaptured.
+        ts = TrainStep(model, world_size=world, rank=rank, loss=args.loss, capture=unet and not args.no_graph)
         mode = {"fp32": "exact fp32", "bf16": "bf16 MFMA operands / fp32 accumulate and storage",
                 "bf16s": "bf16 MFMA operands and activation storage / fp32 accumulate"}[args.precision]
         wl = (f"x4 SR training step, {mode} (fwd + loss {args.loss} + bwd + RCCL gradient all-reduce + Adam), 64 patches of 128x128 per "
               "GPU (BASELINE configs[2], per-rank batch), dropout live")
         if unet:
             wl = (f"x4 SR training step with the UNet hyper-encoder, exact fp32 (fwd + loss {args.loss} + bwd + RCCL gradient "
-                  "all-reduce + Adam), 8 patches of 256x256 per GPU, BatchNorm on per-rank batch statistics")
+                  "all-reduce + Adam), 8 patches of 256x256 per GPU, BatchNorm on per-rank batch statistics"
+                  + ("" if args.no_graph else "; forward + loss + backward replayed from one HIP graph"))
+            args.warmup = max(args.warmup, 3)     # the graph is recorded on the third step
 
         def step():
             return ts.step(x, tgt)

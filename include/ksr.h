@@ -427,6 +427,26 @@ int ksr_unet_bn_relu_bwd(const float* dout, const float* raw, const float* scale
                          float* coef, float* dgamma, float* dbeta, float* dx, int64_t npix, int C,
                          ksr_stream_t stream);
 
+/* One launch for a table of small strided re-layouts (no counterpart call in the reference: there they are the
+ * implicit layouts of nn.Conv2d / nn.ConvTranspose2d weights, conv_sep_kan/unet_blocks.py:9-28,46-63,91-129, and
+ * autograd's chain rule through them).  Entry e, over the 4-D index space shape (row-major, `count` elements):
+ *   dst[sum_d i_d dstride_d] = sum_{r<nred} src[sum_d i_d sstride_d + r rstride] * (src2 ? src2[sum_d i_d s2stride_d + r r2stride] : 1)
+ * Strides are in floats and may be negative (flips) or zero.  `descs` and `blocks` live in device memory; blocks[k]
+ * names the entry and the first of the 256 consecutive elements workgroup k handles (the caller lists
+ * ceil(count/256) blocks per entry).  Entries of one table must not read what another entry of it writes. */
+typedef struct KsrGatherDesc {
+    const float* src;
+    const float* src2;
+    float* dst;
+    int32_t shape[4];
+    int32_t sstride[4];
+    int32_t s2stride[4];
+    int32_t dstride[4];
+    int32_t nred, rstride, r2stride, count;
+} KsrGatherDesc;
+typedef struct KsrGatherBlock { int32_t desc, first; } KsrGatherBlock;
+int ksr_gather_batch(const KsrGatherDesc* descs, const KsrGatherBlock* blocks, int nblocks, ksr_stream_t stream);
+
 /* Sum of the gradients that meet at an encoder level: out = g0 + g1 (optional) + MaxPool2d(2) backward of
  * g_pooled (optional; routed to the first maximum of each window of act, the activated output). */
 int ksr_unet_grad_merge(const float* g0, const float* g1, const float* g_pooled, const float* act, float* out,

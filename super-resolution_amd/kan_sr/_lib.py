@@ -98,7 +98,7 @@ EXPORTS = [
     "ksr_unet_conv_partials", "ksr_unet_conv_fwd", "ksr_unet_bn_finalize", "ksr_unet_bn_relu_fwd", "ksr_unet_convt_fwd",
     "ksr_unet_att_mix",
     "ksr_unet_wgrad_slab_floats", "ksr_unet_wgrad", "ksr_unet_bn_bwd_partials", "ksr_unet_bn_relu_bwd", "ksr_unet_grad_merge",
-    "ksr_unet_s2_dgrad", "ksr_unet_att_mix_bwd",
+    "ksr_unet_s2_dgrad", "ksr_unet_att_mix_bwd", "ksr_gather_batch",
 ]
 
 

@@ -20,6 +20,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 
 from . import engine
+from . import _lib
 from ._lib import KsrError, check, lib, ptr, stream
 from .autograd import PARAM_ORDER, backward_all
 from .engine import TX_PARAM_NAMES
@@ -99,10 +100,18 @@ class GlooComm:
 
 class TrainStep:
     def __init__(self, model, world_size: int = 1, rank: int = 0, lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 0.0, comm=None, loss: str = "l1"):
+                 eps: float = 1e-8, weight_decay: float = 0.0, comm=None, loss: str = "l1", capture: bool = False):
+        """capture (backbones that run their backward on the tape, i.e. UNet): after two ordinary steps at a given
+        input shape, forward + loss + backward are recorded once into a HIP graph and replayed from then on, so that
+        the ~470 launches of a step cost the host one call (the step is bound by the host's launch rate up to 8
+        patches of 256x256 per GPU).  The gradient all-reduce and Adam stay outside the graph (the step counter and
+        lr are by-value kernel arguments).  Inputs are copied into the graph's own buffers unless the caller passes
+        the same tensors again.  While _lib.PROFILE collects per-call events the step runs uncaptured."""
         if loss not in ("l1", "l1+ssim"):
             raise KsrError(f"loss must be 'l1' or 'l1+ssim', got {loss!r}")
         self.loss_kind = loss
+        self.capture = capture
+        self._graph, self._graph_key, self._graph_warm = None, None, 0
         self.base_lr = lr
         self.model = model
         self.world_size, self.rank = world_size, rank
@@ -207,6 +216,49 @@ class TrainStep:
         """Same step with the backward driven by the autograd tape (backbones other than GazeTR): forward through the
         module, loss kernels write dL/dY' into plane 0 of a [B,3,rH,rW] gradient (the chroma planes carry no gradient
         to the parameters and are never read), tape backward into the flat buffer, one all-reduce, Adam."""
+        if self.capture and _lib.PROFILE is None:
+            self._replay(x, tgt)
+        else:
+            self._forward_backward_on_tape(x, tgt)
+        L = lib()
+        if self.side is not None:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            self.comm.allreduce_sum(self.flat_g, c_void_p(self.side.cuda_stream))
+            main.wait_stream(self.side)
+        self.steps += 1
+        check(L.ksr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                              c_int64(self.flat_p.numel()), c_float(self.lr), c_float(self.betas[0]),
+                              c_float(self.betas[1]), c_float(self.eps), c_float(self.wd), c_int(self.steps),
+                              c_float(1.0 / self.world_size), stream()), "ksr_adam_step")
+        encoder = self.model.layers[-1].encoder.encoder
+        if hasattr(encoder, "invalidate_prepared"):
+            encoder.invalidate_prepared()         # the weights changed under the cached kernel layouts
+        return self.loss
+
+    def _replay(self, x: torch.Tensor, tgt: torch.Tensor) -> None:
+        """Forward + loss + backward of this step through the HIP graph of the current input shape (recorded on the
+        third step at that shape; the two before it run uncaptured and size every lazily allocated workspace)."""
+        key = (tuple(x.shape), tuple(tgt.shape), tgt.dtype, self.model.training)
+        if key != self._graph_key:
+            self._graph, self._graph_key, self._graph_warm = None, key, 0
+            self._gx, self._gt = torch.empty_like(x), torch.empty_like(tgt, memory_format=torch.contiguous_format)
+        if self._graph is None and self._graph_warm < 2:
+            self._graph_warm += 1
+            self._forward_backward_on_tape(x, tgt)
+            return
+        if x.data_ptr() != self._gx.data_ptr():
+            self._gx.copy_(x)
+        if tgt.data_ptr() != self._gt.data_ptr():
+            self._gt.copy_(tgt)
+        if self._graph is None:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._forward_backward_on_tape(self._gx, self._gt)
+            self._graph = graph                   # recording launches nothing: the replay below is this step
+        self._graph.replay()
+
+    def _forward_backward_on_tape(self, x: torch.Tensor, tgt: torch.Tensor) -> None:
         L = lib()
         m = self.model
         with torch.enable_grad():
@@ -226,21 +278,7 @@ class TrainStep:
         if getattr(m.layers[-1].encoder.encoder, "grad_sink", None) is None:
             self.flat_g.zero_()                   # autograd accumulates into the views
         out.backward(gfull)
-        if self.side is not None:
-            main = torch.cuda.current_stream()
-            self.side.wait_stream(main)
-            self.comm.allreduce_sum(self.flat_g, c_void_p(self.side.cuda_stream))
-            main.wait_stream(self.side)
-        self.steps += 1
-        check(L.ksr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                              c_int64(self.flat_p.numel()), c_float(self.lr), c_float(self.betas[0]),
-                              c_float(self.betas[1]), c_float(self.eps), c_float(self.wd), c_int(self.steps),
-                              c_float(1.0 / self.world_size), stream()), "ksr_adam_step")
-        encoder = m.layers[-1].encoder.encoder
-        if hasattr(encoder, "invalidate_prepared"):
-            encoder.invalidate_prepared()         # the weights changed under the cached kernel layouts
         self.out = outd
-        return self.loss
 
     def _add_ssim_term(self, out, tgt, gy, g, plane, dims=None, gy_stride=None):
         """loss += 0.15 (1 - SSIM(out, tgt)); gy += the luma gradient of that term (gy rows gy_stride elements apart)."""

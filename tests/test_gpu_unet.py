@@ -43,6 +43,7 @@ def test_anchor_attention_golden(tag, name):
     x = t(g[tag + ".x"]).cuda()
     B, C, H, W = x.shape
     with torch.no_grad():
+        m._ensure_prepared()
         y = m._attention(name, _nhwc(x), B, H, W)
     assert_close(y, _nhwc(t(g[tag + ".y"])), tag)
 
@@ -150,12 +151,15 @@ def test_anchor_attention_golden_gradients(tag, name):
     x = t(g[tag + ".x"]).cuda()
     B, C, H, W = x.shape
     with torch.no_grad():
-        tape, grads = {}, {}
+        tape = {}
+        m._ensure_prepared()
+        m._ensure_emit_plan(B)
         m._attention(name, _nhwc(x), B, H, W, tape=tape)
         m._tape = tape
-        g0, g1 = m._attention_bwd(name, _nhwc(t(g[tag + ".gy"]).cuda()), grads)
+        g0, g1 = m._attention_bwd(name, _nhwc(t(g[tag + ".gy"]).cuda()))
+        grads = m._collect_grads()           # every parameter's slot; only this block's were computed
     assert rel_l2((g0 + g1).cpu(), _nhwc(t(g[tag + ".gx"]))) <= GRAD_REL
-    _check_grads({k[len(name) + 1:]: v for k, v in grads.items()},
+    _check_grads({k[len(name) + 1:]: v for k, v in grads.items() if k.startswith(name + ".")},
                  {k[len(tag) + 3:]: t(v) for k, v in g.items() if k.startswith(tag + ".g.")})
 
 
@@ -258,6 +262,33 @@ def test_unet_train_step_vs_oracle_adam(loss):
     for n, v in m.state_dict().items():
         if "running" in n:
             assert rel_l2(v.cpu(), pr[n]) <= 1e-4, n
+
+
+def test_unet_captured_step_equals_launched_step():
+    """TrainStep(capture=True): the replayed HIP graph (steps 3..) gives bit-for-bit the parameters, running statistics
+    and losses of the step launched kernel by kernel, with fresh input tensors every step and across a change of the
+    input shape (which records a new graph)."""
+    from kan_sr.module import ConvSepKan
+    from kan_sr.train import TrainStep
+    runs = []
+    for capture in (False, True):
+        torch.manual_seed(33)
+        m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4, backbone="unet").cuda().train()
+        ts = TrainStep(m, lr=1e-3, loss="l1+ssim", capture=capture)
+        gen = torch.Generator().manual_seed(7)
+        losses = []
+        for it in range(9):
+            h, w = (32, 48) if it < 5 else (40, 36)                       # the second shape pads inside the Up blocks
+            x, tgt = torch.rand(2, 3, h, w, generator=gen).cuda(), torch.rand(2, 3, 4 * h, 4 * w, generator=gen).cuda()
+            losses.append(float(ts.step(x, tgt)))
+        if capture:
+            assert ts._graph is not None
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}, ts.out.cpu().clone()))
+    (l0, s0, o0), (l1, s1, o1) = runs
+    assert l0 == l1
+    assert torch.equal(o0, o1)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
 
 
 def test_unet_training_reduces_the_loss():
