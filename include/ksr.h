@@ -427,6 +427,19 @@ int ksr_unet_bn_relu_bwd(const float* dout, const float* raw, const float* scale
                          float* coef, float* dgamma, float* dbeta, float* dx, int64_t npix, int C,
                          ksr_stream_t stream);
 
+/* KAN cell (ConvSepKanCell.forward, conv_sep_kan/conv_sep_kan_cells.py:136-156, I = 1) whose per-pixel parameter vector
+ * is the output of a 1x1 conv 4 -> P (OutConv of the UNet hyper-encoder, conv_sep_kan/unet.py:28,41), w[n,:] = lb + lw y[n,:],
+ * computed on the fly instead of read: x [B,1,H,W], y [B*H*W,4], lw [P][4] (= the conv weight [P,4,1,1]), lb [P],
+ * P = O (n_coef + 2) <= 512; out as ksr_kan_cell_fwd.  The backward writes dy [B*H*W,4] and dlwb [5][P] (rows 0..3: the
+ * gradient of lw transposed, row 4: of lb); slab: ksr_kan_lin_slab_floats(...) floats of workspace. */
+int64_t ksr_kan_lin_slab_floats(int B, int H, int W, int O, int n_coef);
+int ksr_kan_lin_fwd(const float* x, const float* y, const float* lw, const float* lb, float* out, int B, int O, int H,
+                    int W, int n_coef, const float* knots, int n_knots, int spline_order, int shuffle_r,
+                    int64_t out_batch_stride, ksr_stream_t stream);
+int ksr_kan_lin_bwd(const float* x, const float* y, const float* lw, const float* lb, const float* gout, float* dy,
+                    float* slab, float* dlwb, int B, int O, int H, int W, int n_coef, const float* knots, int n_knots,
+                    int spline_order, int shuffle_r, int64_t gout_batch_stride, ksr_stream_t stream);
+
 /* One launch for a table of small strided re-layouts (no counterpart call in the reference: there they are the
  * implicit layouts of nn.Conv2d / nn.ConvTranspose2d weights, conv_sep_kan/unet_blocks.py:9-28,46-63,91-129, and
  * autograd's chain rule through them).  Entry e, over the 4-D index space shape (row-major, `count` elements):

@@ -20,6 +20,12 @@ struct CellArgs {
     int w_nhwc;
     int r;            // 0: no shuffle
     long out_bstride;  // elements between images in out (allows writing into a wider tensor)
+    // kan_lin kernels: w[n, :] = lb + lw * ly[n, :] is computed on the fly instead of read
+    const float* ly;  // [N, 4]
+    const float* lw;  // [P][4]
+    const float* lb;  // [P]
+    float* dly;       // backward: gradient of ly [N, 4]
+    float* lslab;     // backward: per-workgroup sums [gridDim.x][5][P] (rows 0..3: gradient of lw^T, row 4: of lb)
 };
 
 __device__ __forceinline__ long w_index(const CellArgs& a, int b, int hw, int p, int HW) {
@@ -238,6 +244,361 @@ int launch_cell_nhwc(bool bwd, const CellArgs& a, const KsrKnots& kn, hipStream_
     return KSR_OK;
 }
 
+// ------------------------------------------------------------------------------------------ 1x1 conv + KAN cell, fused
+// The UNet hyper-encoder ends in a 1x1 conv 4 -> P (OutConv, conv_sep_kan/unet.py:28,41) whose output is the KAN cell's
+// per-pixel parameter vector: P = 160 floats per pixel written, read back, and in the backward read and written once
+// more, re-read by the conv's data gradient and by its weight gradient.  These kernels build the [32 pixels][P] block of
+// a workgroup in LDS from the 4 input channels (w = lb + lw y), run the NHWC cell code above on it and, in the backward,
+// consume the gradient block in place: dy = gw lw (8 threads per pixel, combined by shuffles), and the sums over pixels
+// gw^T y and gw^T 1 in registers of the thread that owns entry p (tid, tid + 256), carried across the tiles of a
+// persistent workgroup and written once as a partial row.  I = 1 only.
+template <int K, bool BWD>
+__global__ void __launch_bounds__(256) kan_lin_kernel(CellArgs a, KsrKnots kn) {
+    extern __shared__ __attribute__((aligned(16))) float wt[];      // [NH_TP][P + NH_PAD] | lw [P][4] | lb [P] | y [NH_TP][4]
+    __shared__ float t[KSR_MAX_KNOTS];
+    const int tid = threadIdx.x;
+    const int P = a.P, LD = P + NH_PAD;
+    float4* lw4 = reinterpret_cast<float4*>(wt + NH_TP * LD);
+    float* lbs = wt + NH_TP * LD + 4 * P;
+    float4* ys = reinterpret_cast<float4*>(lbs + P);
+    if (tid < KSR_MAX_KNOTS) t[tid] = kn.t[tid < kn.M ? tid : 0];
+    for (int i = tid; i < 4 * P; i += 256) reinterpret_cast<float*>(lw4)[i] = a.lw[i];      // parameters may sit at any float offset
+    for (int p = tid; p < P; p += 256) lbs[p] = a.lb[p];
+    const int HW = a.H * a.W;
+    const long N = (long)a.B * HW;
+    const long ntiles = (N + NH_TP - 1) / NH_TP;
+    const int px = tid >> 3, sub = tid & 7;
+    const int uw_off = a.O * a.Kc, rw_off = uw_off + a.O;
+    float accw[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, accb[2] = {0.f, 0.f};
+    const int r_first = tid / P, p_first = tid - r_first * P;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n0 = tile * NH_TP;
+        const int npx = (N - n0) < NH_TP ? (int)(N - n0) : NH_TP;
+        // every global load of the tile is issued here, ahead of the block build that hides its latency
+        const long n = n0 + px;
+        const bool live = px < npx;
+        const int b = live ? (int)(n / HW) : 0, hw = live ? (int)(n % HW) : 0;
+        const int h = hw / a.W, wx = hw % a.W;
+        const float x = live ? a.x[(long)b * HW + hw] : 0.f;
+        float gop[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gop[j] = (BWD && live && sub + 8 * j < a.O) ? a.gout[out_index(a, b, sub + 8 * j, h, wx)] : 0.f;
+        const float4 ynew = (tid < npx) ? reinterpret_cast<const float4*>(a.ly)[n0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
+        __syncthreads();                                   // the previous tile's block is no longer read
+        if (tid < NH_TP) ys[tid] = ynew;
+        __syncthreads();
+        for (int r = r_first, p = p_first; r < NH_TP; ) {          // element (r, p), 256 elements further per step
+            const float4 y = ys[r], w4 = lw4[p];
+            wt[r * LD + p] = fmaf(w4.w, y.w, fmaf(w4.z, y.z, fmaf(w4.y, y.y, fmaf(w4.x, y.x, lbs[p]))));
+            p += 256;
+            while (p >= P) { p -= P; ++r; }
+        }
+        __syncthreads();
+        float* row = wt + px * LD;
+        float Nv[K + 1], dN[K + 1];
+        const int m = ksr_bspline_local<K, false>(x, t, kn.M, Nv, dN);
+        const float sl = ksr_silu(x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int o = sub + 8 * j;
+            if (o >= a.O) break;
+            float* cf = row + o * a.Kc;
+            const float uw = row[uw_off + o], rw = row[rw_off + o];
+            float S = 0.f;
+            if (m >= 0) {
+#pragma unroll
+                for (int q = 0; q <= K; ++q) {
+                    const int g = m - K + q;
+                    if (g >= 0 && g < a.Kc) S += Nv[q] * cf[g];
+                }
+            }
+            if (!BWD) {
+                if (live) a.out[out_index(a, b, o, h, wx)] = rw * sl + uw * S;
+            } else {
+                const float go = gop[j];
+                for (int g = 0; g < a.Kc; ++g) {
+                    float bg = 0.f;
+                    if (m >= 0) {
+#pragma unroll
+                        for (int q = 0; q <= K; ++q) if (g == m - K + q) bg = Nv[q];
+                    }
+                    cf[g] = go * uw * bg;
+                }
+                row[uw_off + o] = go * S;
+                row[rw_off + o] = go * sl;
+            }
+        }
+        if (BWD) {
+            __syncthreads();
+            float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+            for (int p = sub; p < P; p += 8) {
+                const float g = row[p];
+                const float4 w4 = lw4[p];
+                d0 = fmaf(g, w4.x, d0); d1 = fmaf(g, w4.y, d1); d2 = fmaf(g, w4.z, d2); d3 = fmaf(g, w4.w, d3);
+            }
+#pragma unroll
+            for (int sh = 1; sh < 8; sh <<= 1) {
+                d0 += __shfl_xor(d0, sh, 64); d1 += __shfl_xor(d1, sh, 64); d2 += __shfl_xor(d2, sh, 64); d3 += __shfl_xor(d3, sh, 64);
+            }
+            if (live && sub == 0) reinterpret_cast<float4*>(a.dly)[n] = make_float4(d0, d1, d2, d3);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int p = tid + 256 * q;
+                if (p < P) {
+                    for (int r = 0; r < npx; ++r) {
+                        const float g = wt[r * LD + p];
+                        const float4 y = ys[r];
+                        accw[q][0] = fmaf(g, y.x, accw[q][0]); accw[q][1] = fmaf(g, y.y, accw[q][1]);
+                        accw[q][2] = fmaf(g, y.z, accw[q][2]); accw[q][3] = fmaf(g, y.w, accw[q][3]);
+                        accb[q] += g;
+                    }
+                }
+            }
+        }
+    }
+    if (BWD) {
+        float* s = a.lslab + (long)blockIdx.x * 5 * P;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int p = tid + 256 * q;
+            if (p < P) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s[c * P + p] = accw[q][c];
+                s[4 * P + p] = accb[q];
+            }
+        }
+    }
+}
+
+// Forward: one pixel per lane, no parameter block at all: only the 4 live coefficients, uw and rw of each output are
+// evaluated (6 dot products of length 4 per output), with the same fused-multiply-add order as the block form above.
+template <int K>
+__global__ void __launch_bounds__(256) kan_lin_fwd_kernel(CellArgs a, KsrKnots kn) {
+    extern __shared__ __attribute__((aligned(16))) float wt[];      // lw [P][4] | lb [P]
+    __shared__ float t[KSR_MAX_KNOTS];
+    const int tid = threadIdx.x, P = a.P;
+    const float4* lw4 = reinterpret_cast<const float4*>(wt);
+    const float* lbs = wt + 4 * P;
+    if (tid < KSR_MAX_KNOTS) t[tid] = kn.t[tid < kn.M ? tid : 0];
+    for (int i = tid; i < 4 * P; i += 256) wt[i] = a.lw[i];
+    for (int p = tid; p < P; p += 256) wt[4 * P + p] = a.lb[p];
+    __syncthreads();
+    const int HW = a.H * a.W;
+    const long n = (long)blockIdx.x * 256 + tid;
+    if (n >= (long)a.B * HW) return;
+    const int b = (int)(n / HW), hw = (int)(n % HW);
+    const int h = hw / a.W, wx = hw % a.W;
+    const float4 y = reinterpret_cast<const float4*>(a.ly)[n];
+    const float x = a.x[n];
+    float Nv[K + 1], dN[K + 1];
+    const int m = ksr_bspline_local<K, false>(x, t, kn.M, Nv, dN);
+    const float sl = ksr_silu(x);
+    const int uw_off = a.O * a.Kc, rw_off = uw_off + a.O;
+    auto param = [&](int p) {
+        const float4 w4 = lw4[p];
+        return fmaf(w4.w, y.w, fmaf(w4.z, y.z, fmaf(w4.y, y.y, fmaf(w4.x, y.x, lbs[p]))));
+    };
+    for (int o0 = 0; o0 < a.O; o0 += 4) {
+        float res[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = o0 + j;
+            res[j] = 0.f;
+            if (o < a.O) {
+                float S = 0.f;
+                if (m >= 0) {
+#pragma unroll
+                    for (int q = 0; q <= K; ++q) {
+                        const int g = m - K + q;
+                        if (g >= 0 && g < a.Kc) S += Nv[q] * param(o * a.Kc + g);
+                    }
+                }
+                res[j] = param(rw_off + o) * sl + param(uw_off + o) * S;
+            }
+        }
+        if (a.r == 4 && o0 + 4 <= a.O)        // the 4 outputs are 4 neighbouring pixels of one output row
+            *reinterpret_cast<float4*>(a.out + out_index(a, b, o0, h, wx)) = make_float4(res[0], res[1], res[2], res[3]);
+        else
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (o0 + j < a.O) a.out[out_index(a, b, o0 + j, h, wx)] = res[j];
+    }
+}
+
+// Backward for O = 16 outputs (upscale 4) and 4 (Kc + 2) <= 64: one pixel per lane, a wave owns 64 pixels and works through
+// the outputs in 4 chunks of 4.  Per chunk a lane evaluates its pixel's live parameters (as the forward), adds their
+// gradients' share to dy in registers, and writes the chunk's 4 (Kc + 2) gradient entries (zeros for the coefficients
+// outside the pixel's knot interval) to its row of a wave-private LDS tile [64][4 (Kc + 2) + 1]; then lane e sums entry e
+// over the 64 rows against y (gw^T y, gw^T 1) into 5 accumulators per chunk that it keeps across all its tiles.  No
+// workgroup barrier inside the loop: the tile is private to the wave.  About a third of the instructions per pixel of
+// the 8-threads-per-pixel kernel above (which evaluates the basis 8 times per pixel and builds all P parameters).
+template <int K>
+__global__ void __launch_bounds__(256) kan_lin_bwd16_kernel(CellArgs a, KsrKnots kn) {
+    extern __shared__ __attribute__((aligned(16))) float wt[];      // lw [P][4] | lb [P] | per wave: ys [64][4], g [64][EC + 1]
+    __shared__ float t[KSR_MAX_KNOTS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int P = a.P, Kc = a.Kc, EC = 4 * (Kc + 2), LDG = EC + 1;
+    const float4* lw4 = reinterpret_cast<const float4*>(wt);
+    const float* lbs = wt + 4 * P;
+    float4* ysw = reinterpret_cast<float4*>(wt + 5 * P + wv * (256 + 64 * LDG));
+    float* gt = reinterpret_cast<float*>(ysw) + 256;
+    if (tid < KSR_MAX_KNOTS) t[tid] = kn.t[tid < kn.M ? tid : 0];
+    for (int i = tid; i < 4 * P; i += 256) wt[i] = a.lw[i];
+    for (int p = tid; p < P; p += 256) wt[4 * P + p] = a.lb[p];
+    __syncthreads();
+    const int HW = a.H * a.W;
+    const long N = (long)a.B * HW;
+    const long ntiles = (N + 63) / 64;
+    const int uw_off = 16 * Kc, rw_off = uw_off + 16;
+    float acc[4][5];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) acc[c][i] = 0.f;
+    float* myrow = gt + lane * LDG;
+    for (long tile = (long)blockIdx.x * 4 + wv; tile < ntiles; tile += (long)gridDim.x * 4) {
+        const long n = tile * 64 + lane;
+        const bool live = n < N;
+        const int b = live ? (int)(n / HW) : 0, hw = live ? (int)(n % HW) : 0;
+        const int h = hw / a.W, wx = hw % a.W;
+        const float4 y = live ? reinterpret_cast<const float4*>(a.ly)[n] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float x = live ? a.x[n] : 0.f;
+        float go[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {           // outputs 4i..4i+3 are 4 neighbouring pixels of output row 4h + i
+            const float4 v = live ? *reinterpret_cast<const float4*>(a.gout + out_index(a, b, 4 * i, h, wx)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            go[4 * i] = v.x; go[4 * i + 1] = v.y; go[4 * i + 2] = v.z; go[4 * i + 3] = v.w;
+        }
+        float Nv[K + 1], dN[K + 1];
+        const int m = ksr_bspline_local<K, false>(x, t, kn.M, Nv, dN);
+        const float sl = ksr_silu(x);
+        auto param = [&](int p) {
+            const float4 w4 = lw4[p];
+            return fmaf(w4.w, y.w, fmaf(w4.z, y.z, fmaf(w4.y, y.y, fmaf(w4.x, y.x, lbs[p]))));
+        };
+        float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+        auto emit = [&](int e, int p, float g) {           // gradient g of parameter p: tile entry e, and its share of dy
+            myrow[e] = g;
+            const float4 w4 = lw4[p];
+            d0 = fmaf(g, w4.x, d0); d1 = fmaf(g, w4.y, d1); d2 = fmaf(g, w4.z, d2); d3 = fmaf(g, w4.w, d3);
+        };
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();                    // the previous tile's rows and ys are no longer read
+        ysw[lane] = y;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            for (int e = 0; e < 4 * Kc; ++e) myrow[e] = 0.f;
+#pragma unroll
+            for (int jo = 0; jo < 4; ++jo) {
+                const int o = 4 * c + jo;
+                const float uw = param(uw_off + o);
+                float S = 0.f;
+                if (m >= 0) {
+#pragma unroll
+                    for (int q = 0; q <= K; ++q) {
+                        const int g = m - K + q;
+                        if (g >= 0 && g < Kc) {
+                            S += Nv[q] * param(o * Kc + g);
+                            emit(jo * Kc + g, o * Kc + g, go[o] * uw * Nv[q]);
+                        }
+                    }
+                }
+                emit(4 * Kc + jo, uw_off + o, go[o] * S);
+                emit(4 * Kc + 4 + jo, rw_off + o, go[o] * sl);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();                // all 64 rows of the chunk are written
+            if (lane < EC) {
+#pragma unroll 4
+                for (int r = 0; r < 64; ++r) {
+                    const float g = gt[r * LDG + lane];
+                    const float4 yr = ysw[r];
+                    acc[c][0] = fmaf(g, yr.x, acc[c][0]); acc[c][1] = fmaf(g, yr.y, acc[c][1]);
+                    acc[c][2] = fmaf(g, yr.z, acc[c][2]); acc[c][3] = fmaf(g, yr.w, acc[c][3]);
+                    acc[c][4] += g;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();                // the rows are free for the next chunk
+        }
+        if (live) reinterpret_cast<float4*>(a.dly)[n] = make_float4(d0, d1, d2, d3);
+    }
+    if (lane < EC) {
+        float* s = a.lslab + ((long)blockIdx.x * 4 + wv) * 5 * P;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int p = lane < 4 * Kc ? 4 * c * Kc + lane : (lane < 4 * Kc + 4 ? uw_off + 4 * c + (lane - 4 * Kc) : rw_off + 4 * c + (lane - 4 * Kc - 4));
+#pragma unroll
+            for (int i = 0; i < 5; ++i) s[i * P + p] = acc[c][i];
+        }
+    }
+}
+
+// out[e] = sum over the rows of slab [nrows][E]; 16 entries x 16 row slices per workgroup (a slice takes every 16th row, 8
+// loads in flight), slices combined in fixed order
+__global__ void __launch_bounds__(256) kan_lin_reduce_kernel(const float* __restrict__ slab, int nrows, int E, float* __restrict__ out) {
+    __shared__ float part[16][17];
+    const int le = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + le;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < E) {
+        int r = sl;
+        for (; r + 7 * 16 < nrows; r += 8 * 16) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += slab[(long)(r + 16 * u) * E + e];
+        }
+        for (; r < nrows; r += 16) acc[0] += slab[(long)r * E + e];
+    }
+    part[sl][le] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (sl == 0 && e < E) {
+        float v = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v += part[q][le];
+        out[e] = v;
+    }
+}
+
+constexpr int LIN_MAX_WG = 1536;          // 6 workgroups of 25 KB LDS per CU: all resident at once
+constexpr int LIN_MAX_P = 512;
+
+int lin_grid(int B, int H, int W) {
+    const long ntiles = ((long)B * H * W + NH_TP - 1) / NH_TP;
+    return (int)(ntiles < LIN_MAX_WG ? ntiles : LIN_MAX_WG);
+}
+
+constexpr int LIN16_MAX_WG = 768;          // 3 workgroups of ~50 KB LDS per CU
+int lin16_grid(int B, int H, int W) {
+    const long nwg = ((long)B * H * W + 255) / 256;
+    return (int)(nwg < LIN16_MAX_WG ? nwg : LIN16_MAX_WG);
+}
+bool lin16_fits(const CellArgs& a) {       // the one-pixel-per-lane backward: 16 outputs pixel-shuffled by 4, aligned gradient rows
+    return a.O == 16 && a.r == 4 && 4 * (a.Kc + 2) <= 64 && (reinterpret_cast<uintptr_t>(a.gout) & 15) == 0 && a.out_bstride % 4 == 0;
+}
+// partial rows the backward writes to the slab
+int lin_slab_rows(bool fits16, int B, int H, int W) { return fits16 ? 4 * lin16_grid(B, H, W) : lin_grid(B, H, W); }
+
+template <int K>
+int launch_lin(bool bwd, const CellArgs& a, const KsrKnots& kn, hipStream_t s) {
+    const size_t lds = ((size_t)NH_TP * (a.P + NH_PAD) + 5 * (size_t)a.P + 4 * NH_TP) * sizeof(float);
+    const dim3 grid((unsigned)lin_grid(a.B, a.H, a.W)), block(256);
+    if (bwd && lin16_fits(a)) {
+        const size_t lds16 = (5 * (size_t)a.P + 4 * (256 + 64 * (size_t)(4 * (a.Kc + 2) + 1))) * sizeof(float);
+        static bool set_6 = false;
+        if (!set_6) { (void)hipFuncSetAttribute((const void*)kan_lin_bwd16_kernel<K>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); set_6 = true; }
+        hipLaunchKernelGGL((kan_lin_bwd16_kernel<K>), dim3((unsigned)lin16_grid(a.B, a.H, a.W)), block, lds16, s, a, kn);
+    } else if (bwd) {
+        static bool set_b = false;
+        if (!set_b) { (void)hipFuncSetAttribute((const void*)kan_lin_kernel<K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); set_b = true; }
+        hipLaunchKernelGGL((kan_lin_kernel<K, true>), grid, block, lds, s, a, kn);
+    } else {
+        const long n = (long)a.B * a.H * a.W;
+        hipLaunchKernelGGL((kan_lin_fwd_kernel<K>), dim3((unsigned)((n + 255) / 256)), block, 5 * (size_t)a.P * sizeof(float), s, a, kn);
+    }
+    KSR_LAUNCH_CHECK("kan_lin");
+    return KSR_OK;
+}
+
 // ------------------------------------------------------------------------------------------ bilinear
 // out[b, oc0 + c, :, :] = bilinear_up(in[b, ic0 + c, :, :], r), c < nc.  align_corners = false.
 struct BilArgs {
@@ -371,6 +732,61 @@ extern "C" int ksr_kan_cell_fwd(const float* x, const float* w, float* out, int 
     a.B = B; a.I = I; a.O = O; a.H = H; a.W = W; a.Kc = n_coef; a.w_nhwc = w_nhwc; a.r = shuffle_r;
     a.out_bstride = out_batch_stride > 0 ? out_batch_stride : (long)O * H * W;
     return cell_common(false, a, knots, n_knots, spline_order, stream);
+}
+
+namespace {
+int lin_common(bool bwd, CellArgs& a, const float* knots, int n_knots, int k, hipStream_t s) {
+    KSR_CHECK_ARG(a.B > 0 && a.O > 0 && a.H > 0 && a.W > 0 && a.Kc > 0, "kan_lin: non-positive dimension");
+    KSR_CHECK_ARG(a.r == 0 || a.O % (a.r * a.r) == 0, "kan_lin: out_dim %d not divisible by r^2 (r=%d)", a.O, a.r);
+    a.I = 1;
+    a.P = a.O * (a.Kc + 2);
+    KSR_UNSUPPORTED(a.O > 64 || a.P > LIN_MAX_P, "kan_lin: out_dim %d / %d parameters per pixel exceed 64 / %d", a.O, a.P, LIN_MAX_P);
+    KSR_CHECK_ARG(((reinterpret_cast<uintptr_t>(a.ly) | reinterpret_cast<uintptr_t>(a.dly)) & 15) == 0, "kan_lin: y, dy must be 16-byte aligned");
+    KSR_CHECK_ARG(bwd || a.r != 4 || ((reinterpret_cast<uintptr_t>(a.out) & 15) == 0 && a.out_bstride % 4 == 0),
+                  "kan_lin_fwd: with shuffle_r = 4, out must be 16-byte aligned and its batch stride a multiple of 4");
+    KsrKnots kn;
+    int rc = fill_knots(kn, knots, n_knots, k, a.Kc);
+    if (rc) return rc;
+    switch (k) {
+        case 0: return launch_lin<0>(bwd, a, kn, s);
+        case 1: return launch_lin<1>(bwd, a, kn, s);
+        case 2: return launch_lin<2>(bwd, a, kn, s);
+        default: return launch_lin<3>(bwd, a, kn, s);
+    }
+}
+}  // namespace
+
+extern "C" int64_t ksr_kan_lin_slab_floats(int B, int H, int W, int O, int n_coef) {
+    if (B <= 0 || H <= 0 || W <= 0 || O <= 0 || n_coef <= 0) return 0;
+    const int rows16 = 4 * lin16_grid(B, H, W), rows = lin_grid(B, H, W);
+    return (int64_t)(rows16 > rows ? rows16 : rows) * 5 * O * (n_coef + 2);
+}
+
+extern "C" int ksr_kan_lin_fwd(const float* x, const float* y, const float* lw, const float* lb, float* out, int B, int O, int H,
+                               int W, int n_coef, const float* knots, int n_knots, int spline_order, int shuffle_r,
+                               int64_t out_batch_stride, hipStream_t stream) {
+    KSR_CHECK_ARG(x && y && lw && lb && out, "kan_lin_fwd: null pointer");
+    CellArgs a{};
+    a.x = x; a.ly = y; a.lw = lw; a.lb = lb; a.out = out;
+    a.B = B; a.O = O; a.H = H; a.W = W; a.Kc = n_coef; a.r = shuffle_r;
+    a.out_bstride = out_batch_stride > 0 ? out_batch_stride : (long)O * H * W;
+    return lin_common(false, a, knots, n_knots, spline_order, stream);
+}
+
+extern "C" int ksr_kan_lin_bwd(const float* x, const float* y, const float* lw, const float* lb, const float* gout, float* dy,
+                               float* slab, float* dlwb, int B, int O, int H, int W, int n_coef, const float* knots, int n_knots,
+                               int spline_order, int shuffle_r, int64_t gout_batch_stride, hipStream_t stream) {
+    KSR_CHECK_ARG(x && y && lw && lb && gout && dy && slab && dlwb, "kan_lin_bwd: null pointer");
+    CellArgs a{};
+    a.x = x; a.ly = y; a.lw = lw; a.lb = lb; a.gout = gout; a.dly = dy; a.lslab = slab;
+    a.B = B; a.O = O; a.H = H; a.W = W; a.Kc = n_coef; a.r = shuffle_r;
+    a.out_bstride = gout_batch_stride > 0 ? gout_batch_stride : (long)O * H * W;
+    int rc = lin_common(true, a, knots, n_knots, spline_order, stream);
+    if (rc) return rc;
+    const int E = 5 * a.P;
+    hipLaunchKernelGGL(kan_lin_reduce_kernel, dim3((unsigned)((E + 15) / 16)), dim3(256), 0, stream, slab, lin_slab_rows(lin16_fits(a), B, H, W), E, dlwb);
+    KSR_LAUNCH_CHECK("kan_lin_bwd(reduce)");
+    return KSR_OK;
 }
 
 extern "C" int ksr_kan_cell_bwd(const float* x, const float* w, const float* gout, float* gw, float* gx, int B, int I,

@@ -76,6 +76,7 @@ def _declare(L: ctypes.CDLL) -> None:
     L.ksr_unet_conv_partials.restype = c_int64
     L.ksr_unet_wgrad_slab_floats.restype = c_int64
     L.ksr_unet_bn_bwd_partials.restype = c_int64
+    L.ksr_kan_lin_slab_floats.restype = c_int64
 
 
 # every symbol include/ksr.h declares (tests/test_host_logic.py compares the two lists)
@@ -99,6 +100,7 @@ EXPORTS = [
     "ksr_unet_att_mix",
     "ksr_unet_wgrad_slab_floats", "ksr_unet_wgrad", "ksr_unet_bn_bwd_partials", "ksr_unet_bn_relu_bwd", "ksr_unet_grad_merge",
     "ksr_unet_s2_dgrad", "ksr_unet_att_mix_bwd", "ksr_gather_batch",
+    "ksr_kan_lin_slab_floats", "ksr_kan_lin_fwd", "ksr_kan_lin_bwd",
 ]
 
 

@@ -152,9 +152,14 @@ class ConvSepKan(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = x.contiguous()
         if self.backbone == "unet":
-            from .ops import kan_head
+            from .ops import kan_head, kan_lin_head
             engine.set_precision(self.precision)
-            w = self.layers[-1].encoder.encoder.forward_nhwc(x[:, :1])
+            net = self.layers[-1].encoder.encoder
+            if net.out_channels <= 512:
+                # the [N, P] parameter tensor is never materialised: the KAN-cell kernels apply the UNet's last 1x1 conv
+                y4 = net.forward_nhwc(x[:, :1], fuse_head=True)
+                return kan_lin_head(x, y4, net, self.grid_size, self.spline_order, self.grid_range, self.upscale)
+            w = net.forward_nhwc(x[:, :1])
             return kan_head(x, w, self.grid_size, self.spline_order, self.grid_range, self.upscale)
         g = engine.Geometry(x, self.upscale, self.grid_size, self.spline_order, self.grid_range)
         p = self._params()

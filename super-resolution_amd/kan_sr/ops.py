@@ -116,6 +116,58 @@ def kan_head(x: torch.Tensor, w: torch.Tensor, grid_size: int, spline_order: int
     return _KanHead.apply(x, w, grid_size + spline_order, knots, spline_order, r)
 
 
+class _KanLinHead(torch.autograd.Function):
+    """_KanHead with the parameter tensor never materialised: w = OutConv(y4) (the UNet's last 1x1 conv, 4 -> P) is
+    computed inside the KAN-cell kernels.  y4 [B*H*W, 4] is the UNet's last activation; the conv's weight and bias are read
+    from `net.reproj`, and their gradients are left in the UNet's kernel-layout gradient buffer (net._KG["reproj"],
+    rows: weight^T | bias), from where the UNet's own backward hands them on with all its other parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, x, y4, net, n_coef, knots, spline_order, r):
+        x, y4 = _f32c(x), _f32c(y4)
+        B, _, H, W = x.shape
+        P = net.out_channels
+        lw, lb = net.reproj.conv.weight.detach().view(P, 4), net.reproj.conv.bias.detach()
+        out = torch.empty(B, 3, H * r, W * r, device=x.device, dtype=torch.float32)
+        bilinear_up_into(x, out, r, 1, 2, 1)
+        y = x[:, :1].contiguous()
+        kn = host_floats(knots)
+        check(lib().ksr_kan_lin_fwd(ptr(y), ptr(y4), ptr(lw), ptr(lb), ptr(out), c_int(B), c_int(r * r), c_int(H), c_int(W),
+                                    c_int(n_coef), kn, c_int(len(knots)), c_int(spline_order), c_int(r),
+                                    c_int64(3 * H * r * W * r), stream()), "ksr_kan_lin_fwd")
+        ctx.save_for_backward(y, y4)
+        ctx.net, ctx.cfg = net, (n_coef, knots, spline_order, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        y, y4 = ctx.saved_tensors
+        n_coef, knots, spline_order, r = ctx.cfg
+        net = ctx.net
+        B, _, H, W = y.shape
+        if ctx.needs_input_grad[0]:
+            raise _lib.KsrError("gradient with respect to the input image is not implemented")
+        gout = _f32c(gout)
+        P = net.out_channels
+        lw, lb = net.reproj.conv.weight.detach().view(P, 4), net.reproj.conv.bias.detach()
+        net._ensure_emit_plan(B)
+        dy4 = torch.empty_like(y4)
+        slab = torch.empty(int(lib().ksr_kan_lin_slab_floats(c_int(B), c_int(H), c_int(W), c_int(r * r), c_int(n_coef))),
+                           device=y.device, dtype=torch.float32)
+        kn = host_floats(knots)
+        check(lib().ksr_kan_lin_bwd(ptr(y), ptr(y4), ptr(lw), ptr(lb), ptr(gout), ptr(dy4), ptr(slab), ptr(net._KG["reproj"]),
+                                    c_int(B), c_int(r * r), c_int(H), c_int(W), c_int(n_coef), kn, c_int(len(knots)),
+                                    c_int(spline_order), c_int(r), c_int64(3 * H * r * W * r), stream()), "ksr_kan_lin_bwd")
+        return None, dy4, None, None, None, None, None
+
+
+def kan_lin_head(x: torch.Tensor, y4: torch.Tensor, net, grid_size: int, spline_order: int, grid_range: Sequence[float],
+                 r: int) -> torch.Tensor:
+    """x [B,3,H,W], y4 [B*H*W, 4] (the input of net.reproj) -> [B,3,rH,rW]."""
+    knots = make_knots(grid_size, spline_order, grid_range)
+    return _KanLinHead.apply(x, y4, net, grid_size + spline_order, knots, spline_order, r)
+
+
 def bilinear_up_into(x: torch.Tensor, out: torch.Tensor, r: int, in_channel0: int, n_channels: int,
                      out_channel0: int) -> None:
     """Upsample planes [in_channel0, in_channel0+n) of x [B,C,H,W] into planes out_channel0.. of

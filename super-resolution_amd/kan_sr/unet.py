@@ -141,6 +141,7 @@ class UNet(nn.Module):
         self._W: dict = {}             # key -> weight in a kernel's layout (static buffers of the current _GatherPlan)
         self._prep_plans: dict = {}    # parameter addresses -> (plan, buffers); never dropped: HIP graphs may replay them
         self._prep_ver = None
+        self._ptrs, self._sink_key = None, None
         self._emit_plans: dict = {}    # (batch, addresses) -> (plan, kernel-layout gradient buffers, own gradient buffer)
         # name -> preallocated gradient tensor: when set (TrainStep does), the backward writes every parameter gradient
         # there and hands autograd no gradients, instead of returning fresh tensors for autograd to accumulate
@@ -151,7 +152,7 @@ class UNet(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         # .to() / .cuda() / .float() replace the buffer tensors: forget everything that was listed or derived from them
         self._counters, self._named = None, None
-        self._W, self._prep_ver = {}, None
+        self._W, self._prep_ver, self._ptrs, self._sink_key = {}, None, None, None
         self._prep_plans.clear(), self._emit_plans.clear()
         return super()._apply(fn, *args, **kwargs)
 
@@ -176,9 +177,15 @@ class UNet(nn.Module):
             self._named = tuple(zip(*self.named_parameters()))
         return self._named
 
+    def _param_ptrs(self):
+        """Addresses of the parameters, read once per forward pass (the backward reuses them)."""
+        if self._ptrs is None:
+            self._ptrs = tuple(p.data_ptr() for p in self._named_params()[1])
+        return self._ptrs
+
     def _ensure_prepared(self):
         names, params = self._named_params()
-        ptrs = tuple(p.data_ptr() for p in params)
+        ptrs = self._param_ptrs()
         hit = self._prep_plans.get(ptrs)
         if hit is None:
             with torch.no_grad():
@@ -251,7 +258,9 @@ class UNet(nn.Module):
         the other."""
         names, params = self._named_params()
         sink = self.grad_sink
-        key = (B, tuple(p.data_ptr() for p in params), None if sink is None else tuple(sink[n].data_ptr() for n in names))
+        if sink is not None and (self._sink_key is None or self._sink_key[0] is not sink):
+            self._sink_key = (sink, tuple(sink[n].data_ptr() for n in names))      # the sink's tensors are fixed views
+        key = (B, self._param_ptrs(), None if sink is None else self._sink_key[1])
         hit = self._emit_plans.get(key)
         if hit is None:
             with torch.no_grad():
@@ -502,8 +511,9 @@ class UNet(nn.Module):
     def _blocks(self):
         return [("proj", self.proj)] + [(f"down{i}.maxpool_conv.1", getattr(self, f"down{i}").maxpool_conv[1]) for i in range(1, 5)]
 
-    def _run(self, x, train, tape):
+    def _run(self, x, train, tape, fuse_head=False):
         B, _, H, W = x.shape
+        self._ptrs = None
         self._ensure_prepared()
         feats, pooled = [], x                     # [B,1,H,W] is [B,H,W,1]
         cin, h, w = 1, H, W
@@ -518,25 +528,32 @@ class UNet(nn.Module):
             skip = self._attention(f"att{5 - i}", xs, B, hs, ws, tape=tape)
             y = self._up(i, y, cy, skip, B, h, w, train, tape=tape)
             cy, h, w = cs, hs, ws
-        out, _ = self._conv(y, 4, self._W["reproj"], self.out_channels, B, H, W, bias=self.reproj.conv.bias.detach(), ks=1)
+        if fuse_head:         # the caller's KAN-cell kernels apply reproj themselves (ops.kan_lin_head)
+            out = y
+        else:
+            out, _ = self._conv(y, 4, self._W["reproj"], self.out_channels, B, H, W, bias=self.reproj.conv.bias.detach(), ks=1)
         if tape is not None:
-            tape["reproj"] = dict(y=y, dims=(B, H, W))
+            tape["reproj"] = dict(y=y, dims=(B, H, W), fused=fuse_head)
         if train:
             if self._counters is None:
                 self._counters = [m.num_batches_tracked for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
             torch._foreach_add_(self._counters, 1)
-        return out.view(B * H * W, self.out_channels)
+        return out.view(B * H * W, -1)
 
     def _backward(self, tape, dw):
-        """dw [B*H*W, P]: gradient of the output -> {parameter name: gradient}."""
+        """dw [B*H*W, P]: gradient of the output (with the head fused: [B*H*W, 4], gradient of reproj's input, reproj's
+        own parameter gradients being in self._KG["reproj"] already) -> {parameter name: gradient}."""
         self._tape = tape
         B, H, W = tape["reproj"]["dims"]
         self._ensure_prepared()
         self._ensure_emit_plan(B)
         P = self.out_channels
         y = tape["reproj"]["y"]
-        self._wgrad(dw, P, B, H, W, a0=y, ca0=4, Ha=H, Wa=W, ks=1, ones=True, out=self._KG["reproj"])
-        dy, _ = self._conv(dw, P, self.reproj.conv.weight.detach().view(P, 4), 4, B, H, W, ks=1)
+        if tape["reproj"]["fused"]:
+            dy = dw
+        else:
+            self._wgrad(dw, P, B, H, W, a0=y, ca0=4, Ha=H, Wa=W, ks=1, ones=True, out=self._KG["reproj"])
+            dy, _ = self._conv(dw, P, self.reproj.conv.weight.detach().view(P, 4), 4, B, H, W, ks=1)
         att_grads = {}
         for i in range(4, 0, -1):
             dskip, dy = self._up_bwd(i, dy)
@@ -558,9 +575,10 @@ class UNet(nn.Module):
         self._tape = None
         return self._collect_grads()
 
-    def forward_nhwc(self, y_plane: torch.Tensor) -> torch.Tensor:
+    def forward_nhwc(self, y_plane: torch.Tensor, fuse_head: bool = False) -> torch.Tensor:
         """y_plane [B,1,H,W] (fp32, GPU) -> per-pixel parameters [B*H*W, P] (NHWC); differentiable with respect to the
-        parameters (not the image)."""
+        parameters (not the image).  fuse_head: stop before reproj and return its input [B*H*W, 4] for
+        ops.kan_lin_head, which applies reproj inside the KAN-cell kernels."""
         if self.in_channels != 1 or self.out_channels % 4:
             raise KsrError("UNet kernels need in_channels = 1 and out_channels a multiple of 4")
         if not y_plane.is_cuda or y_plane.dtype != torch.float32:
@@ -571,9 +589,9 @@ class UNet(nn.Module):
         x = y_plane.contiguous()
         names, params = self._named_params()
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
-            return _UNetFn.apply(x, self, names, *params)
+            return _UNetFn.apply(x, self, names, fuse_head, *params)
         with torch.no_grad():
-            return self._run(x, self.training, None)
+            return self._run(x, self.training, None, fuse_head)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """[B,1,H,W] -> [B,P,H,W], the reference's signature (the relayout to NCHW is a torch copy)."""
@@ -587,16 +605,16 @@ class _UNetFn(torch.autograd.Function):
     the kernels read them from the module."""
 
     @staticmethod
-    def forward(ctx, x, net, names, *params):
+    def forward(ctx, x, net, names, fuse_head, *params):
         if x.requires_grad:
             raise KsrError("gradient with respect to the input image is not implemented")
         ctx.net, ctx.names, ctx.tape = net, names, {}
-        return net._run(x, net.training, ctx.tape)
+        return net._run(x, net.training, ctx.tape, fuse_head)
 
     @staticmethod
     def backward(ctx, dw):
         grads = ctx.net._backward(ctx.tape, dw.contiguous())
         ctx.tape = None
         if ctx.net.grad_sink is not None:
-            return (None,) * (3 + len(ctx.names))
-        return (None, None, None) + tuple(grads[n].contiguous() for n in ctx.names)
+            return (None,) * (4 + len(ctx.names))
+        return (None, None, None, None) + tuple(grads[n].contiguous() for n in ctx.names)

@@ -264,6 +264,37 @@ def test_unet_train_step_vs_oracle_adam(loss):
             assert rel_l2(v.cpu(), pr[n]) <= 1e-4, n
 
 
+@pytest.mark.parametrize("B,H,W,r,G,k", [(2, 17, 23, 4, 5, 3), (1, 16, 40, 4, 16, 3), (3, 9, 11, 2, 5, 2), (1, 300, 200, 4, 5, 3),
+                                         (2, 384, 320, 4, 5, 3), (1, 33, 35, 4, 8, 3), (2, 20, 20, 4, 5, 1)])
+def test_fused_outconv_kan_head_equals_unfused(B, H, W, r, G, k):
+    """ksr_kan_lin_fwd / _bwd (the UNet's last 1x1 conv applied inside the KAN-cell kernels) against the same head with
+    the parameter tensor materialised (torch 1x1 conv + ksr_kan_cell, itself pinned on the reference goldens): pixel
+    counts that are not multiples of the 32-pixel tile, more tiles than persistent workgroups (300x200), more than 256
+    parameters per pixel (G = 16), another spline order."""
+    from kan_sr.ops import kan_head, kan_lin_head
+    torch.manual_seed(B + H)
+    P = r * r * (G + k + 2)
+    net = _unet(P)
+    with torch.no_grad():
+        net.reproj.conv.weight.normal_(0, 0.5)
+        net.reproj.conv.bias.normal_(0, 0.5)
+    x = torch.rand(B, 3, H, W, device="cuda") * 2.4 - 1.2                 # some pixels outside the grid range
+    y4 = torch.randn(B * H * W, 4, device="cuda", requires_grad=True)
+    gy = torch.randn(B, 3, r * H, r * W, device="cuda")
+    lw = net.reproj.conv.weight.detach().view(P, 4).clone().requires_grad_()
+    lb = net.reproj.conv.bias.detach().clone().requires_grad_()
+    ref = kan_head(x, y4 @ lw.t() + lb, G, k, [-1, 1], r)
+    ref.backward(gy)
+    want_dy, y4.grad = y4.grad, None
+    out = kan_lin_head(x, y4, net, G, k, [-1, 1], r)
+    assert float((out - ref).detach().abs().max()) <= 1e-5 + 1e-5 * float(ref.detach().abs().max())
+    out.backward(gy)
+    assert rel_l2(y4.grad.cpu(), want_dy.cpu()) <= 1e-5
+    got = net._KG["reproj"].cpu()                                          # [5][P]: weight^T | bias
+    assert rel_l2(got[:4].t(), lw.grad.cpu()) <= 1e-4
+    assert rel_l2(got[4], lb.grad.cpu()) <= 1e-4
+
+
 def test_unet_captured_step_equals_launched_step():
     """TrainStep(capture=True): the replayed HIP graph (steps 3..) gives bit-for-bit the parameters, running statistics
     and losses of the step launched kernel by kernel, with fresh input tensors every step and across a change of the
