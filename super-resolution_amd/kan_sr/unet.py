@@ -142,6 +142,7 @@ class UNet(nn.Module):
         self._prep_plans: dict = {}    # parameter addresses -> (plan, buffers); never dropped: HIP graphs may replay them
         self._prep_ver = None
         self._ptrs, self._sink_key = None, None
+        self._bn_eval: dict = {}       # BatchNorm2d -> (versions, (scale, shift, saved)) of the eval-mode affine form
         self._emit_plans: dict = {}    # (batch, addresses) -> (plan, kernel-layout gradient buffers, own gradient buffer)
         # name -> preallocated gradient tensor: when set (TrainStep does), the backward writes every parameter gradient
         # there and hands autograd no gradients, instead of returning fresh tensors for autograd to accumulate
@@ -153,6 +154,7 @@ class UNet(nn.Module):
         # .to() / .cuda() / .float() replace the buffer tensors: forget everything that was listed or derived from them
         self._counters, self._named = None, None
         self._W, self._prep_ver, self._ptrs, self._sink_key = {}, None, None, None
+        self._bn_eval.clear()
         self._prep_plans.clear(), self._emit_plans.clear()
         return super()._apply(fn, *args, **kwargs)
 
@@ -162,6 +164,7 @@ class UNet(nn.Module):
         torch's back (a kernel writing through their storage, as TrainStep's Adam does): torch-side updates
         (optimizers, load_state_dict, copy_) bump the version counters the copies are keyed on and need no call."""
         self._prep_ver = None
+        self._bn_eval.clear()
 
     def _double_convs(self):
         """(key, module, channels of the first and second input) of the nine DoubleConv blocks."""
@@ -372,14 +375,27 @@ class UNet(nn.Module):
     def _bn(self, bn: nn.BatchNorm2d, partials, count, train):
         C = bn.num_features
         dev = bn.weight.device
-        scale, shift, saved = _new(dev, C), _new(dev, C), _new(dev, 2, C)
         if bn.running_mean is None:
             raise KsrError("BatchNorm2d without running statistics has no kernel")
+        ver = None
+        if not train:
+            # eval: scale and shift depend on the parameters and running statistics only; kept until one of them changes
+            # (torch-side changes bump the version counters, kernels that write them call invalidate_prepared / run in
+            # train mode, which clears the cache)
+            ver = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version)
+            hit = self._bn_eval.get(bn)
+            if hit is not None and hit[0] == ver:
+                return hit[1]
+        else:
+            self._bn_eval.clear()
+        scale, shift, saved = _new(dev, C), _new(dev, C), _new(dev, 2, C)
         momentum = 0.1 if bn.momentum is None else bn.momentum
         check(lib().ksr_unet_bn_finalize(ptr(partials), c_int(0 if partials is None else partials.shape[0]), c_int64(count),
                                          ptr(bn.weight.detach()), ptr(bn.bias.detach()), ptr(bn.running_mean),
                                          ptr(bn.running_var), c_float(momentum), c_float(bn.eps), c_int(int(train)),
                                          ptr(scale), ptr(shift), ptr(saved), c_int(C), stream()), "ksr_unet_bn_finalize")
+        if ver is not None:
+            self._bn_eval[bn] = (ver, (scale, shift, saved))
         return scale, shift, saved
 
     def _bn_bwd(self, bn: nn.BatchNorm2d, dout, raw, aff, train, npix, names):

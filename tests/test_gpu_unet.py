@@ -71,6 +71,12 @@ def test_unet_golden_eval_and_train(tag, P):
                 assert int(after[n]) == int(v), n
             else:
                 assert rel_l2(after[n].cpu(), t(v)) <= 1e-5, n
+    # eval again: the train pass moved the running statistics, so the cached eval-mode scale / shift must not be reused
+    p_after = {k: v.detach().cpu().clone() for k, v in after.items()}
+    with torch.no_grad():
+        m.eval()
+        assert_close(m(x), orc.unet(x.cpu(), p_after, "", False), "eval after the train pass")
+        assert_close(m(x), orc.unet(x.cpu(), p_after, "", False), "eval, cached affine form")
 
 
 @pytest.mark.parametrize("B,H,W,P,train", [(1, 16, 16, 40, False), (3, 48, 80, 160, True), (2, 64, 32, 336, True),
