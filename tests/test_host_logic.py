@@ -203,3 +203,79 @@ def test_checkpoint_roundtrip_in_reference_layout(tmp_path):
     assert ts2.steps == 7 and ts2.lr == 3e-4 and torch.equal(ts2.exp_avg, ts.exp_avg) and torch.equal(ts2.exp_avg_sq, ts.exp_avg_sq)
     assert m2.layers[-1].encoder.encoder.feed.weight.data_ptr() >= ts2.flat_p.data_ptr()      # still bound to the flat buffer
     assert adam_state_dict(TrainStep(ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2)))["state"] == {}
+
+
+def _run_gather_plan_on_host(plan):
+    """Executes the rows of a kan_sr.unet._GatherPlan built over CPU tensors exactly as ksr_gather_batch defines them
+    (include/ksr.h), reading and writing the tensors' memory through their addresses."""
+    import ctypes
+    import itertools
+    for sp, s2p, dp, shape, ss, s2s, ds, nred, rs, r2s, count in plan.rows:
+        f = ctypes.POINTER(ctypes.c_float)
+        src, src2, dst = ctypes.cast(sp, f), (ctypes.cast(s2p, f) if s2p else None), ctypes.cast(dp, f)
+        n = 0
+        for idx in itertools.product(*[range(k) for k in shape]):
+            so = sum(i * s for i, s in zip(idx, ss))
+            s2o = sum(i * s for i, s in zip(idx, s2s))
+            acc = 0.0
+            for r in range(nred):
+                acc += src[so + r * rs] * (src2[s2o + r * r2s] if src2 is not None else 1.0)
+            dst[sum(i * s for i, s in zip(idx, ds))] = acc
+            n += 1
+        assert n == count
+
+
+def test_unet_gather_tables_on_host():
+    """The two tables of strided gathers the UNet backbone launches per step, interpreted on the CPU: the weight table
+    must reproduce the kernels' layouts (torch permutes / flips / the composed attention projection), the gradient
+    table the chain rule back to the parameters' shapes."""
+    import torch.nn.functional as F
+    from kan_sr.unet import UNet
+    torch.manual_seed(0)
+    m = UNet(1, 40)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.normal_()
+    plan, W = m._build_prep_plan()
+    _run_gather_plan_on_host(plan)
+    dc = m.down2.maxpool_conv[1].double_conv
+    w1, w2 = dc[0].weight.detach(), dc[3].weight.detach()
+    key = "down2.maxpool_conv.1"
+    assert torch.equal(W[key + ".0"], w1.permute(2, 3, 1, 0).reshape(9, 8, 16))
+    assert torch.equal(W[key + ".3.T"], w2.permute(2, 3, 1, 0).reshape(9, 16, 16).flip(0).transpose(1, 2))
+    assert torch.equal(W[key + ".0.T0"], w1.permute(2, 3, 1, 0).reshape(9, 8, 16).flip(0).transpose(1, 2))
+    wu = m.up2.conv.double_conv[0].weight.detach()                              # [16][32][3][3]: skip 16 | upsampled 16
+    assert torch.equal(W["up2.conv.0.T1"], wu.permute(2, 3, 1, 0).reshape(9, 32, 16).flip(0).transpose(1, 2)[:, :, 16:])
+    assert torch.equal(W["up3.up"], m.up3.up.weight.detach().permute(2, 3, 0, 1).reshape(4, 16, 8))
+    # the composed projection z = (q | k | a) equals the three reference convs (unet_blocks.py:100-127, without padding)
+    att, c = m.att2, 8
+    x = torch.randn(1, c, 3, 3)
+    z = torch.einsum("tiz,it->z", W["att2.wz"], x[0].reshape(c, 9)) + W["att2.bz"]
+    q = F.conv2d(x, att.q_proj.weight, groups=c).reshape(-1)
+    k = F.conv2d(x, att.k_proj.weight).reshape(-1)
+    a = att.a_proj[1](F.conv2d(x, att.a_proj[0].weight, groups=c)).reshape(-1)
+    assert torch.allclose(z[:2 * c + c // 2], torch.cat([q, k, a]).detach(), atol=1e-5)
+    assert torch.equal(W["att2.wzT"], W["att2.wz"].transpose(1, 2))
+    # gradient table: fill the kernel-layout buffers, compare with autograd through the same compositions
+    B = 2
+    eplan, KG, gdst, own = m._build_emit_plan(B)
+    for v in KG.values():
+        v.normal_()
+    _run_gather_plan_on_host(eplan)
+    g = KG["att2.wz"]                                                            # [9][c+1][zc]
+    wz = torch.zeros(9, c, g.shape[2])
+    ps = [att.q_proj.weight, att.k_proj.weight, att.a_proj[0].weight, att.a_proj[1].weight]
+    for p in ps:
+        p.grad = None
+    wz[:, :, :c] = torch.diag_embed(att.q_proj.weight.reshape(c, 9).t())
+    wz[:, :, c:2 * c] = att.k_proj.weight.permute(2, 3, 1, 0).reshape(9, c, c)
+    wz[:, :, 2 * c:2 * c + c // 2] = att.a_proj[0].weight.reshape(c, 9).t()[:, :, None] * att.a_proj[1].weight.reshape(c // 2, c).t()[None]
+    (wz * g[:, :c]).sum().backward()
+    for name, p in zip(["q_proj.weight", "k_proj.weight", "a_proj.0.weight", "a_proj.1.weight"], ps):
+        assert torch.allclose(gdst["att2." + name], p.grad, atol=1e-5, rtol=1e-5), name
+    assert torch.equal(gdst["att2.a_proj.1.bias"], g[0, c, 2 * c:2 * c + c // 2])
+    assert torch.allclose(gdst["att2.v_proj.weight"].reshape(-1), KG["att2.dpar"][:, :c * c].sum(0), atol=1e-6)
+    assert torch.allclose(gdst["up3.up.bias"], KG["up3.up"][:, 16].sum(0), atol=1e-6)
+    assert torch.equal(gdst["up3.up.weight"], KG["up3.up"][:, :16].reshape(2, 2, 16, 8).permute(2, 3, 0, 1))
+    assert torch.equal(gdst["reproj.conv.weight"].reshape(40, 4), KG["reproj"][:4].t())
+    assert torch.equal(gdst[key + ".double_conv.0.weight"], KG[key + ".0"].reshape(3, 3, 8, 16).permute(3, 2, 0, 1))
