@@ -253,7 +253,9 @@ class TrainStep:
             self._gt.copy_(tgt)
         if self._graph is None:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: only this thread's calls are policed while recording.  Other threads of the process (the
+            # process group's watchdog polling its events when world_size > 1) would abort a recording in "global" mode.
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 self._forward_backward_on_tape(self._gx, self._gt)
             self._graph = graph                   # recording launches nothing: the replay below is this step
         self._graph.replay()
