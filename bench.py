@@ -110,13 +110,37 @@ def measured_traffic(entry: str):
 def unet_kernel_models(P: int):
     """Algorithmic HBM bytes per LR pixel and training step of the two entry points that carry the UNet backbone
     (every launch reads its inputs and writes its output once, fp32; level l of the pyramid has 4^-l pixels):
-    convolutions (forward, data gradients, per-image 1x1 applications) and weight gradients."""
+    convolutions (forward, data gradients, per-image 1x1 applications) and weight gradients.  The last 1x1 conv
+    (4 -> P) is part of the KAN-cell kernels (ksr_kan_lin_*: luma 4 B, its 4 input channels 16 B, 16 outputs 64 B per
+    pixel; the backward also writes the 16 B gradient of the input channels)."""
     dc = 52 + 28 + 14 + 7 + 3.5 + 10 + 20 + 40 + 80            # the nine DoubleConv blocks, forward
     att_z, att_apply, att_dz = 50.75, 60.0, 41.5                # stride-2 projections, T application, D application
-    reproj = 4 * (4 + P)
-    conv = (dc + att_z + att_apply + reproj) + ((dc - 20 + 30) + 45 + att_apply + att_dz + reproj)
-    wgrad = dc + reproj + 4 * P + 45 + 30 + att_apply + att_z + 2 * 20.75
-    return {"ksr_unet_conv_fwd": ("hbm", 0, conv, PEAK_MFMA_F32_TFLOPS), "ksr_unet_wgrad": ("hbm", 0, wgrad, PEAK_MFMA_F32_TFLOPS)}
+    conv = (dc + att_z + att_apply) + ((dc - 20 + 30) + 45 + att_apply + att_dz)
+    wgrad = dc + 45 + 30 + att_apply + att_z + 2 * 20.75
+    return {"ksr_unet_conv_fwd": ("hbm", 0, conv, PEAK_MFMA_F32_TFLOPS), "ksr_unet_wgrad": ("hbm", 0, wgrad, PEAK_MFMA_F32_TFLOPS),
+            "ksr_kan_lin_fwd": ("hbm", 0, 84.0, PEAK_MFMA_F32_TFLOPS), "ksr_kan_lin_bwd": ("hbm", 0, 100.0, PEAK_MFMA_F32_TFLOPS)}
+
+
+UNET_ENTRY_KERNELS = {"ksr_unet_conv_fwd": ("unet_conv_kernel", "unet_conv_ksplit_kernel"), "ksr_unet_wgrad": ("unet_wgrad_kernel",)}
+
+
+def measured_traffic_unet(entry: str):
+    """HBM bytes per launch of a UNet entry point, averaged over its kernel instances by their launch counts in the
+    committed PMC summary (ksr_unet_wgrad: plus its reduce kernel), or None."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_train_unet_b8_pmc_hbm.csv")
+    if entry not in UNET_ENTRY_KERNELS or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rows = list(csv.DictReader(fh))
+    sel = [r for r in rows if r["kernel"].split("<")[0] in UNET_ENTRY_KERNELS[entry]]
+    n = sum(int(r["launches_in_pmc_pass"]) for r in sel)
+    if not n:
+        return None
+    avg = sum(float(r["hbm_bytes_per_launch"]) * int(r["launches_in_pmc_pass"]) for r in sel) / n
+    if entry == "ksr_unet_wgrad":
+        avg += sum(float(r["hbm_bytes_per_launch"]) for r in rows if r["kernel"] == "unet_wgrad_reduce_kernel")
+    return int(avg)
 
 
 def build_model(upscale=4, G=5, k=3, seed=0, backbone="gazetr"):
@@ -314,6 +338,10 @@ def main():
         if args.workload == "train" and args.precision == "bf16s" and B == 64:
             roofline["traffic"] = measured_traffic(dom)
             roofline["traffic_source"] = "profiles/r01_train_b64_bf16s_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
+            roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
+        if unet and B == 8:
+            roofline["traffic"] = measured_traffic_unet(dom)
+            roofline["traffic_source"] = "profiles/r01_train_unet_b8_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
             roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
         roofline["avg_launch_ms"] = round(avg_ms, 4)
         roofline["launches_per_step"] = len(prof[dom]) // nlaunch

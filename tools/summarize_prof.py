@@ -63,6 +63,7 @@ per_kernel = {r[0]: r[6] for r in rows}
 wg = [r for r in rows if r[0].startswith("wgrad_kernel<")]
 if wg:
     per_kernel["entry:ksr_wgrad"] = int(sum(r[6] * r[1] for r in wg) / sum(r[1] for r in wg) + per_kernel.get("reduce_kernel", 0))
-with open(os.path.join(OUT, "pmc_hbm_bytes_per_launch.json"), "w") as fh:
+# bench.py reads the default workload's file; other tags keep their own
+with open(os.path.join(OUT, "pmc_hbm_bytes_per_launch.json" if TAG == "r01_train_b64_bf16s" else f"{TAG}_pmc_hbm_bytes_per_launch.json"), "w") as fh:
     json.dump(per_kernel, fh, indent=1)
 print(f"wrote {len(rows)} kernels to profiles/{TAG}_*")
