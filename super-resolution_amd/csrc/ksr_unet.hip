@@ -464,7 +464,7 @@ static int conv_block(int B, int npix) { return (long)B * npix <= 16384 ? 64 : 2
 // Lanes per pixel of the channel-split kernel, or 0 when the pixel-per-lane kernel is the one to use.
 static int conv_ksplit_lanes(int B, int npix, int c0, int c1, int cout, int64_t w_image_stride) {
     const int cin = c0 + c1;
-    if (w_image_stride != 0 || cout % 16 != 0 || (long)B * npix > 16384 || (c0 & 3) || (c1 & 3)) return 0;
+    if (w_image_stride != 0 || cout % 16 != 0 || (long)B * npix > 32768 || (c0 & 3) || (c1 & 3)) return 0;
     if (cin != 16 && cin != 32 && cin != 64 && cin != 128) return 0;
     return cin == 16 ? 4 : (cin == 32 ? 8 : 16);
 }

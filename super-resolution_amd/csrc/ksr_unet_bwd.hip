@@ -343,12 +343,16 @@ __device__ __forceinline__ int s2_candidate(int k, int i, int n) {
     return k == 0 ? i : (k == 1 ? (i == 1 ? -1 : -99) : (i == n - 2 ? n : -99));
 }
 
-// data gradient of conv3x3(stride 2, reflect pad 1): one input pixel, CT input channels per lane.  weight [9][cz][cin]
-template <int CT>
+// data gradient of conv3x3(stride 2, reflect pad 1): one input pixel, CT input channels per lane.  weight [9][cz][cin].
+// LPP > 1 (small images: a few thousand pixels would leave most of the chip idle behind serial chains of cz x taps
+// loads): LPP neighbouring lanes share a pixel and split the cz gradient channels, a butterfly adds their sums.
+template <int CT, int LPP>
 __global__ void __launch_bounds__(256) unet_s2_dgrad_kernel(S2Args a) {
     const int b = blockIdx.y, c0 = blockIdx.z * CT;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= a.H * a.W) return;
+    const int sub = threadIdx.x % LPP;
+    const int pr = blockIdx.x * (256 / LPP) + threadIdx.x / LPP;
+    const bool live = pr < a.H * a.W;
+    const int p = live ? pr : 0;                             // idle lanes redo pixel 0 (they take part in the butterfly)
     const int iy = p / a.W, ix = p - iy * a.W;
     float acc[CT];
 #pragma unroll
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(256) unet_s2_dgrad_kernel(S2Args a) {
                     if (tx < 0 || (tx & 1) || (tx >> 1) >= a.Wo) continue;
                     const float* g = a.dz + (((long)b * a.Ho + (ty >> 1)) * a.Wo + (tx >> 1)) * a.cz;
                     const float* w = a.weight + (long)(ky * 3 + kx) * a.cz * a.cin + c0;
-                    for (int co = 0; co < a.cz; co += 4) {
+                    for (int co = 4 * sub; co < a.cz; co += 4 * LPP) {
                         const float4 g4 = *reinterpret_cast<const float4*>(g + co);
                         const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
@@ -379,6 +383,11 @@ __global__ void __launch_bounds__(256) unet_s2_dgrad_kernel(S2Args a) {
             }
         }
     }
+#pragma unroll
+    for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int m = LPP >> 1; m >= 1; m >>= 1) acc[i] += __shfl_xor(acc[i], m, 64);
+    if (!live || sub != 0) return;
     float* o = a.dx + ((long)b * a.H * a.W + p) * a.cin + c0;
 #pragma unroll
     for (int i = 0; i < CT; i += 4) *reinterpret_cast<float4*>(o + i) = make_float4(acc[i], acc[i + 1], acc[i + 2], acc[i + 3]);
@@ -681,9 +690,15 @@ extern "C" int ksr_unet_s2_dgrad(const float* dz, int cz, const float* weight, f
     KSR_UNSUPPORTED(cz % 4 != 0 || cin % 4 != 0, "unet_s2_dgrad: channel counts (%d, %d) must be multiples of 4", cz, cin);
     KSR_UNSUPPORTED(B > 65535, "unet_s2_dgrad: batch %d too large for one launch", B);
     S2Args a{dz, weight, dx, cz, cin, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
-    const unsigned gx = (unsigned)((H * W + 255) / 256);
-    if (cin % 8 == 0) hipLaunchKernelGGL(unet_s2_dgrad_kernel<8>, dim3(gx, (unsigned)B, (unsigned)(cin / 8)), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(unet_s2_dgrad_kernel<4>, dim3(gx, (unsigned)B, (unsigned)(cin / 4)), dim3(256), 0, stream, a);
+    const bool split = (long)B * H * W <= 32768 && cz >= 16;             // 4 lanes per pixel
+    const unsigned gx = (unsigned)((H * W + (split ? 63 : 255)) / (split ? 64 : 256));
+    if (cin % 8 == 0) {
+        if (split) hipLaunchKernelGGL((unet_s2_dgrad_kernel<8, 4>), dim3(gx, (unsigned)B, (unsigned)(cin / 8)), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((unet_s2_dgrad_kernel<8, 1>), dim3(gx, (unsigned)B, (unsigned)(cin / 8)), dim3(256), 0, stream, a);
+    } else {
+        if (split) hipLaunchKernelGGL((unet_s2_dgrad_kernel<4, 4>), dim3(gx, (unsigned)B, (unsigned)(cin / 4)), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((unet_s2_dgrad_kernel<4, 1>), dim3(gx, (unsigned)B, (unsigned)(cin / 4)), dim3(256), 0, stream, a);
+    }
     KSR_LAUNCH_CHECK("unet_s2_dgrad");
     return KSR_OK;
 }
