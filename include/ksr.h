@@ -29,7 +29,8 @@ typedef struct ihipStream_t* ksr_stream_t; /* == hipStream_t */
 int ksr_version(void);
 const char* ksr_last_error(void);
 
-/* Precision mode of the kernels below (process-wide, read at launch time):
+/* Precision mode of the kernels below (a property of the CALLING THREAD, read at launch time; every thread starts in
+ * mode 0, so concurrent callers with different modes do not interfere):
  *   0  exact fp32 MFMA, fp32 storage: the mode in which parity with the reference's fp32 results is stated;
  *   1  bf16 MFMA operands with fp32 accumulation (1x1 convs / linears, attention products, weight gradients),
  *      fp32 storage (the reference has no such mode; separately stated tolerance);

@@ -17,8 +17,9 @@ extern "C" int ksr_version(void) { return 100; }
 
 // Precision mode: 0 = exact fp32, 1 = bf16 MFMA operands / fp32 accumulate and storage, 2 = as 1 with the
 // activation and gradient tensors between kernels stored as bf16.
-// Process-wide, read at launch time; the caller sets it before a forward/backward sequence.
-static int g_prec = 0;
+// Per calling thread (a new thread starts in mode 0), read at launch time: the caller sets it before a forward /
+// backward sequence, and two models of different precision driven from two threads do not disturb each other.
+static thread_local int g_prec = 0;
 int ksr_prec() { return g_prec; }
 
 extern "C" int ksr_set_precision(int prec) {

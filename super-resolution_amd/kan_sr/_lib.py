@@ -111,11 +111,14 @@ def check(rc: int, what: str) -> None:
 
 
 def ptr(t: torch.Tensor | None) -> c_void_p:
-    """Device pointer of a contiguous fp32 GPU tensor (None -> NULL)."""
+    """Device pointer of a contiguous GPU tensor (None -> NULL).  float32 everywhere, or bfloat16 for the [N, C]
+    activation tensors of the bf16-storage mode; any other element type would be read as garbage."""
     if t is None:
         return c_void_p(0)
     if not t.is_cuda:
         raise KsrError("libksr ops need GPU tensors (the HIP path is the only path)")
+    if t.dtype is not torch.float32 and t.dtype is not torch.bfloat16:
+        raise KsrError(f"libksr ops need float32 tensors (bfloat16 for bf16-storage activations), got {t.dtype}")
     if not t.is_contiguous():
         raise KsrError("libksr ops need contiguous tensors")
     return c_void_p(t.data_ptr())

@@ -65,6 +65,9 @@ def load_adam_state(ts: TrainStep, opt_state: dict) -> None:
         k = named[full].numel()
         st = opt_state["state"].get(names.index(full))
         if st is not None:
+            if st["exp_avg"].numel() != k or st["exp_avg_sq"].numel() != k:
+                raise KsrError(f"optimizer state of {full}: {st['exp_avg'].numel()} elements in the checkpoint, {k} in the "
+                               "model (a checkpoint of a different layer configuration?)")
             ts.exp_avg[off:off + k].copy_(st["exp_avg"].reshape(-1))
             ts.exp_avg_sq[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
             steps = max(steps, int(float(st["step"])))
@@ -76,6 +79,13 @@ def load_adam_state(ts: TrainStep, opt_state: dict) -> None:
     groups = opt_state.get("param_groups") or [{}]
     ts.lr = float(groups[0].get("lr", ts.lr))
     ts.base_lr = float(groups[0].get("initial_lr", ts.base_lr))
+    # the remaining hyper-parameters travel with the checkpoint as well (torch.optim.Adam's load_state_dict semantics)
+    if "betas" in groups[0]:
+        ts.betas = tuple(float(b) for b in groups[0]["betas"])
+    ts.eps = float(groups[0].get("eps", ts.eps))
+    ts.wd = float(groups[0].get("weight_decay", ts.wd))
+    if groups[0].get("amsgrad") or groups[0].get("maximize"):
+        raise KsrError("the checkpoint's optimizer uses amsgrad / maximize, which the fused Adam step does not implement")
 
 
 def save_checkpoint(model: torch.nn.Module, path: str, epoch: int = 0, global_step: int = 0,

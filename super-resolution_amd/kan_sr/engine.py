@@ -7,6 +7,7 @@ needs, and the backward itself lives in autograd.py (one torch.autograd.Function
 from __future__ import annotations
 
 import ctypes
+import threading
 from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
 from typing import Dict, Optional, Sequence
 
@@ -56,25 +57,25 @@ def _dims(g: Geometry):
 
 
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16s": 2}
-_current_precision = "fp32"
+_tls = threading.local()          # the library keeps the mode per calling thread; so does this mirror of it
 
 
 def set_precision(name: str) -> None:
-    """Precision mode of the kernels for the calls that follow (process-wide):
+    """Precision mode of the kernels for the calls that follow ON THIS THREAD (autograd runs the backward on a thread
+    of its own: every backward entry sets the mode again):
     "fp32"  exact fp32 MFMA, fp32 storage (the parity mode);
     "bf16"  bf16 MFMA operands, fp32 accumulation, fp32 storage;
     "bf16s" as "bf16", and the [N, C] activation / gradient tensors between kernels are stored as bf16
             (the image, the output, per-pixel scalars, parameters and their gradients stay fp32)."""
-    global _current_precision
     if name not in PRECISIONS:
         raise KsrError(f"precision must be one of {sorted(PRECISIONS)}, got {name!r}")
     check(lib().ksr_set_precision(c_int(PRECISIONS[name])), "ksr_set_precision")
-    _current_precision = name
+    _tls.precision = name
 
 
 def act_dtype() -> torch.dtype:
     """Storage type of the activation tensors in the current precision mode."""
-    return torch.bfloat16 if _current_precision == "bf16s" else torch.float32
+    return torch.bfloat16 if getattr(_tls, "precision", "fp32") == "bf16s" else torch.float32
 
 
 def new_seed() -> int:

@@ -125,6 +125,12 @@ class TrainStep:
         # order.  Any other backbone (UNet) runs its backward through the autograd tape; its parameters are laid out in
         # module order and their .grad tensors are views of the flat buffer, exchanged in one bucket.
         self.tape_backward = getattr(model, "backbone", "gazetr") != "gazetr"
+        if not self.tape_backward and getattr(model, "attention", False):
+            raise KsrError("TrainStep covers the plain `feed` head; a model with attention=True trains through "
+                           "autograd (loss.backward() + a torch optimizer)")
+        for n, prm in named.items():
+            if prm.dtype is not torch.float32:
+                raise KsrError(f"TrainStep needs float32 parameters, {n} is {prm.dtype}")
         self.order = [n for n, _ in layer.named_parameters()] if self.tape_backward else FLAT_ORDER
         if self.tape_backward:
             table, off = {}, 0
@@ -169,6 +175,16 @@ class TrainStep:
         m = self.model
         engine.set_precision(m.precision)
         x = x.contiguous()
+        r = m.upscale
+        if x.dim() != 4 or x.shape[1] != 3 or x.dtype is not torch.float32 or not x.is_cuda:
+            raise KsrError(f"TrainStep.step: x must be a float32 GPU tensor [B,3,H,W], got {x.dtype} {tuple(x.shape)}")
+        want = (x.shape[0], r * x.shape[2], r * x.shape[3])
+        if (tgt.dim() != 4 or tgt.dtype is not torch.float32 or tgt.device != x.device or tgt.shape[1] < 1
+                or (tgt.shape[0], tgt.shape[2], tgt.shape[3]) != want
+                or (self.loss_kind == "l1+ssim" and tgt.shape[1] < 3)):
+            raise KsrError(f"TrainStep.step: tgt must be a float32 tensor [{want[0]}, >=1 (3 with the SSIM term), {want[1]}, "
+                           f"{want[2]}] on the input's device, got {tgt.dtype} {tuple(tgt.shape)}")
+        tgt = tgt.contiguous()
         if self.tape_backward:
             return self._step_on_tape(x, tgt)
         g = engine.Geometry(x, m.upscale, m.grid_size, m.spline_order, m.grid_range)
@@ -252,6 +268,12 @@ class TrainStep:
         if tgt.data_ptr() != self._gt.data_ptr():
             self._gt.copy_(tgt)
         if self._graph is None:
+            # A forward of the model between the last Adam step and this recording (validation, a preview) would have
+            # refreshed the kernel-layout weight copies and the eval-mode BatchNorm cache already: the recording would
+            # then lack the launches that rebuild them, and every replay would run on the weights of this moment.
+            encoder = self.model.layers[-1].encoder.encoder
+            if hasattr(encoder, "invalidate_prepared"):
+                encoder.invalidate_prepared()
             graph = torch.cuda.CUDAGraph()
             # thread_local: only this thread's calls are policed while recording.  Other threads of the process (the
             # process group's watchdog polling its events when world_size > 1) would abort a recording in "global" mode.

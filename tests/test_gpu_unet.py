@@ -328,6 +328,42 @@ def test_unet_captured_step_equals_launched_step():
         assert torch.equal(s0[k], s1[k]), k
 
 
+def test_unet_capture_after_an_interleaved_forward_keeps_following_the_weights():
+    """A forward of the model between the last warm-up step and the recording step (a validation or preview call)
+    refreshes the kernel-layout weight copies early; the recording must still contain the launches that rebuild them,
+    or every replay would convolve with the weights of the recording moment."""
+    from kan_sr.module import ConvSepKan
+    from kan_sr.train import TrainStep
+    runs = []
+    for capture in (False, True):
+        torch.manual_seed(34)
+        m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4, backbone="unet").cuda().train()
+        ts = TrainStep(m, lr=1e-2, loss="l1", capture=capture)
+        gen = torch.Generator().manual_seed(8)
+        losses = []
+        for it in range(7):
+            x, tgt = torch.rand(2, 3, 32, 32, generator=gen).cuda(), torch.rand(2, 3, 128, 128, generator=gen).cuda()
+            if it in (2, 4):                       # between warm-up step 2 and the recording step; and between replays
+                with torch.no_grad():
+                    m(x)
+                m.eval()
+                with torch.no_grad():
+                    m(x)
+                m.train()
+            losses.append(float(ts.step(x, tgt)))
+        if capture:
+            assert ts._graph is not None
+        runs.append((losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}))
+    (l0, s0), (l1, s1) = runs
+    assert l0 == l1, (l0, l1)
+    for k in s0:
+        if "num_batches_tracked" in k or "running" in k:
+            continue                               # the interleaved train-mode forwards move these in both runs alike
+        assert torch.equal(s0[k], s1[k]), k
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k
+
+
 def test_unet_training_reduces_the_loss():
     from kan_sr.module import ConvSepKan
     from kan_sr.init import init_like_training_setup
