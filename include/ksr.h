@@ -341,6 +341,18 @@ int ksr_l1_y_loss(const float* pred, int64_t pred_batch_stride, const float* tgt
                   float* grad, int64_t grad_batch_stride, int B, int64_t plane_elems, float grad_scale,
                   float* slab256, float* loss_out, ksr_stream_t stream);
 
+/* ksr_l1_y_loss for callers that cannot allocate device memory (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments without the workspace: the 256
+ * partial sums live in a 1 KB array inside the library's device image, one copy per GPU, held until the process ends; its
+ * address is looked up (hipGetSymbolAddress) on the first call on each device - make that first call outside stream
+ * capture, with the device of `stream` current.  Calls no hipMalloc / hipFree.  B * plane_elems <=
+ * KSR_L1_STATIC_MAX_ELEMS (2^32), larger inputs are rejected with KSR_ERR_ARG.  All calls on one GPU share the array:
+ * calls that overlap on one GPU (two streams, two threads) race. */
+#define KSR_L1_STATIC_MAX_ELEMS ((int64_t)1 << 32)
+int ksr_l1_y_loss_static(const float* pred, int64_t pred_batch_stride, const float* tgt, int64_t tgt_batch_stride,
+                         float* grad, int64_t grad_batch_stride, int B, int64_t plane_elems, float grad_scale,
+                         float* loss_out, ksr_stream_t stream);
+
 /* torch.optim.Adam step (default.py:61) over flat buffers; grads are multiplied by grad_scale first
  * (1/world_size after a sum all-reduce).  step counts from 1. */
 int ksr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

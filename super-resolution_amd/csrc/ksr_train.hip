@@ -1,8 +1,16 @@
 // Training-step support: the Y-plane L1 loss with its gradient, a fused Adam step over the flat
 // parameter buffer, and the gradient all-reduce (RCCL over xGMI).
 #include "ksr_common.h"
+#include "ksr.h"
 #include <math.h>
+#include <atomic>
 #include <rccl/rccl.h>
+
+// Partial sums of ksr_l1_y_loss_static (one float per workgroup, at most 256 workgroups): 1 KB that every GPU the
+// library runs on holds until the process ends.  In host code this name is only a handle for hipGetSymbolAddress;
+// the device address is looked up once per device and kept in g_scratch.
+#define KSR_L1_STATIC_FLOATS 256
+static __device__ __align__(256) float scratch[KSR_L1_STATIC_FLOATS];
 
 namespace {
 
@@ -66,6 +74,45 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
 ncclComm_t g_comm = nullptr;
 int g_nranks = 1;
 
+constexpr int KSR_MAX_DEVICES = 64;
+std::atomic<float*> g_scratch[KSR_MAX_DEVICES];      // device address of `scratch` on each GPU (zero-initialised)
+
+// Address of the current device's copy of `scratch`.  Two threads that race here resolve the same address.
+int scratch_of_current_device(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= KSR_MAX_DEVICES) {
+        ksr_set_error("l1_y_loss_static: no usable current device (%s)", hipGetErrorString(e));
+        return KSR_ERR_HIP;
+    }
+    float* p = g_scratch[dev].load(std::memory_order_acquire);
+    if (p == nullptr) {
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || p == nullptr) {
+            ksr_set_error("l1_y_loss_static: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return KSR_ERR_HIP;
+        }
+        g_scratch[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return KSR_OK;
+}
+
+int l1_launch(const float* pred, int64_t pred_batch_stride, const float* tgt, int64_t tgt_batch_stride, float* grad,
+              int64_t grad_batch_stride, int B, int64_t plane_elems, float grad_scale, float* slab256, float* loss_out,
+              hipStream_t stream) {
+    const long total4 = (long)B * plane_elems / 4;
+    long g = (total4 + 255) / 256;
+    if (g > KSR_L1_STATIC_FLOATS) g = KSR_L1_STATIC_FLOATS;
+    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)g), dim3(256), 0, stream, pred, tgt, grad, (long)plane_elems,
+                       (long)pred_batch_stride, (long)tgt_batch_stride, (long)grad_batch_stride, B, grad_scale, slab256);
+    KSR_LAUNCH_CHECK("l1_y_loss");
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, stream, slab256, (int)g,
+                       1.0f / (float)((double)B * (double)plane_elems), loss_out);
+    KSR_LAUNCH_CHECK("l1_y_loss(finish)");
+    return KSR_OK;
+}
+
 }  // namespace
 
 extern "C" int ksr_l1_y_loss(const float* pred, int64_t pred_batch_stride, const float* tgt, int64_t tgt_batch_stride,
@@ -74,16 +121,28 @@ extern "C" int ksr_l1_y_loss(const float* pred, int64_t pred_batch_stride, const
     KSR_CHECK_ARG(pred && tgt && grad && slab256 && loss_out, "l1_y_loss: null pointer");
     KSR_CHECK_ARG(B > 0 && plane_elems > 0 && plane_elems % 4 == 0 && pred_batch_stride % 4 == 0 &&
                   tgt_batch_stride % 4 == 0 && grad_batch_stride % 4 == 0, "l1_y_loss: sizes must be multiples of 4");
-    const long total4 = (long)B * plane_elems / 4;
-    long g = (total4 + 255) / 256;
-    if (g > 256) g = 256;
-    hipLaunchKernelGGL(l1_kernel, dim3((unsigned)g), dim3(256), 0, stream, pred, tgt, grad, (long)plane_elems,
-                       (long)pred_batch_stride, (long)tgt_batch_stride, (long)grad_batch_stride, B, grad_scale, slab256);
-    KSR_LAUNCH_CHECK("l1_y_loss");
-    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, stream, slab256, (int)g,
-                       1.0f / (float)((double)B * (double)plane_elems), loss_out);
-    KSR_LAUNCH_CHECK("l1_y_loss(finish)");
-    return KSR_OK;
+    return l1_launch(pred, pred_batch_stride, tgt, tgt_batch_stride, grad, grad_batch_stride, B, plane_elems, grad_scale,
+                     slab256, loss_out, stream);
+}
+
+// The same loss for callers that cannot allocate: the partial sums live in this library's own `scratch` array instead of
+// a caller-provided workspace.  Every partial sum the finish kernel reads is written by the first kernel of the same
+// call, so nothing has to be cleared between calls.  Calls that overlap on one GPU share the array and race.
+extern "C" int ksr_l1_y_loss_static(const float* pred, int64_t pred_batch_stride, const float* tgt, int64_t tgt_batch_stride,
+                                    float* grad, int64_t grad_batch_stride, int B, int64_t plane_elems, float grad_scale,
+                                    float* loss_out, hipStream_t stream) {
+    KSR_CHECK_ARG(pred && tgt && grad && loss_out, "l1_y_loss_static: null pointer");
+    KSR_CHECK_ARG(B > 0 && plane_elems > 0 && plane_elems % 4 == 0 && pred_batch_stride % 4 == 0 &&
+                  tgt_batch_stride % 4 == 0 && grad_batch_stride % 4 == 0, "l1_y_loss_static: sizes must be multiples of 4");
+    KSR_CHECK_ARG((int64_t)B * plane_elems <= KSR_L1_STATIC_MAX_ELEMS,
+                  "l1_y_loss_static: %lld elements exceed the maximum of %lld (2^32) this entry point accepts: each of its %d "
+                  "partial sums would add more than 2^24 fp32 terms; use ksr_l1_y_loss",
+                  (long long)B * (long long)plane_elems, (long long)KSR_L1_STATIC_MAX_ELEMS, KSR_L1_STATIC_FLOATS);
+    float* slab = nullptr;
+    const int rc = scratch_of_current_device(&slab);
+    if (rc != KSR_OK) return rc;
+    return l1_launch(pred, pred_batch_stride, tgt, tgt_batch_stride, grad, grad_batch_stride, B, plane_elems, grad_scale, slab,
+                     loss_out, stream);
 }
 
 extern "C" int ksr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

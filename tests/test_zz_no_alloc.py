@@ -1,0 +1,52 @@
+"""The allocation-free entry point ksr_l1_y_loss_static (partial sums in the library's own device array) against
+ksr_l1_y_loss (caller-provided workspace), through the C ABI: bit-equal loss and gradient on two calls in a row, the
+second with a smaller input (the array keeps the first call's partial sums), and the size limit."""
+from ctypes import c_float, c_int, c_int64
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(B, C, Hh, Wh, seed):
+    from kan_sr._lib import check, lib, ptr, stream
+    L = lib()
+    g = torch.Generator().manual_seed(seed)
+    pred = torch.rand(B, 3, Hh, Wh, generator=g).cuda()
+    tgt = torch.rand(B, C, Hh, Wh, generator=g).cuda()
+    tgt[0, 0, 0, :8] = pred[0, 0, 0, :8]                  # exact ties: gradient 0
+    plane = Hh * Wh
+    ga = torch.full((B, plane), float("nan"), device="cuda")
+    gb = torch.full((B, plane), float("nan"), device="cuda")
+    la = torch.full((1,), float("nan"), device="cuda")
+    lb = torch.full((1,), float("nan"), device="cuda")
+    slab = torch.empty(256, device="cuda")
+    check(L.ksr_l1_y_loss(ptr(pred), c_int64(3 * plane), ptr(tgt), c_int64(C * plane), ptr(ga), c_int64(plane), c_int(B),
+                          c_int64(plane), c_float(1.0), ptr(slab), ptr(la), stream()), "ksr_l1_y_loss")
+    before = torch.cuda.memory_allocated()
+    check(L.ksr_l1_y_loss_static(ptr(pred), c_int64(3 * plane), ptr(tgt), c_int64(C * plane), ptr(gb), c_int64(plane),
+                                 c_int(B), c_int64(plane), c_float(1.0), ptr(lb), stream()), "ksr_l1_y_loss_static")
+    assert torch.cuda.memory_allocated() == before
+    torch.cuda.synchronize()
+    ref = (pred[:, 0] - tgt[:, 0]).abs().mean()
+    assert abs(float(la) - float(ref)) <= 1e-6
+    assert torch.equal(la, lb), (float(la), float(lb))
+    assert torch.equal(ga, gb)
+    assert float(ga.abs().sum()) > 0 and float(ga[0, :8].abs().sum()) == 0.0
+
+
+def test_static_l1_equals_workspace_l1_twice_second_smaller():
+    _both(6, 3, 256, 384, seed=1)       # 256 workgroups: every partial sum of the array is written
+    _both(1, 1, 8, 12, seed=2)          # one workgroup: the other 255 entries keep the first call's sums
+    _both(3, 3, 64, 100, seed=3)
+
+
+def test_static_l1_rejects_sizes_beyond_its_maximum():
+    from kan_sr._lib import lib, ptr, stream
+    L = lib()
+    t = torch.zeros(16, device="cuda")
+    rc = L.ksr_l1_y_loss_static(ptr(t), c_int64(4), ptr(t), c_int64(4), ptr(t), c_int64(4), c_int(1 << 20),
+                                c_int64((1 << 12) + 4), c_float(1.0), ptr(t), stream())
+    assert rc == -1
+    assert b"exceed the maximum" in L.ksr_last_error()
