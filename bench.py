@@ -6,7 +6,8 @@
 One JSON line on stdout (rank 0).  Workloads (synthetic data, random-init weights, seeds fixed):
   train : (default) x4 SR training step (forward + L1(Y) + backward + RCCL gradient all-reduce when N>1 +
           Adam), 64 patches of 128x128 per GPU (weak scaling: the per-rank batch semantics of the
-          reference's trainer), dropout live.  At N=1 the line also carries "inference": the 1-GPU
+          reference's trainer), dropout live.  --scaling strong: a global batch of 64 patches split over the N GPUs
+          (64/N per GPU).  --graph replays the step from a HIP graph.  At N=1 the line also carries "inference": the 1-GPU
           960x540 -> 3840x2160 frame rate, the second half of BASELINE.json's metric.
   infer : x4 SR inference, fp32, eval, one 960x540 YCbCr frame -> 3840x2160 per step and GPU
           (BASELINE config "x4 SR inference, 1xMI355X, fp32, 1080p->4K"); N>1 = N independent replicas.
@@ -207,6 +208,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train", "train-unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default=os.environ.get("KSR_BENCH_SCALING", "weak"), choices=["weak", "strong"],
+                    help="train: weak = 64 patches per GPU (default); strong = a global batch of 64 patches split over the GPUs")
+    ap.add_argument("--per-gpu-batch", type=int, default=0, help="train: override the per-GPU batch (tools / sweeps)")
+    ap.add_argument("--graph", action="store_true", help="train: replay the step (forward + loss + backward + Adam) from a HIP graph")
     ap.add_argument("--no-graph", action="store_true", help="train-unet: launch every kernel from the host instead of replaying the step's HIP graph")
     ap.add_argument("--loss", default=os.environ.get("KSR_BENCH_LOSS", "l1+ssim"), choices=["l1", "l1+ssim"],
                     help="training loss: the reference's training_step loss L1(Y) + 0.15 (1 - SSIM) (default) or L1(Y) only")
@@ -228,7 +233,9 @@ def main():
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group("nccl", device_id=dev)
+        # a CPU group carries the barrier, the timing reduction and the RCCL unique id: the only RCCL communicator of the
+        # process is the one the training step owns (kan_sr.train.RcclComm)
+        dist.init_process_group("gloo")
 
     from kan_sr import _lib, engine
     _lib.lib()   # fail loudly if the HIP library is missing
@@ -250,22 +257,33 @@ def main():
     else:
         from kan_sr.train import TrainStep
         B, H, W = (8, 256, 256) if unet else (64, 128, 128)
+        if args.scaling == "strong" and not unet:
+            if 64 % world:
+                raise SystemExit("--scaling strong splits a global batch of 64: the GPU count must divide it")
+            B = 64 // world
+        if args.per_gpu_batch > 0:
+            B = args.per_gpu_batch
+        # UNet: ~470 small launches, bound by the host's launch rate: replay a HIP graph.  GazeTR: measured no gain from
+        # replaying (B = 8: 1.33 ms replayed, 1.30 ms launched: the ~130 kernels are bound by the GPU), so only on request.
+        graph = unet or args.graph
         model.train()
         model.precision = args.precision
         x = torch.rand(B, 3, H, W, device=dev)
         tgt = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
         # UNet step: forward + loss + backward replayed from a HIP graph (recorded on the third step; the step is bound by
         # the host's launch rate otherwise).  The per-kernel timing run further down runs uncaptured.
-        ts = TrainStep(model, world_size=world, rank=rank, loss=args.loss, capture=unet and not args.no_graph)
+        ts = TrainStep(model, world_size=world, rank=rank, loss=args.loss, capture=graph and not args.no_graph)
         mode = {"fp32": "exact fp32", "bf16": "bf16 MFMA operands / fp32 accumulate and storage",
                 "bf16s": "bf16 MFMA operands and activation storage / fp32 accumulate"}[args.precision]
-        wl = (f"x4 SR training step, {mode} (fwd + loss {args.loss} + bwd + RCCL gradient all-reduce + Adam), 64 patches of 128x128 per "
-              "GPU (BASELINE configs[2], per-rank batch), dropout live")
+        wl = (f"x4 SR training step, {mode} (fwd + loss {args.loss} + bwd + RCCL gradient all-reduce + Adam), {B} patches of 128x128 per "
+              "GPU (BASELINE configs[2], " + ("per-rank batch" if args.scaling == "weak" else f"global batch {B * world} split over the GPUs")
+              + "), dropout live" + ("; step replayed from a HIP graph" if graph and not args.no_graph else ""))
+        if graph:
+            args.warmup = max(args.warmup, 3)     # the graph is recorded on the third step
         if unet:
             wl = (f"x4 SR training step with the UNet hyper-encoder, exact fp32 (fwd + loss {args.loss} + bwd + RCCL gradient "
                   "all-reduce + Adam), 8 patches of 256x256 per GPU, BatchNorm on per-rank batch statistics"
                   + ("" if args.no_graph else "; forward + loss + backward replayed from one HIP graph"))
-            args.warmup = max(args.warmup, 3)     # the graph is recorded on the third step
 
         def step():
             return ts.step(x, tgt)
@@ -285,7 +303,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -386,7 +404,7 @@ def main():
         print(json.dumps({
             "metric": "output megapixels/sec", "value": round(value, 3), "unit": "MP/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16" if (args.workload == "train" and args.precision != "fp32") else "f32",
             "data": "synthetic", "config": {"workload": wl, "upscale": 4, "grid_size": 5, "spline_order": 3,
                                             "per_gpu_batch": B, "lr_patch": [H, W]},

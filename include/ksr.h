@@ -359,6 +359,18 @@ int ksr_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
                   float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
                   ksr_stream_t stream);
 
+/* The same step for recorded HIP graphs, whose by-value arguments are frozen: the step count (from 1) and the learning
+ * rate are read from device memory at execution time.  Bias corrections are evaluated on the device in fp64. */
+int ksr_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                      const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                      const uint64_t* step_dev, float grad_scale, ksr_stream_t stream);
+
+/* Dropout stream id from device memory, for the same reason: while the CALLING THREAD has a device word set here, every
+ * entry point with a (p_drop, seed) pair draws its masks from seed + word * 0x9E3779B97F4A7C15 (the word is read when
+ * the kernel executes); the forward and backward entry points of one step must see the same word.  NULL (the default)
+ * switches this off.  The train-mode dropout of gazetr.py:37-49,77 has no such notion: torch's generator advances. */
+int ksr_set_dropout_seed_source(const uint64_t* device_word);
+
 /* Gradient exchange: one RCCL communicator per process (one process per GPU).  Rank 0 creates the
  * 128-byte id, every rank calls ksr_comm_init with it; ksr_allreduce_sum is an in-place fp32 sum. */
 int ksr_comm_unique_id(void* out128);

@@ -29,3 +29,12 @@ extern "C" int ksr_set_precision(int prec) {
 }
 
 extern "C" int ksr_get_precision(void) { return g_prec; }
+
+// Per calling thread, like the precision mode: NULL (the default) = the by-value seeds are used as they are.
+static thread_local const unsigned long long* g_seed_dev = nullptr;
+const unsigned long long* ksr_seed_dev() { return g_seed_dev; }
+
+extern "C" int ksr_set_dropout_seed_source(const uint64_t* device_word) {
+    g_seed_dev = reinterpret_cast<const unsigned long long*>(device_word);
+    return KSR_OK;
+}

@@ -10,6 +10,7 @@ struct AttnArgs {
     int S, Sp, HW;
     float p_drop;
     unsigned long long seed;
+    const unsigned long long* seed_dev;   // optional device word mixed into `seed` at kernel start (ksr_set_dropout_seed_source)
 };
 
 struct AttnBwdArgs {
@@ -20,6 +21,7 @@ struct AttnBwdArgs {
     int S, Sp, HW;
     float p_drop;
     unsigned long long seed;
+    const unsigned long long* seed_dev;   // optional device word mixed into `seed` at kernel start (ksr_set_dropout_seed_source)
 };
 
 // key (or query) index inside a 32-slot block held by accumulator register r of lane half h

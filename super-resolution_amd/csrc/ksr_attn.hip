@@ -24,6 +24,7 @@ struct __attribute__((aligned(16))) AttnSmem {
 
 template <int NW>   // key blocks per query: Sp / 32 (1 when Sp <= 32)
 __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnArgs a) {
+    KSR_MIX_SEED(a);
     __shared__ AttnSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -204,6 +205,7 @@ __device__ __forceinline__ void store_acc_dims(float* __restrict__ dst, int h, c
 
 template <int NW, bool DROP>
 __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnBwdArgs a) {
+    KSR_MIX_SEED(a);
     __shared__ AttnBwdSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -380,7 +382,7 @@ extern "C" int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, f
     KSR_CHECK_ARG(qkv && ctx && S > 0 && HW > 0, "batch_attn_fwd: bad argument");
     KSR_UNSUPPORTED(S > 128, "batch_attn_fwd: local batch %d > 128 not supported", S);
     KSR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "batch_attn_fwd: dropout p must be in [0,1)");
-    AttnArgs a{qkv, ctx, S, padded_S(S), HW, p_drop, seed};
+    AttnArgs a{qkv, ctx, S, padded_S(S), HW, p_drop, seed, ksr_seed_dev()};
     const int PPW = 128 / a.Sp;
     const int ntiles = (HW + PPW - 1) / PPW;
     const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), block(256);
@@ -401,7 +403,7 @@ extern "C" int ksr_batch_attn_bwd(const float* qkv, const float* ctx, const floa
                                   float p_drop, uint64_t seed, hipStream_t stream) {
     KSR_CHECK_ARG(qkv && ctx && dctx && dqkv && S > 0 && HW > 0, "batch_attn_bwd: bad argument");
     KSR_UNSUPPORTED(S > 128, "batch_attn_bwd: local batch %d > 128 not supported", S);
-    AttnBwdArgs a{qkv, ctx, dctx, dqkv, S, padded_S(S), HW, p_drop, seed};
+    AttnBwdArgs a{qkv, ctx, dctx, dqkv, S, padded_S(S), HW, p_drop, seed, ksr_seed_dev()};
     const int PPW = 128 / a.Sp;
     const int ntiles = (HW + PPW - 1) / PPW;
     const dim3 grid((unsigned)(ntiles < 512 ? ntiles : 512)), block(256);

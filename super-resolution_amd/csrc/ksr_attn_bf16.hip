@@ -193,6 +193,7 @@ struct __attribute__((aligned(16))) FwdSmem {
 
 template <int NW, class ST>
 __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
+    KSR_MIX_SEED(a);
     __shared__ FwdSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, g = lane >> 5;
@@ -308,6 +309,7 @@ __device__ __forceinline__ void put_rows(__bf16* __restrict__ rows, int slot, in
 
 template <int NW, bool DROP, class ST>
 __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
+    KSR_MIX_SEED(a);
     __shared__ BwdSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, g = lane >> 5;

@@ -11,6 +11,15 @@
 #define KSR_ERR_HIP (-3)
 #define KSR_ERR_COMM (-4)
 
+// Dropout stream id that changes without a new kernel argument (a recorded HIP graph replays its arguments): when the
+// calling thread has named a device word (ksr_set_dropout_seed_source), every kernel that draws dropout masks adds
+// word * odd constant to its by-value seed before use.  Forward and backward kernels of one step read the same word.
+const unsigned long long* ksr_seed_dev();
+#define KSR_MIX_SEED(a)                                                        \
+    do {                                                                       \
+        if ((a).seed_dev) (a).seed += *(a).seed_dev * 0x9E3779B97F4A7C15ULL;   \
+    } while (0)
+
 #define KSR_MAX_KNOTS 64
 #define KSR_MAX_ORDER 3
 

@@ -71,6 +71,30 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// The same step with the step count and the learning rate read from device memory (a recorded HIP graph replays its
+// by-value arguments; these two change every step / every epoch).
+__global__ void __launch_bounds__(256) adam_dev_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ m, float* __restrict__ v, long n,
+                                                       const float* __restrict__ lr_dev, float beta1, float beta2, float eps,
+                                                       float wd, const unsigned long long* __restrict__ step_dev,
+                                                       float gscale) {
+    const double st = (double)*step_dev;
+    const float bc1 = (float)(1.0 - pow((double)beta1, st));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, st));
+    const float lr = *lr_dev;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gscale;
+        const float pi = p[i];
+        if (wd != 0.f) gi += wd * pi;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = pi - (lr / bc1) * (mi / denom);
+    }
+}
+
 ncclComm_t g_comm = nullptr;
 int g_nranks = 1;
 
@@ -156,6 +180,19 @@ extern "C" int ksr_adam_step(float* params, const float* grads, float* exp_avg, 
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)g), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, (long)n,
                        lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
     KSR_LAUNCH_CHECK("adam_step");
+    return KSR_OK;
+}
+
+extern "C" int ksr_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 const float* lr_dev, float beta1, float beta2, float eps, float weight_decay,
+                                 const uint64_t* step_dev, float grad_scale, hipStream_t stream) {
+    KSR_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && lr_dev && step_dev && n > 0, "adam_step_dev: bad argument");
+    long g = (n + 255) / 256;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3((unsigned)g), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, (long)n,
+                       lr_dev, beta1, beta2, eps, weight_decay, reinterpret_cast<const unsigned long long*>(step_dev),
+                       grad_scale);
+    KSR_LAUNCH_CHECK("adam_step_dev");
     return KSR_OK;
 }
 

@@ -34,6 +34,7 @@ struct TxArgs {
     float eps;
     float p_drop;                 // 0 in eval mode
     unsigned long long seed;      // dropout stream id
+    const unsigned long long* seed_dev;   // optional device word mixed into `seed` at kernel start (ksr_set_dropout_seed_source)
 };
 
 constexpr int KV_LD = 132;        // floats per slot: [h0: k32 v32][h1: k32 v32] + 4 pad
@@ -72,6 +73,7 @@ __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* 
 // exchange buffer in LDS (4x the occupancy).  MODE 2: see TxSmem.
 template <int PREC, bool TRAIN, int MODE>
 __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(TxArgs a) {
+    KSR_MIX_SEED(a);
     using ST = typename KsrStore<PREC>::T;
     constexpr bool POST = MODE != 0;          // row tiles, coalesced loads / stores, no cross-token step
     __shared__ TxSmem<MODE> sm;
@@ -348,7 +350,7 @@ extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* 
         a.sv_qkv = saves[0]; a.sv_ctx = saves[1]; a.sv_xhat1 = saves[2]; a.sv_rstd1 = saves[3]; a.sv_s1 = saves[4];
         a.sv_hmid = saves[5]; a.sv_xhat2 = saves[6]; a.sv_rstd2 = saves[7]; a.sv_xhatf = saves[8]; a.sv_rstdf = saves[9];
     }
-    a.S = S; a.HW = HW; a.eps = eps; a.p_drop = p_drop; a.seed = seed;
+    a.S = S; a.HW = HW; a.eps = eps; a.p_drop = p_drop; a.seed = seed; a.seed_dev = ksr_seed_dev();
     const int PPW = 128 / S;
     const int ntiles = (HW + PPW - 1) / PPW;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
@@ -391,7 +393,7 @@ extern "C" int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, fl
         a.sv_xhat1 = saves[2]; a.sv_rstd1 = saves[3]; a.sv_s1 = saves[4];
         a.sv_hmid = saves[5]; a.sv_xhat2 = saves[6]; a.sv_rstd2 = saves[7]; a.sv_xhatf = saves[8]; a.sv_rstdf = saves[9];
     }
-    a.S = 1; a.HW = (int)N; a.eps = eps; a.p_drop = p_drop; a.seed = seed;
+    a.S = 1; a.HW = (int)N; a.eps = eps; a.p_drop = p_drop; a.seed = seed; a.seed_dev = ksr_seed_dev();
     const long ntiles = (N + 127) / 128;
     const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
     const bool train = saves || p_drop > 0.f;

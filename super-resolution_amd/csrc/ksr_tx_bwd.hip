@@ -21,6 +21,7 @@ struct TxBwdTokArgs {
     long N;
     float p_drop;
     unsigned long long seed;
+    const unsigned long long* seed_dev;   // optional device word mixed into `seed` at kernel start (ksr_set_dropout_seed_source)
 };
 
 struct __attribute__((aligned(16))) TxBwdTokSmem {
@@ -47,6 +48,7 @@ __device__ __forceinline__ void ln_bwd(const float (&dy)[32], const float* __res
 
 template <int PREC>
 __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
+    KSR_MIX_SEED(a);
     using ST = typename KsrStore<PREC>::T;
     __shared__ TxBwdTokSmem sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -205,12 +207,14 @@ struct TxBwdAttnArgs {
     int S, HW;
     float p_drop;
     unsigned long long seed;
+    const unsigned long long* seed_dev;   // optional device word mixed into `seed` at kernel start (ksr_set_dropout_seed_source)
 };
 
 constexpr int XLD = 140;     // floats per slot in the exchange buffer (2 x 68 + 4 pad)
 
 template <class ST>   // storage type of qkv / ctx / dctx / dqkv
 __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
+    KSR_MIX_SEED(a);
     __shared__ __attribute__((aligned(16))) float xb[128 * XLD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
@@ -367,7 +371,7 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     KSR_CHECK_ARG(!ln_slab || (ln_grads && ln_row_stride >= 64), "batch_tx_layer_bwd_token: ln_slab needs ln_grads and a row stride >= 64");
     a.ln_slab = ln_slab;
     KSR_CHECK_ARG(!(p_drop > 0.f) || a.da, "batch_tx_layer_bwd_token: dropout needs the da output");
-    a.N = (long)N; a.p_drop = p_drop; a.seed = seed;
+    a.N = (long)N; a.p_drop = p_drop; a.seed = seed; a.seed_dev = ksr_seed_dev();
     const long ntiles = (N + 127) / 128;
 #define KSR_CALL(P) hipLaunchKernelGGL(tx_bwd_token_kernel<P>, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a)
     KSR_DISPATCH_PREC(KSR_CALL);
@@ -385,7 +389,7 @@ extern "C" int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, c
                                            int HW, float p_drop, uint64_t seed, hipStream_t stream) {
     KSR_CHECK_ARG(qkv && ctx && dctx && dqkv && S > 0 && HW > 0, "batch_tx_layer_bwd_attn: bad argument");
     KSR_UNSUPPORTED(S > 128, "batch_tx_layer_bwd_attn: local batch %d > 128 not supported", S);
-    TxBwdAttnArgs a{qkv, ctx, dctx, dqkv, S, HW, p_drop, seed};
+    TxBwdAttnArgs a{qkv, ctx, dctx, dqkv, S, HW, p_drop, seed, ksr_seed_dev()};
     const int PPW = 128 / S;
     const int ntiles = (HW + PPW - 1) / PPW;
     if (ksr_prec() == KSR_BF16S) hipLaunchKernelGGL(tx_bwd_attn_kernel<__bf16>, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, stream, a);

@@ -90,7 +90,7 @@ EXPORTS = [
     "ksr_batch_attn_bwd",
     "ksr_in_proj_bwd", "ksr_gate_pw_bwd", "ksr_fn1_bwd", "ksr_pw2_bwd", "ksr_pw1_bwd",
     "ksr_wgrad_slab_floats", "ksr_wgrad", "ksr_colreduce", "ksr_dwconv_wgrad", "ksr_stem_scalar_wgrad", "ksr_outer2",
-    "ksr_l1_y_loss", "ksr_l1_y_loss_static", "ksr_adam_step", "ksr_comm_unique_id", "ksr_comm_init", "ksr_allreduce_sum", "ksr_comm_nranks",
+    "ksr_l1_y_loss", "ksr_l1_y_loss_static", "ksr_adam_step", "ksr_adam_step_dev", "ksr_set_dropout_seed_source", "ksr_comm_unique_id", "ksr_comm_init", "ksr_allreduce_sum", "ksr_comm_nranks",
     "ksr_comm_destroy",
     "ksr_pointwise_bwd", "ksr_chan_dw_fwd", "ksr_chan_dw_bwd", "ksr_gram_slab_floats", "ksr_gram_batched",
     "ksr_chan_soft_fwd", "ksr_chan_soft_bwd", "ksr_sum_entries", "ksr_chan_apply",

@@ -49,14 +49,14 @@ class _Ws:
     are enqueued on a second stream, so that they fill the ramp-up / tail of the chain's kernels instead of
     lengthening it; `join()` makes the main stream wait for them."""
 
-    def __init__(self, dev, arena=None, n_tokens=0):
+    def __init__(self, dev, arena=None, n_tokens=0, allow_side_stream=True):
         self.dev = dev
         self._slab = None
         self._ln_slab = None
         self._sums_slab = None
         self.arena = arena
         # small problems are bound by the host's launch rate, where the extra stream bookkeeping only costs
-        self.wstream = _side_stream(dev) if (SIDE_STREAM_FOR_WGRAD and dev.type == "cuda"
+        self.wstream = _side_stream(dev) if (SIDE_STREAM_FOR_WGRAD and allow_side_stream and dev.type == "cuda"
                                              and n_tokens >= SIDE_STREAM_MIN_TOKENS) else None
 
     @contextlib.contextmanager
@@ -259,14 +259,14 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
 
 def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str,
                  g: Geometry, sv: dict, save_us: torch.Tensor, p_drop: float, seed: int, arena=None,
-                 on_tail_done=None) -> Dict[str, torch.Tensor]:
+                 on_tail_done=None, allow_side_stream: bool = True) -> Dict[str, torch.Tensor]:
     """gout: gradient of the Y plane of the output (images gout_batch_stride elements apart).
     arena: optional name -> view map; gradients are then written in place.  on_tail_done() is called
     once the gradients of feed + both transformer layers + the final norm have been enqueued (the
     first all-reduce bucket), while the conv-trunk backward is still to come."""
     L = lib()
     N = g.N
-    ws = _Ws(x.device, arena, g.N)
+    ws = _Ws(x.device, arena, g.N, allow_side_stream)      # one stream while a HIP graph is being recorded
     grads: Dict[str, torch.Tensor] = {}
     # ---- feed + KAN ----
     lane_len = int(L.ksr_feed_kan_lane_len(c_int(g.r), c_int(g.n_coef)))

@@ -14,6 +14,7 @@ so no activation crosses GPUs: the only exchange is the gradient all-reduce.
 from __future__ import annotations
 
 import ctypes
+from collections import OrderedDict
 from ctypes import c_float, c_int, c_int64, c_void_p
 from typing import Callable, Dict, List, Optional
 
@@ -61,8 +62,9 @@ def shard_batch(global_batch: int, world_size: int, rank: int):
 
 
 class RcclComm:
-    """Gradient exchange through libksr's RCCL wrapper.  The 128-byte unique id travels over the
-    torch.distributed process group that the launcher (torchrun) already set up."""
+    """Gradient exchange through libksr's RCCL wrapper: the process's only RCCL communicator.  The 128-byte unique id
+    travels over the torch.distributed process group the launcher set up; a CPU (gloo) group is enough and keeps a
+    second RCCL communicator out of the process."""
 
     def __init__(self, rank: int, world_size: int):
         import torch.distributed as dist
@@ -70,7 +72,8 @@ class RcclComm:
         buf = (ctypes.c_ubyte * 128)()
         if rank == 0:
             check(L.ksr_comm_unique_id(buf), "ksr_comm_unique_id")
-        idt = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device="cuda")
+        on_gpu = dist.get_backend() == "nccl"
+        idt = torch.tensor(list(bytes(buf)), dtype=torch.uint8, device="cuda" if on_gpu else "cpu")
         dist.broadcast(idt, src=0)
         raw = bytes(idt.cpu().tolist())
         check(L.ksr_comm_init(c_int(rank), c_int(world_size), ctypes.c_char_p(raw)), "ksr_comm_init")
@@ -99,19 +102,28 @@ class GlooComm:
 
 
 class TrainStep:
+    MAX_GRAPHS = 4          # recorded input shapes kept at once (least recently used is dropped)
+
     def __init__(self, model, world_size: int = 1, rank: int = 0, lr: float = 1e-3, betas=(0.9, 0.999),
-                 eps: float = 1e-8, weight_decay: float = 0.0, comm=None, loss: str = "l1", capture: bool = False):
-        """capture (backbones that run their backward on the tape, i.e. UNet): after two ordinary steps at a given
-        input shape, forward + loss + backward are recorded once into a HIP graph and replayed from then on, so that
-        the ~470 launches of a step cost the host one call (the step is bound by the host's launch rate up to 8
-        patches of 256x256 per GPU).  The gradient all-reduce and Adam stay outside the graph (the step counter and
-        lr are by-value kernel arguments).  Inputs are copied into the graph's own buffers unless the caller passes
-        the same tensors again.  While _lib.PROFILE collects per-call events the step runs uncaptured."""
+                 eps: float = 1e-8, weight_decay: float = 0.0, comm=None, loss: str = "l1", capture: bool = False,
+                 device_state: Optional[bool] = None):
+        """capture: after two ordinary steps at a given input shape, forward + loss + backward (and, when nothing has
+        to be exchanged between GPUs first, Adam) are recorded once into a HIP graph and replayed from then on, so
+        that the 130 (GazeTR) to 470 (UNet) launches of a step cost the host one call: small per-GPU batches are bound
+        by the host's launch rate otherwise.  Up to MAX_GRAPHS input shapes stay recorded.  Inputs are copied into the
+        graph's own buffers unless the caller passes the same tensors again; `loss` / `out` of a replayed step alias
+        graph-owned memory that the next replay of that shape overwrites.  While _lib.PROFILE collects per-call events
+        the step runs unrecorded.
+
+        device_state (default: capture, for the GazeTR encoder): the step counter, the learning rate and the dropout
+        stream word live in device memory (a recorded graph replays its by-value arguments): Adam runs as
+        ksr_adam_step_dev, the dropout masks of step t come from a seed drawn once at construction mixed with the step
+        counter.  The UNet encoder (no dropout) keeps Adam outside its graph with by-value arguments."""
         if loss not in ("l1", "l1+ssim"):
             raise KsrError(f"loss must be 'l1' or 'l1+ssim', got {loss!r}")
         self.loss_kind = loss
         self.capture = capture
-        self._graph, self._graph_key, self._graph_warm = None, None, 0
+        self._graphs: "OrderedDict" = OrderedDict()
         self.base_lr = lr
         self.model = model
         self.world_size, self.rank = world_size, rank
@@ -131,6 +143,10 @@ class TrainStep:
         for n, prm in named.items():
             if prm.dtype is not torch.float32:
                 raise KsrError(f"TrainStep needs float32 parameters, {n} is {prm.dtype}")
+        self.device_state = (capture and not self.tape_backward) if device_state is None else bool(device_state)
+        if capture and not self.tape_backward and not self.device_state:
+            raise KsrError("capture=True with the GazeTR encoder needs device_state: a recorded graph would replay one "
+                           "dropout seed and one Adam step count for ever")
         self.order = [n for n, _ in layer.named_parameters()] if self.tape_backward else FLAT_ORDER
         if self.tape_backward:
             table, off = {}, 0
@@ -159,7 +175,12 @@ class TrainStep:
         if self.tape_backward and hasattr(layer, "grad_sink"):
             # the backbone's backward writes each parameter gradient straight into its view (no accumulation pass)
             layer.grad_sink = {n: self.arena[self.pre + n] for n in self.order}
-        self.steps = 0
+        self._steps = 0
+        if self.device_state:
+            self._ctr = torch.zeros(1, device=dev, dtype=torch.int64)        # step counter = dropout stream word
+            self._lr_dev = torch.full((1,), float(lr), device=dev, dtype=torch.float32)
+            self._lr_on_dev = float(lr)
+            self._seed_base = engine.new_seed()
         self.comm = comm
         if world_size > 1 and comm is None:
             self.comm = RcclComm(rank, world_size)
@@ -169,9 +190,27 @@ class TrainStep:
         self.loss = self._l1
         self.last_seed = 0
 
+    @property
+    def steps(self) -> int:
+        return self._steps
+
+    @steps.setter
+    def steps(self, value: int) -> None:
+        """Optimisation steps taken so far (Adam's bias correction; restored by a checkpoint)."""
+        self._steps = int(value)
+        if self.device_state:
+            self._ctr.fill_(self._steps)
+
+    @property
+    def _graph(self):
+        """The most recently used recorded graph (None before the first recording)."""
+        for ent in reversed(self._graphs.values()):
+            if ent["graph"] is not None:
+                return ent["graph"]
+        return None
+
     def step(self, x: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
         """One optimisation step on this rank's shard.  Returns the (device) loss tensor of the shard."""
-        L = lib()
         m = self.model
         engine.set_precision(m.precision)
         x = x.contiguous()
@@ -185,11 +224,76 @@ class TrainStep:
             raise KsrError(f"TrainStep.step: tgt must be a float32 tensor [{want[0]}, >=1 (3 with the SSIM term), {want[1]}, "
                            f"{want[2]}] on the input's device, got {tgt.dtype} {tuple(tgt.shape)}")
         tgt = tgt.contiguous()
+        if self.device_state and self._lr_on_dev != float(self.lr):
+            self._lr_dev.fill_(float(self.lr))
+            self._lr_on_dev = float(self.lr)
+        if self.capture and _lib.PROFILE is None:
+            exchanged = self._replay(x, tgt)
+        else:
+            exchanged = self._body(x, tgt, overlap_comm=True)
+        if self.side is not None and not exchanged:
+            main = torch.cuda.current_stream()
+            self.side.wait_stream(main)
+            self.comm.allreduce_sum(self.flat_g, c_void_p(self.side.cuda_stream))
+            main.wait_stream(self.side)
+        self._steps += 1
+        if not self._adam_in_body():
+            self._adam()
         if self.tape_backward:
-            return self._step_on_tape(x, tgt)
+            encoder = m.layers[-1].encoder.encoder
+            if hasattr(encoder, "invalidate_prepared"):
+                encoder.invalidate_prepared()         # the weights changed under the cached kernel layouts
+        return self.loss
+
+    def _adam_in_body(self) -> bool:
+        return self.device_state and self.comm is None
+
+    def _adam(self) -> None:
+        L = lib()
+        if self.device_state:
+            check(L.ksr_adam_step_dev(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                                      c_int64(self.flat_p.numel()), ptr(self._lr_dev), c_float(self.betas[0]),
+                                      c_float(self.betas[1]), c_float(self.eps), c_float(self.wd),
+                                      c_void_p(self._ctr.data_ptr()), c_float(1.0 / self.world_size), stream()),
+                  "ksr_adam_step_dev")
+            return
+        check(L.ksr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
+                              c_int64(self.flat_p.numel()), c_float(self.lr), c_float(self.betas[0]),
+                              c_float(self.betas[1]), c_float(self.eps), c_float(self.wd), c_int(self._steps),
+                              c_float(1.0 / self.world_size), stream()), "ksr_adam_step")
+
+    def _body(self, x: torch.Tensor, tgt: torch.Tensor, overlap_comm: bool) -> bool:
+        """Forward + loss + backward of one step (+ Adam when its inputs are device-resident and nothing has to be
+        exchanged first): the part of a step that a HIP graph can hold.  Returns whether the gradients were already
+        exchanged (the two overlapped buckets of the GazeTR path)."""
+        L = lib()
+        if self.device_state:
+            self._ctr.add_(1)
+            check(L.ksr_set_dropout_seed_source(c_void_p(self._ctr.data_ptr())), "ksr_set_dropout_seed_source")
+        try:
+            if self.tape_backward:
+                self._forward_backward_on_tape(x, tgt)
+                exchanged = False
+            else:
+                exchanged = self._forward_backward_native(x, tgt, overlap_comm)
+        finally:
+            if self.device_state:
+                L.ksr_set_dropout_seed_source(c_void_p(0))
+        if self._adam_in_body():
+            self._adam()
+        return exchanged
+
+    def _forward_backward_native(self, x: torch.Tensor, tgt: torch.Tensor, overlap_comm: bool) -> bool:
+        """GazeTR encoder: hand-scheduled forward, loss and backward; with a communicator (and overlap_comm) the two
+        gradient buckets are all-reduced on the side stream while the backward continues."""
+        L = lib()
+        m = self.model
         g = engine.Geometry(x, m.upscale, m.grid_size, m.spline_order, m.grid_range)
         p_drop = m.layers[-1].encoder.encoder.encoder.layers[0].p_drop if m.training else 0.0
-        seed = engine.new_seed() if p_drop > 0 else 0
+        if self.device_state:
+            seed = self._seed_base if p_drop > 0 else 0
+        else:
+            seed = engine.new_seed() if p_drop > 0 else 0
         self.last_seed = seed
         out = torch.empty(g.B, 3, g.H * g.r, g.W * g.r, device=x.device, dtype=torch.float32)
         engine.bilinear_up_into(x, out, g.r, 1, 2, 1)
@@ -207,67 +311,41 @@ class TrainStep:
         if self.loss_kind == "l1+ssim":
             self._add_ssim_term(out, tgt, gy, g, plane)
         main = torch.cuda.current_stream()
+        overlap = overlap_comm and self.side is not None
 
         def tail_done():
-            if self.side is None:
-                return
             self.side.wait_stream(main)
             self.comm.allreduce_sum(self.flat_g[:self.tail_end], c_void_p(self.side.cuda_stream))
 
         backward_all(gy, plane, x, self.p, self.pre, g, sv, save_us, p_drop, seed, arena=self.arena,
-                     on_tail_done=tail_done)
-        if self.side is not None:
+                     on_tail_done=tail_done if overlap else None, allow_side_stream=overlap_comm)
+        if overlap:
             self.side.wait_stream(main)
             self.comm.allreduce_sum(self.flat_g[self.tail_end:], c_void_p(self.side.cuda_stream))
             main.wait_stream(self.side)
-        self.steps += 1
-        check(L.ksr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                              c_int64(self.flat_p.numel()), c_float(self.lr), c_float(self.betas[0]),
-                              c_float(self.betas[1]), c_float(self.eps), c_float(self.wd), c_int(self.steps),
-                              c_float(1.0 / self.world_size), stream()), "ksr_adam_step")
         self.out = out
-        return self.loss
+        return overlap
 
-    def _step_on_tape(self, x: torch.Tensor, tgt: torch.Tensor) -> torch.Tensor:
-        """Same step with the backward driven by the autograd tape (backbones other than GazeTR): forward through the
-        module, loss kernels write dL/dY' into plane 0 of a [B,3,rH,rW] gradient (the chroma planes carry no gradient
-        to the parameters and are never read), tape backward into the flat buffer, one all-reduce, Adam."""
-        if self.capture and _lib.PROFILE is None:
-            self._replay(x, tgt)
+    def _replay(self, x: torch.Tensor, tgt: torch.Tensor) -> bool:
+        """This step's _body through the HIP graph of the current input shape (recorded on the third step at that
+        shape; the two before it run unrecorded and size every lazily allocated workspace)."""
+        key = (tuple(x.shape), tuple(tgt.shape), self.model.training, self.model.precision)
+        ent = self._graphs.get(key)
+        if ent is None:
+            ent = self._graphs[key] = dict(graph=None, warm=0, gx=torch.empty_like(x),
+                                           gt=torch.empty_like(tgt, memory_format=torch.contiguous_format))
+            while len(self._graphs) > self.MAX_GRAPHS:
+                self._graphs.popitem(last=False)
         else:
-            self._forward_backward_on_tape(x, tgt)
-        L = lib()
-        if self.side is not None:
-            main = torch.cuda.current_stream()
-            self.side.wait_stream(main)
-            self.comm.allreduce_sum(self.flat_g, c_void_p(self.side.cuda_stream))
-            main.wait_stream(self.side)
-        self.steps += 1
-        check(L.ksr_adam_step(ptr(self.flat_p), ptr(self.flat_g), ptr(self.exp_avg), ptr(self.exp_avg_sq),
-                              c_int64(self.flat_p.numel()), c_float(self.lr), c_float(self.betas[0]),
-                              c_float(self.betas[1]), c_float(self.eps), c_float(self.wd), c_int(self.steps),
-                              c_float(1.0 / self.world_size), stream()), "ksr_adam_step")
-        encoder = self.model.layers[-1].encoder.encoder
-        if hasattr(encoder, "invalidate_prepared"):
-            encoder.invalidate_prepared()         # the weights changed under the cached kernel layouts
-        return self.loss
-
-    def _replay(self, x: torch.Tensor, tgt: torch.Tensor) -> None:
-        """Forward + loss + backward of this step through the HIP graph of the current input shape (recorded on the
-        third step at that shape; the two before it run uncaptured and size every lazily allocated workspace)."""
-        key = (tuple(x.shape), tuple(tgt.shape), tgt.dtype, self.model.training)
-        if key != self._graph_key:
-            self._graph, self._graph_key, self._graph_warm = None, key, 0
-            self._gx, self._gt = torch.empty_like(x), torch.empty_like(tgt, memory_format=torch.contiguous_format)
-        if self._graph is None and self._graph_warm < 2:
-            self._graph_warm += 1
-            self._forward_backward_on_tape(x, tgt)
-            return
-        if x.data_ptr() != self._gx.data_ptr():
-            self._gx.copy_(x)
-        if tgt.data_ptr() != self._gt.data_ptr():
-            self._gt.copy_(tgt)
-        if self._graph is None:
+            self._graphs.move_to_end(key)
+        if ent["graph"] is None and ent["warm"] < 2:
+            ent["warm"] += 1
+            return self._body(x, tgt, overlap_comm=True)
+        if x.data_ptr() != ent["gx"].data_ptr():
+            ent["gx"].copy_(x)
+        if tgt.data_ptr() != ent["gt"].data_ptr():
+            ent["gt"].copy_(tgt)
+        if ent["graph"] is None:
             # A forward of the model between the last Adam step and this recording (validation, a preview) would have
             # refreshed the kernel-layout weight copies and the eval-mode BatchNorm cache already: the recording would
             # then lack the launches that rebuild them, and every replay would run on the weights of this moment.
@@ -278,9 +356,12 @@ class TrainStep:
             # thread_local: only this thread's calls are policed while recording.  Other threads of the process (the
             # process group's watchdog polling its events when world_size > 1) would abort a recording in "global" mode.
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                self._forward_backward_on_tape(self._gx, self._gt)
-            self._graph = graph                   # recording launches nothing: the replay below is this step
-        self._graph.replay()
+                self._body(ent["gx"], ent["gt"], overlap_comm=False)
+            ent.update(graph=graph, loss=self.loss, out=self.out, ssim=getattr(self, "ssim", None))
+            # recording launches nothing: the replay below is this step
+        ent["graph"].replay()
+        self.loss, self.out, self.ssim = ent["loss"], ent["out"], ent["ssim"]
+        return False
 
     def _forward_backward_on_tape(self, x: torch.Tensor, tgt: torch.Tensor) -> None:
         L = lib()

@@ -290,3 +290,72 @@ def test_training_learns_smooth_images_in_bf16_storage_mode():
     assert last == last and last < first / 5, (first, last)
     assert bool(torch.isfinite(ts.flat_p).all())
     ts.close()
+
+
+@pytest.mark.parametrize("B", [8, 12])
+def test_gazetr_captured_step_equals_launched_step(B):
+    """TrainStep(capture=True) on the GazeTR encoder: the replayed HIP graph (forward + loss + backward + Adam; steps 3..)
+    gives bit for bit the losses, outputs and parameters of the same step launched kernel by kernel, with dropout
+    live (masks from the device-resident step counter), fresh input tensors every step, a change of the input shape and
+    a return to the first shape (both graphs stay recorded).  B = 8: fused transformer kernel; B = 12: QKV GEMM + MFMA
+    attention + post kernel."""
+    from kan_sr.train import TrainStep
+    runs = []
+    for capture in (False, True):
+        torch.manual_seed(41)
+        m, _ = _model(4, seed=6)
+        m = m.cuda().train()
+        m.precision = "bf16s"
+        ts = TrainStep(m, lr=1e-3, loss="l1+ssim", capture=capture, device_state=True)
+        gen = torch.Generator().manual_seed(7)
+        losses, outs = [], []
+        for it in range(12):
+            h, w = (16, 24) if (it < 5 or it >= 9) else (20, 12)
+            x, tgt = torch.rand(B, 3, h, w, generator=gen).cuda(), torch.rand(B, 3, 4 * h, 4 * w, generator=gen).cuda()
+            losses.append(float(ts.step(x, tgt)))
+            outs.append(ts.out[:, 0].clone())
+        if capture:
+            assert len([e for e in ts._graphs.values() if e["graph"] is not None]) == 2
+        assert ts.steps == 12 and int(ts._ctr) == 12
+        runs.append((losses, outs, ts.flat_p.clone(), ts.exp_avg_sq.clone()))
+        ts.close()
+    (l0, o0, p0, v0), (l1, o1, p1, v1) = runs
+    assert l0 == l1, (l0, l1)
+    assert len(set(l0)) == len(l0)                     # the steps differ (new masks, new data)
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+def test_device_resident_adam_matches_host_argument_adam():
+    """ksr_adam_step_dev (step count and lr read from device memory, bias corrections evaluated on the device) against
+    ksr_adam_step (by-value arguments) over 6 steps in eval mode, with a learning-rate change in between."""
+    from kan_sr.train import TrainStep
+    res = []
+    for dev_state in (False, True):
+        torch.manual_seed(5)
+        m, _ = _model(2, seed=8)
+        ts = TrainStep(m.cuda().eval(), lr=1e-3, device_state=dev_state)
+        gen = torch.Generator().manual_seed(3)
+        for it in range(6):
+            if it == 3:
+                ts.set_epoch(250)
+            ts.step(torch.rand(2, 3, 8, 32, generator=gen).cuda(), torch.rand(2, 3, 16, 64, generator=gen).cuda())
+        res.append((ts.flat_p.clone(), ts.exp_avg.clone()))
+    assert torch.equal(res[0][1], res[1][1])
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-7
+
+
+def test_dropout_masks_change_with_the_device_step_counter():
+    """With device_state the dropout stream is seed_base mixed with the step counter: two steps on identical data and
+    parameters (lr 0) draw different masks; resetting the counter reproduces the first step's loss bit for bit."""
+    from kan_sr.train import TrainStep
+    torch.manual_seed(9)
+    m, _ = _model(2, seed=4)
+    ts = TrainStep(m.cuda().train(), lr=0.0, device_state=True)
+    x, tgt = torch.rand(4, 3, 8, 32).cuda(), torch.rand(4, 3, 16, 64).cuda()
+    a = float(ts.step(x, tgt))
+    b = float(ts.step(x, tgt))
+    ts.steps = 0
+    c = float(ts.step(x, tgt))
+    assert a != b and a == c
