@@ -89,6 +89,18 @@ int ksr_stem_fwd(const float* x_img, int64_t img_batch_stride, const float* pw1_
                  const float* fn1_w, const float* fn1_b, float* t_out, float* save_v, int B, int H, int W,
                  ksr_stream_t stream);
 
+/* ffn1, ffn2 and ffn3.pointwise1 in one pass over the Y plane (gazetr.py:102-105; FFN unet_blocks.py:236-241, GatedFFN
+ * :267-275): ffn1's 64 channels are an affine function of one scalar v per pixel, so relu(fn_1(ffn1(Y))) is
+ * relu(A v + B) per channel and the 128-channel tensor needs neither a GEMM nor a trip through memory.
+ * params[14]: ffn1.pointwise1 {weight, bias}, ffn1.depthwise {weight [9], bias}, ffn1.pointwise2 {weight [64], bias},
+ * ffn2.fn_1.0 {weight [128,64], bias}, ffn2.gate {weight [64,9], bias}, ffn2.fn_2 {weight [64,64], bias},
+ * ffn3.pointwise1 {weight [64,64], bias}.  t3_out [N,64] = ffn3.pointwise1(sigmoid(ffn2(ffn1(Y)))).
+ * Training passes all four saves: v [N] (fp32), t [N,128] = relu(fn_1(x1)), gate [N,64], x3 [N,64] = sigmoid(ffn2);
+ * inference passes none. */
+int ksr_stem_gate_fwd(const float* x_img, int64_t img_batch_stride, const float* const* params, float* t3_out,
+                      float* save_v, float* save_t, float* save_gate, float* save_x3, int B, int H, int W,
+                      ksr_stream_t stream);
+
 /* 1x1 conv 64 -> n_out with activation act (0 none, 1 ReLU): FFN.pointwise1 (n_out 64, act 0;
  * unet_blocks.py:237), GatedFFN.fn_1 (n_out 128, act 1; unet_blocks.py:268) and the attention in_proj
  * (n_out 192, act 0; nn.MultiheadAttention in gazetr.py:39). in [N,64], out [N,n_out]. */

@@ -195,6 +195,182 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ffn1 + ffn2 + ffn3.pointwise1 in one kernel, reading only the Y plane.
+// ffn1's output is x1[k] = p2w[k] v + p2b[k] with ONE scalar v = relu(dw3x3(pw1(Y))) per pixel, so ffn2.fn_1 applied to
+// it is affine in v per channel: t[c] = relu(A[c] v + B[c]), A = fn1_w p2w, B = fn1_w p2b + fn1_b (formed once per
+// workgroup).  The 128-channel tensor t therefore needs no GEMM and no HBM round trip: the gate's depthwise 3x3 is
+// evaluated from the 6 x 34 window of v, which comes from an 8 x 36 window of Y.  Then value * gate -> fn_2 (MFMA) ->
+// sigmoid -> ffn3.pointwise1 (MFMA), the second product taking the first one's result straight from registers.
+struct StemGateArgs {
+    const float* img; long img_bstride;                       // NCHW image, plane 0 = Y
+    const float *p1w, *p1b, *dw1w, *dw1b, *p2w, *p2b;          // ffn1: pointwise1 {w,b}, depthwise [9], [1], pointwise2 [64],[64]
+    const float *fn1w, *fn1b;                                  // ffn2.fn_1 [128,64], [128]
+    const float *gw, *gb;                                      // ffn2.gate [64,9], [64]
+    const float *fn2w, *fn2b;                                  // ffn2.fn_2 [64,64], [64]
+    const float *pw1w, *pw1b;                                  // ffn3.pointwise1 [64,64], [64]
+    float* t3;                                                 // [N,64] ffn3.pointwise1 output
+    float *sv_v, *sv_t, *sv_g, *sv_x3;                         // training saves: v [N], t [N,128], gate [N,64], x3 [N,64]
+    int B, H, W;
+};
+
+constexpr int SG_YH = 8, SG_YW = 36, SG_VH = 6, SG_VW = 34;
+
+template <int PREC>
+struct __attribute__((aligned(16))) StemGateSmem {
+    float frag1[2 * 32 * 64 / (PREC != KSR_F32 ? 2 : 1)];
+    float frag2[2 * 32 * 64 / (PREC != KSR_F32 ? 2 : 1)];
+    float bias1[64], bias2[64];
+    float dww[9 * 64], dwb[64];
+    float A[128], Bc[128];
+    float u[SG_YH * SG_YW];            // pw1(Y) inside the image, 0 outside
+    float v[SG_VH * SG_VW];            // relu(dw3x3(u)) inside the image, -1 outside (v >= 0 inside)
+    float xpose[4 * KSR_XPOSE_FLOATS];
+};
+
+template <int PREC>
+__global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
+    using ST = typename KsrStore<PREC>::T;
+    __shared__ StemGateSmem<PREC> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+
+    ksr_stage_weights<PREC, 32, 2, false>(sm.frag1, sm.bias1, a.fn2w, 64, a.fn2b, MapHL{32}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 32, 2, false>(sm.frag2, sm.bias2, a.pw1w, 64, a.pw1b, MapHL{32}, MapHL{32}, tid, 256);
+    ksr_stage_dw<false>(sm.dww, a.gw, tid);
+    if (tid < 64) sm.dwb[tid] = a.gb[tid];
+    if (tid < 128) {
+        float sa = 0.f, sb = 0.f;
+        for (int k = 0; k < 64; ++k) {
+            const float w = a.fn1w[tid * 64 + k];
+            sa = fmaf(w, a.p2w[k], sa);
+            sb = fmaf(w, a.p2b[k], sb);
+        }
+        sm.A[tid] = sa;
+        sm.Bc[tid] = sb + a.fn1b[tid];
+    }
+    const float w1 = a.p1w[0], b1 = a.p1b[0], db1 = a.dw1b[0];
+    float k1[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) k1[t] = a.dw1w[t];
+    __syncthreads();
+
+    const int HW = a.H * a.W;
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
+    const long ntiles = (long)a.B * tiles_y * tiles_x;
+    float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const int b = (int)(tile / ((long)tiles_x * tiles_y));
+        const int y0 = ty * 4, x0 = tx * 32;
+        const int y = y0 + wv, x = x0 + tok;
+        const bool live = (y < a.H) && (x < a.W);
+        const long n = (long)b * HW + (long)y * a.W + x;
+        const float* Y = a.img + (long)b * a.img_bstride;
+        __syncthreads();                       // the previous tile's readers of u / v are done
+        for (int i = tid; i < SG_YH * SG_YW; i += 256) {
+            const int yy = y0 - 2 + i / SG_YW, xx = x0 - 2 + i % SG_YW;
+            const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            sm.u[i] = in ? w1 * Y[(long)yy * a.W + xx] + b1 : 0.f;
+        }
+        __syncthreads();
+        if (tid < SG_VH * SG_VW) {
+            const int vy = tid / SG_VW, vx = tid % SG_VW;
+            const int yy = y0 - 1 + vy, xx = x0 - 1 + vx;
+            float v = db1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) v += k1[dy * 3 + dx] * sm.u[(vy + dy) * SG_YW + vx + dx];
+            v = v > 0.f ? v : 0.f;
+            sm.v[tid] = (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) ? v : -1.f;
+        }
+        __syncthreads();
+
+        // gate = dw3x3(relu(A v + B)) over this lane's 32 gate channels (64 + 32h + i of t)
+        float g[32], tg[32];
+        {
+            float Ag[32], Bg[32];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(&sm.A[64 + 32 * h + 4 * q]);
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(&sm.Bc[64 + 32 * h + 4 * q]);
+                const f32x4 gb = *reinterpret_cast<const f32x4*>(&sm.dwb[32 * h + 4 * q]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { Ag[4 * q + e] = av[e]; Bg[4 * q + e] = bv[e]; g[4 * q + e] = gb[e]; }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float vn = sm.v[(wv + dy) * SG_VW + tok + dx];
+                    const bool in = vn >= 0.f;
+                    const float* wp = &sm.dww[(dy * 3 + dx) * 64 + 32 * h];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const f32x4 wq = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = fmaf(Ag[4 * q + e], vn, Bg[4 * q + e]);
+                            t = (in && t > 0.f) ? t : 0.f;
+                            if (dy == 1 && dx == 1) tg[4 * q + e] = t;
+                            g[4 * q + e] += wq[e] * t;
+                        }
+                    }
+                }
+        }
+        const float vc = sm.v[(wv + 1) * SG_VW + tok + 1];     // this pixel's v (>= 0 when live)
+        float op[32], val[32];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&sm.A[32 * h + 4 * q]);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&sm.Bc[32 * h + 4 * q]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t = fmaf(av[e], vc, bv[e]);
+                val[4 * q + e] = t > 0.f ? t : 0.f;
+                op[4 * q + e] = val[4 * q + e] * g[4 * q + e];
+            }
+        }
+        const long n0w = (long)b * HW + (long)y * a.W + x0;
+        const int nvalid = (y < a.H) ? (a.W - x0 < 32 ? a.W - x0 : 32) : 0;
+        if (a.sv_v) {
+            if (live && h == 0) a.sv_v[n] = vc;
+            ksr_store32_co<ST>(xb, a.sv_t, n0w, nvalid, 128, 0, lane, val);
+            ksr_store32_co<ST>(xb, a.sv_t, n0w, nvalid, 128, 64, lane, tg);
+            ksr_store32_co<ST>(xb, a.sv_g, n0w, nvalid, 64, 0, lane, g);
+        }
+        f32x16 acc[2];
+        ksr_wave_gemm<PREC, 32, 2>(sm.frag1, sm.bias1, op, acc, lane);
+        float x3[32];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { x3[q] = ksr_sigmoid(acc[0][q]); x3[16 + q] = ksr_sigmoid(acc[1][q]); }
+        if (a.sv_x3) {
+            ksr_store32_co<ST>(xb, a.sv_x3, n0w, nvalid, 64, 0, lane, x3);
+            if (sizeof(ST) == 2) {
+                // the backward and the next layer read x3 as stored: continue from the rounded values
+#pragma unroll
+                for (int i = 0; i < 32; ++i) x3[i] = (float)(__bf16)x3[i];
+            }
+        }
+        ksr_wave_gemm<PREC, 32, 2>(sm.frag2, sm.bias2, x3, acc, lane);
+        float o[32];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { o[q] = acc[0][q]; o[16 + q] = acc[1][q]; }
+        ksr_store32_co<ST>(xb, a.t3, n0w, nvalid, 64, 0, lane, o);
+    }
+}
+
+template <int PREC>
+int launch_stem_gate_p(const StemGateArgs& a, hipStream_t s) {
+    const long ntiles = (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32);
+    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
+    hipLaunchKernelGGL((stem_gate_fwd_kernel<PREC>), dim3(grid), dim3(256), 0, s, a);
+    KSR_LAUNCH_CHECK("stem_gate_fwd");
+    return KSR_OK;
+}
+
 template <int PREC, int PRO, int NOUT, int ACT>
 int launch_conv_p(const ConvArgs& a, hipStream_t s) {
     const bool spatial = (PRO == PRO_DWRELU || PRO == PRO_GATE);
@@ -270,4 +446,25 @@ extern "C" int ksr_gate_pw_fwd(const float* t_in, const float* gate_w, const flo
     a.in = t_in; a.in_ld = 128; a.dw_w = gate_w; a.dw_b = gate_b; a.wt = w; a.bias = bias; a.out = out;
     a.save = save_gate; a.out32 = out_f32_copy; a.B = B; a.H = H; a.W = W;
     return launch_conv<PRO_GATE, 64, ACT_SIGMOID>(a, stream);
+}
+
+extern "C" int ksr_stem_gate_fwd(const float* x_img, int64_t img_batch_stride, const float* const* params, float* t3_out,
+                                 float* save_v, float* save_t, float* save_gate, float* save_x3, int B, int H, int W,
+                                 hipStream_t stream) {
+    KSR_CHECK_ARG(x_img && params && t3_out, "stem_gate_fwd: null pointer");
+    for (int i = 0; i < 14; ++i) KSR_CHECK_ARG(params[i] != nullptr, "stem_gate_fwd: params[%d] is null", i);
+    const bool any = save_v || save_t || save_gate || save_x3, all = save_v && save_t && save_gate && save_x3;
+    KSR_CHECK_ARG(!any || all, "stem_gate_fwd: pass all four save tensors (training) or none (inference)");
+    if (int rc = check_dims(B, H, W, "stem_gate_fwd")) return rc;
+    StemGateArgs a{};
+    a.img = x_img; a.img_bstride = img_batch_stride;
+    a.p1w = params[0]; a.p1b = params[1]; a.dw1w = params[2]; a.dw1b = params[3]; a.p2w = params[4]; a.p2b = params[5];
+    a.fn1w = params[6]; a.fn1b = params[7]; a.gw = params[8]; a.gb = params[9]; a.fn2w = params[10]; a.fn2b = params[11];
+    a.pw1w = params[12]; a.pw1b = params[13];
+    a.t3 = t3_out; a.sv_v = save_v; a.sv_t = save_t; a.sv_g = save_gate; a.sv_x3 = save_x3;
+    a.B = B; a.H = H; a.W = W;
+#define KSR_CALL(P) return launch_stem_gate_p<P>(a, stream)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
+    return KSR_OK;
 }

@@ -94,21 +94,19 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=adt)                  # activations [N, C]
     new32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)      # per-pixel scalars
     keep = saves is not None
-    t2 = new(N, 128)
+    # ffn1 + ffn2 + ffn3.pointwise1 in one kernel that reads only the Y plane (relu(fn_1(ffn1(Y))) is affine in one scalar
+    # per pixel): the [N,128] tensor t2 is written only when the backward needs it
+    t2 = new(N, 128) if keep else None
     v = new32(N) if keep else None
-    check(L.ksr_stem_fwd(ptr(x), c_int64(3 * g.H * g.W), ptr(p[pre + "ffn1.pointwise1.weight"]),
-                         ptr(p[pre + "ffn1.pointwise1.bias"]), ptr(p[pre + "ffn1.depthwise.weight"]),
-                         ptr(p[pre + "ffn1.depthwise.bias"]), ptr(p[pre + "ffn1.pointwise2.weight"]),
-                         ptr(p[pre + "ffn1.pointwise2.bias"]), ptr(p[pre + "ffn2.fn_1.0.weight"]),
-                         ptr(p[pre + "ffn2.fn_1.0.bias"]), ptr(t2), ptr(v), *_dims(g), stream()), "ksr_stem_fwd")
-    x3 = new(N, 64)
     g2 = new(N, 64) if keep else None
-    check(L.ksr_gate_pw_fwd(ptr(t2), ptr(p[pre + "ffn2.gate.weight"]), ptr(p[pre + "ffn2.gate.bias"]),
-                            ptr(p[pre + "ffn2.fn_2.weight"]), ptr(p[pre + "ffn2.fn_2.bias"]), ptr(x3), ptr(g2), ptr(None),
-                            *_dims(g), stream()), "ksr_gate_pw_fwd")
+    x3 = new(N, 64) if keep else None
     t3 = new(N, 64)
-    check(L.ksr_pointwise_fwd(ptr(x3), ptr(p[pre + "ffn3.pointwise1.weight"]), ptr(p[pre + "ffn3.pointwise1.bias"]),
-                              ptr(t3), c_int(64), c_int(0), *_dims(g), stream()), "ksr_pointwise_fwd")
+    names14 = ("ffn1.pointwise1.weight", "ffn1.pointwise1.bias", "ffn1.depthwise.weight", "ffn1.depthwise.bias",
+               "ffn1.pointwise2.weight", "ffn1.pointwise2.bias", "ffn2.fn_1.0.weight", "ffn2.fn_1.0.bias",
+               "ffn2.gate.weight", "ffn2.gate.bias", "ffn2.fn_2.weight", "ffn2.fn_2.bias",
+               "ffn3.pointwise1.weight", "ffn3.pointwise1.bias")
+    check(L.ksr_stem_gate_fwd(ptr(x), c_int64(3 * g.H * g.W), _ptr_array([p[pre + n] for n in names14]), ptr(t3),
+                              ptr(v), ptr(t2), ptr(g2), ptr(x3), *_dims(g), stream()), "ksr_stem_gate_fwd")
     x4 = new(N, 64)
     a4 = new(N, 64) if keep else None
     check(L.ksr_dwrelu_pw_fwd(ptr(t3), ptr(p[pre + "ffn3.depthwise.weight"]), ptr(p[pre + "ffn3.depthwise.bias"]),
