@@ -223,6 +223,18 @@ int ksr_pw2_bwd(const float* dy, const float* pw2_w, const float* operand_saved,
 int ksr_pw1_bwd(const float* ds, const float* dw_w, const float* pw1_w, const float* y_saved, float* dt,
                 float* dz_prev, int B, int H, int W, ksr_stream_t stream);
 
+/* ksr_gate_pw_bwd / ksr_pw2_bwd with the weight and bias gradient of their 64 -> 64 conv (fn_2 with input value * gate;
+ * pointwise2 with input operand_saved) accumulated in the same pass: both operands of that product are already in the
+ * kernel's registers, so the separate ksr_wgrad launch and its second read of them are saved.  bf16 storage mode
+ * (ksr_set_precision(2)) only; other modes return KSR_ERR_UNSUPPORTED.  slab: ksr_fused_wgrad_slab_floats() floats of
+ * workspace; dW [64,64], db [64].  Deterministic (fixed-order reductions). */
+int64_t ksr_fused_wgrad_slab_floats(void);
+int ksr_gate_pw_bwd_wg(const float* dz, const float* fn2_w, const float* gate_saved, const float* t_saved,
+                       float* dt_value, float* dgate, float* slab, float* dW, float* db, int B, int H, int W,
+                       ksr_stream_t stream);
+int ksr_pw2_bwd_wg(const float* dy, const float* pw2_w, const float* operand_saved, float* ds, float* slab, float* dW,
+                   float* db, int B, int H, int W, ksr_stream_t stream);
+
 /* Weight gradient of a 1x1 conv / linear layer: dW[j][k] = sum_n dz[n, dz_c0+j] * a1[n, a1_c0+k]
  * (* a2[n, a2_c0+k] when a2 != NULL), db[j] = sum_n dz[n, dz_c0+j].  J % 32 == 0, K in {32, 64}.
  * slab: ksr_wgrad_slab_floats(J, K) floats of workspace.  kan_upscale > 0: dz is ksr_feed_kan_bwd's

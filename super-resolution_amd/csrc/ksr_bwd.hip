@@ -4,6 +4,7 @@
 // TRANSPOSED depthwise 3x3 to a gradient tensor staged as an LDS halo tile (flipped taps), the
 // epilogue applies the derivative of whatever preceded the 1x1 conv in the forward pass.
 #include "ksr_conv_common.h"
+#include "ksr_wg_fuse.h"
 
 namespace {
 
@@ -26,6 +27,7 @@ struct BwdArgs {
     float* out2;                                // [N,64]
     const float* v; const float* p2w; float* dpre;   // STEM epilogue
     float* sums_slab;                           // STEM, optional: [3][gridDim.x][2][64] per-workgroup column sums
+    float* wg_slab;                             // WGF: [gridDim.x][KSR_WGF_ROW] partial weight / bias gradients of the 1x1 conv
     int B, H, W;
 };
 
@@ -40,8 +42,12 @@ struct __attribute__((aligned(16))) BwdSmem {
 };
 static_assert(4 * KSR_XPOSE_FLOATS <= HALO_FLOATS, "transposers must fit in the halo tile");
 
-template <int PREC, int KIN, int BPRO, int BEPI>
+// WGF: the kernel also accumulates the weight and bias gradient of the forward 1x1 conv whose output gradient is dz
+// (KIN = 64; the conv's input is an operand of the epilogue: value * gate, the ReLU operand, or the sigmoid output).
+template <int PREC, int KIN, int BPRO, int BEPI, bool WGF = false>
 __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
+    static_assert(!WGF || (KIN == 64 && PREC == KSR_BF16S && BPRO == BPRO_PLAIN && (BEPI == BEPI_GATE || BEPI == BEPI_RELUMASK)),
+                  "fused weight gradient: 64 -> 64 convs, bf16 storage mode, no stencil prologue (register budget)");
     constexpr int KH = KIN / 2;
     using ST = typename KsrStore<PREC>::T;
     __shared__ BwdSmem<PREC, KIN, BPRO> sm;
@@ -93,6 +99,8 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     // STEM with sums_slab: sum_n d[n,c] * v[n] and sum_n d[n,c] for d = the two halves of dz and the output (lane = c)
     float cs[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     const bool col_sums = BEPI == BEPI_STEM && a.sums_slab != nullptr;
+    KsrWgFused wgf;
+    if constexpr (WGF) ksr_wgf_init(wgf);
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         bool live;
@@ -195,6 +203,12 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             else ksr_load32_co<ST>(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] = e[i] > 0.f ? dA[i] : 0.f;
+            if constexpr (WGF) {
+                float d0[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) d0[i] = dz[i];
+                ksr_wgf_accumulate(xb, lane, d0, e, wgf);
+            }
         }
         if (BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD) {
             float e[32];
@@ -215,6 +229,12 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
                 dA[i] = val[i] > 0.f ? dA[i] * gte[i] : 0.f;
             }
             ksr_store32_co<ST, !AHEAD>(xb, a.out2, n0w, nvalid, 64, 0, lane, o2);
+            if constexpr (WGF) {
+                float d0[32], m[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) { d0[i] = dz[i]; m[i] = val[i] * gte[i]; }
+                ksr_wgf_accumulate(xb, lane, d0, m, wgf);
+            }
         }
         if (BEPI == BEPI_STEM) {
             float s = 0.f;
@@ -227,6 +247,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         if (a.out1) ksr_store32_co<ST, !AHEAD>(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
         if (AHEAD && tile + gridDim.x < ntiles) fetch_epi(tile + gridDim.x);
     }
+    if constexpr (WGF) ksr_wgf_finish(spatial ? sm.halo : sm.xpose, a.wg_slab + (long)blockIdx.x * KSR_WGF_ROW, tid, wgf);
     if (BEPI == BEPI_STEM && col_sums) {
         // the four waves' sums meet in LDS (the halo / transposer area is free once every wave has left the loop)
         float* area = spatial ? sm.halo : sm.xpose;
@@ -285,6 +306,17 @@ int launch_dgrad_p(const BwdArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((dgrad_kernel<PREC, KIN, BPRO, BEPI>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("dgrad");
     return KSR_OK;
+}
+
+// Data gradient + fused weight gradient of a 64 -> 64 conv (bf16 storage mode), then the reduction of the partial rows.
+template <int BPRO, int BEPI>
+int launch_dgrad_wgf(const BwdArgs& a, float* dW, float* db, hipStream_t s) {
+    KSR_CHECK_ARG(a.wg_slab && dW && db, "fused weight gradient: null pointer");
+    KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "fused weight gradient: bf16 storage mode only (the other modes use ksr_wgrad)");
+    const unsigned grid = dgrad_grid(a, BPRO != BPRO_PLAIN);
+    hipLaunchKernelGGL((dgrad_kernel<KSR_BF16S, 64, BPRO, BEPI, true>), dim3(grid), dim3(256), 0, s, a);
+    KSR_LAUNCH_CHECK("dgrad(fused weight gradient)");
+    return ksr_slab_reduce(a.wg_slab, (int)grid, 64, 64, dW, db, s);
 }
 
 template <int KIN, int BPRO, int BEPI>
@@ -399,4 +431,31 @@ extern "C" int ksr_pointwise_bwd(const float* dz, int n_out, const float* w, flo
     if (n_out == 192) return launch_dgrad<192, BPRO_PLAIN, BEPI_STORE>(a, stream);
     ksr_set_error("pointwise_bwd: unsupported n_out=%d", n_out);
     return KSR_ERR_UNSUPPORTED;
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same data gradients with the weight / bias gradient of the 1x1 conv accumulated in the same pass (bf16 storage mode):
+// both operands of that product are already in the kernel's registers, so the separate ksr_wgrad launch and its
+// second read of them go away.  slab: ksr_fused_wgrad_slab_floats() floats of workspace.
+extern "C" int64_t ksr_fused_wgrad_slab_floats(void) { return (int64_t)KSR_WGF_MAX_GRID * KSR_WGF_ROW; }
+
+extern "C" int ksr_gate_pw_bwd_wg(const float* dz, const float* fn2_w, const float* gate_saved, const float* t_saved,
+                                  float* dt_value, float* dgate, float* slab, float* dW, float* db, int B, int H, int W,
+                                  hipStream_t stream) {
+    KSR_CHECK_ARG(dz && fn2_w && gate_saved && t_saved && dt_value && dgate, "gate_pw_bwd_wg: null pointer");
+    if (int rc = dims_ok(B, H, W, "gate_pw_bwd_wg")) return rc;
+    BwdArgs a{};
+    a.dz = dz; a.dz_ld = 64; a.wt = fn2_w; a.e1 = gate_saved; a.e1_ld = 64; a.e2 = t_saved; a.e2_ld = 128;
+    a.out1 = dt_value; a.out1_ld = 128; a.out1_c0 = 0; a.out2 = dgate; a.wg_slab = slab; a.B = B; a.H = H; a.W = W;
+    return launch_dgrad_wgf<BPRO_PLAIN, BEPI_GATE>(a, dW, db, stream);
+}
+
+extern "C" int ksr_pw2_bwd_wg(const float* dy, const float* pw2_w, const float* operand_saved, float* ds, float* slab,
+                              float* dW, float* db, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dy && pw2_w && operand_saved && ds, "pw2_bwd_wg: null pointer");
+    if (int rc = dims_ok(B, H, W, "pw2_bwd_wg")) return rc;
+    BwdArgs a{};
+    a.dz = dy; a.dz_ld = 64; a.wt = pw2_w; a.e1 = operand_saved; a.e1_ld = 64; a.out1 = ds; a.out1_ld = 64;
+    a.wg_slab = slab; a.B = B; a.H = H; a.W = W;
+    return launch_dgrad_wgf<BPRO_PLAIN, BEPI_RELUMASK>(a, dW, db, stream);
 }

@@ -607,6 +607,11 @@ long gram_grid(int Jp, int K, int nb, long tokens) {
 
 extern "C" int ksr_wgrad_slab_floats(int J, int K) { return WG_GRID * (J * K + J); }
 
+// Fixed-order sum of G partial rows [J*K | J] (written by a kernel that accumulated the products itself) to dW, db.
+int ksr_slab_reduce(const float* slab, int G, int J, int K, float* dW, float* db, hipStream_t stream) {
+    return launch_reduce(slab, G, J, K, (long)J * K + J, dW, K, 1, db, 0, 0, 0, stream);
+}
+
 // dW [J][K] (row-major, or scattered through the KAN channel map when kan_upscale > 0) and db [J].
 // slab: workspace of ksr_wgrad_slab_floats(J, K) floats.
 extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const float* a1, int a1_ld, int a1_c0, int K,

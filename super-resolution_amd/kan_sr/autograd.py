@@ -54,6 +54,7 @@ class _Ws:
         self._slab = None
         self._ln_slab = None
         self._sums_slab = None
+        self._fused_slab = None
         self.arena = arena
         # small problems are bound by the host's launch rate, where the extra stream bookkeeping only costs
         self.wstream = _side_stream(dev) if (SIDE_STREAM_FOR_WGRAD and allow_side_stream and dev.type == "cuda"
@@ -97,6 +98,17 @@ class _Ws:
         w, b = self.arena[name_w], self.arena[name_b]
         assert w.numel() == n and b.numel() == n and b.data_ptr() == w.data_ptr() + 4 * n, (name_w, name_b)
         return torch.as_strided(w, (2, n), (n, 1))
+
+    def fused_wgrad(self) -> bool:
+        """bf16 storage mode: the data-gradient kernels of the 64 -> 64 convs accumulate the weight gradient themselves."""
+        return engine.act_dtype() is torch.bfloat16
+
+    def fused_slab(self):
+        """Workspace of the fused weight gradients.  One per call site would allow overlap; the launches that use it are
+        ordered on one stream, and each call's reduction has consumed the rows before the next call's kernel starts."""
+        if self._fused_slab is None:
+            self._fused_slab = torch.empty(int(lib().ksr_fused_wgrad_slab_floats()), device=self.dev, dtype=torch.float32)
+        return self._fused_slab
 
     def sums_slab(self):
         if self._sums_slab is None:
@@ -201,10 +213,15 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
     q = pre + name + "."
     dt = ws.act(N, 128)
     dgate = ws.act(N, 64)
-    check(L.ksr_gate_pw_bwd(ptr(dz), ptr(p[q + "fn_2.weight"]), ptr(gate_saved), ptr(t), ptr(dt), ptr(dgate),
-                            *_dims(g), stream()), "ksr_gate_pw_bwd")
     gw, gb = ws.grad(q + "fn_2.weight", 64, 64, 1, 1), ws.grad(q + "fn_2.bias", 64)
-    _wgrad(ws, dz, 64, 0, 64, t, 128, 0, 64, N, gw, gb, a2=gate_saved, a2_ld=64, a2_c0=0)
+    if ws.fused_wgrad():
+        # bf16 storage: the kernel that turns dz into dt / dgate holds both operands of fn_2's weight gradient
+        check(L.ksr_gate_pw_bwd_wg(ptr(dz), ptr(p[q + "fn_2.weight"]), ptr(gate_saved), ptr(t), ptr(dt), ptr(dgate),
+                                   ptr(ws.fused_slab()), ptr(gw), ptr(gb), *_dims(g), stream()), "ksr_gate_pw_bwd_wg")
+    else:
+        check(L.ksr_gate_pw_bwd(ptr(dz), ptr(p[q + "fn_2.weight"]), ptr(gate_saved), ptr(t), ptr(dt), ptr(dgate),
+                                *_dims(g), stream()), "ksr_gate_pw_bwd")
+        _wgrad(ws, dz, 64, 0, 64, t, 128, 0, 64, N, gw, gb, a2=gate_saved, a2_ld=64, a2_c0=0)
     grads[q + "fn_2.weight"], grads[q + "fn_2.bias"] = gw, gb
     grads[q + "gate.weight"], grads[q + "gate.bias"] = _dwconv_wgrad(ws, t, 128, 64, dgate, g, q + "gate.weight",
                                                                    q + "gate.bias")
@@ -302,10 +319,14 @@ def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, t
     # ---- ffn3 ----
     q = pre + "ffn3."
     ds4 = ws.act(N, 64)
-    check(L.ksr_pw2_bwd(ptr(dx4), ptr(p[q + "pointwise2.weight"]), ptr(sv["a4"]), ptr(ds4), *_dims(g), stream()),
-          "ksr_pw2_bwd")
     gw, gb = ws.grad(q + "pointwise2.weight", 64, 64, 1, 1), ws.grad(q + "pointwise2.bias", 64)
-    _wgrad(ws, dx4, 64, 0, 64, sv["a4"], 64, 0, 64, N, gw, gb)
+    if ws.fused_wgrad():
+        check(L.ksr_pw2_bwd_wg(ptr(dx4), ptr(p[q + "pointwise2.weight"]), ptr(sv["a4"]), ptr(ds4), ptr(ws.fused_slab()),
+                               ptr(gw), ptr(gb), *_dims(g), stream()), "ksr_pw2_bwd_wg")
+    else:
+        check(L.ksr_pw2_bwd(ptr(dx4), ptr(p[q + "pointwise2.weight"]), ptr(sv["a4"]), ptr(ds4), *_dims(g), stream()),
+              "ksr_pw2_bwd")
+        _wgrad(ws, dx4, 64, 0, 64, sv["a4"], 64, 0, 64, N, gw, gb)
     grads[q + "pointwise2.weight"], grads[q + "pointwise2.bias"] = gw, gb
     grads[q + "depthwise.weight"], grads[q + "depthwise.bias"] = _dwconv_wgrad(ws, sv["t3"], 64, 0, ds4, g,
                                                                              q + "depthwise.weight", q + "depthwise.bias")

@@ -459,3 +459,55 @@ def test_fused_stem_gate_kernel_equals_the_three_separate_kernels(B, H, W):
     assert torch.equal(saves["v"], v)
     for name, ref in (("t2", t2), ("g2", g2), ("x3", x3), ("t3", t3)):
         assert_fwd(saves[name], ref, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 9, 11), (3, 40, 32), (16, 64, 64)])
+def test_fused_weight_gradient_equals_separate_wgrad(B, H, W):
+    """bf16 storage mode: ksr_gate_pw_bwd_wg / ksr_pw2_bwd_wg (weight gradient accumulated inside the data-gradient
+    kernel) against ksr_gate_pw_bwd / ksr_pw2_bwd + ksr_wgrad on the same bf16 tensors: identical data gradients, weight
+    and bias gradients equal up to fp32 summation order, and both close to an fp64 evaluation."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(B + H)
+    L = lib()
+    N = B * H * W
+    dims = (c_int(B), c_int(H), c_int(W))
+    bf = lambda *s: torch.randn(*s, device="cuda").bfloat16()
+    dz, gate, t, a4 = bf(N, 64), bf(N, 64), bf(N, 128).abs() * (torch.rand(N, 128, device="cuda") > 0.3).bfloat16(), bf(N, 64).relu()
+    w = torch.randn(64, 64, device="cuda") * 0.1
+    engine.set_precision("bf16s")
+    try:
+        slab = torch.empty(int(L.ksr_fused_wgrad_slab_floats()), device="cuda")
+        ws = torch.empty(int(L.ksr_wgrad_slab_floats(c_int(64), c_int(64))), device="cuda")
+        # ---- gated block tail
+        dt0, dg0 = torch.zeros(N, 128, device="cuda").bfloat16(), torch.empty(N, 64, device="cuda").bfloat16()
+        dt1, dg1 = torch.zeros(N, 128, device="cuda").bfloat16(), torch.empty(N, 64, device="cuda").bfloat16()
+        dW0, db0, dW1, db1 = (torch.empty(s, device="cuda") for s in ((64, 64), (64,), (64, 64), (64,)))
+        check(L.ksr_gate_pw_bwd(ptr(dz), ptr(w), ptr(gate), ptr(t), ptr(dt0), ptr(dg0), *dims, stream()), "gate_pw_bwd")
+        check(L.ksr_wgrad(ptr(dz), c_int(64), c_int(0), c_int(64), ptr(t), c_int(128), c_int(0), c_int(64), ptr(gate), c_int(64),
+                          c_int(0), c_int64(N), ptr(ws), ptr(dW0), ptr(db0), c_int(0), c_int(0), stream()), "wgrad")
+        check(L.ksr_gate_pw_bwd_wg(ptr(dz), ptr(w), ptr(gate), ptr(t), ptr(dt1), ptr(dg1), ptr(slab), ptr(dW1), ptr(db1), *dims,
+                                   stream()), "gate_pw_bwd_wg")
+        assert torch.equal(dt0, dt1) and torch.equal(dg0, dg1)
+        ref = dz.double().T @ (t[:, :64].double() * gate.double()).bfloat16().double()
+        assert rel_l2(dW1.cpu(), ref.cpu()) <= 2e-3 and rel_l2(dW0.cpu(), ref.cpu()) <= 2e-3
+        assert rel_l2(dW1.cpu(), dW0.cpu()) <= 1e-5
+        assert rel_l2(db1.cpu(), dz.double().sum(0).cpu()) <= 1e-5 and rel_l2(db1.cpu(), db0.cpu()) <= 1e-5
+        # ---- FFN pointwise2
+        ds0, ds1 = torch.empty(N, 64, device="cuda").bfloat16(), torch.empty(N, 64, device="cuda").bfloat16()
+        check(L.ksr_pw2_bwd(ptr(dz), ptr(w), ptr(a4), ptr(ds0), *dims, stream()), "pw2_bwd")
+        check(L.ksr_wgrad(ptr(dz), c_int(64), c_int(0), c_int(64), ptr(a4), c_int(64), c_int(0), c_int(64), None, c_int(0), c_int(0),
+                          c_int64(N), ptr(ws), ptr(dW0), ptr(db0), c_int(0), c_int(0), stream()), "wgrad")
+        check(L.ksr_pw2_bwd_wg(ptr(dz), ptr(w), ptr(a4), ptr(ds1), ptr(slab), ptr(dW1), ptr(db1), *dims, stream()), "pw2_bwd_wg")
+        assert torch.equal(ds0, ds1)
+        assert rel_l2(dW1.cpu(), (dz.double().T @ a4.double()).cpu()) <= 1e-5
+        assert rel_l2(dW1.cpu(), dW0.cpu()) <= 1e-5 and rel_l2(db1.cpu(), db0.cpu()) <= 1e-5
+        # deterministic
+        dW2, db2 = torch.empty_like(dW1), torch.empty_like(db1)
+        check(L.ksr_pw2_bwd_wg(ptr(dz), ptr(w), ptr(a4), ptr(ds1), ptr(slab), ptr(dW2), ptr(db2), *dims, stream()), "pw2_bwd_wg")
+        assert torch.equal(dW1, dW2) and torch.equal(db1, db2)
+        engine.set_precision("fp32")
+        rc = L.ksr_pw2_bwd_wg(ptr(dz), ptr(w), ptr(a4), ptr(ds1), ptr(slab), ptr(dW2), ptr(db2), *dims, stream())
+        assert rc == -2
+    finally:
+        engine.set_precision("fp32")
