@@ -62,7 +62,7 @@ __device__ __forceinline__ void fetch_rows(const void* __restrict__ base, const 
             for (int i = 0; i < 8; ++i) {
                 const long n = rm(4 * i + r4);
                 const bool ok = n >= 0;
-                const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (ok ? n : 0) * ld + c0 + c4);
+                const float4 v = ksr_ld_stream(reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (ok ? n : 0) * ld + c0 + c4));
                 t.v[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
             }
         } else {
@@ -71,7 +71,7 @@ __device__ __forceinline__ void fetch_rows(const void* __restrict__ base, const 
             for (int i = 0; i < 4; ++i) {
                 const long n = rm(8 * i + r8);
                 const bool ok = n >= 0;
-                const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (ok ? n : 0) * ld + c0 + c8);
+                const uint4 v = ksr_ld_stream(reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (ok ? n : 0) * ld + c0 + c8));
                 t.v[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
             }
         }
@@ -83,7 +83,7 @@ __device__ __forceinline__ void fetch_rows(const void* __restrict__ base, const 
         for (int i = 0; i < 8; ++i) {
             const long n = rm(4 * i + r4);
             t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n >= 0) t.v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + n * ld + c0 + c4);
+            if (n >= 0) t.v[i] = ksr_ld_stream(reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + n * ld + c0 + c4));
         }
     } else {
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
@@ -91,7 +91,7 @@ __device__ __forceinline__ void fetch_rows(const void* __restrict__ base, const 
         for (int i = 0; i < 4; ++i) {
             const long n = rm(8 * i + r8);
             t.v[i] = make_uint4(0u, 0u, 0u, 0u);
-            if (n >= 0) t.v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + n * ld + c0 + c8);
+            if (n >= 0) t.v[i] = ksr_ld_stream(reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + n * ld + c0 + c8));
         }
     }
 }

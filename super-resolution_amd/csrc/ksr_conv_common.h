@@ -32,10 +32,10 @@ __device__ __forceinline__ void ksr_halo_fetch(const void* __restrict__ src, int
         const long e = ((long)b * HW + (long)gy * W + gx) * ld + c0;
         if constexpr (sizeof(T) == 4) {
             r.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in) r.v[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + e + 4 * q);
+            if (in) r.v[it] = ksr_ld_stream(reinterpret_cast<const float4*>(reinterpret_cast<const float*>(src) + e + 4 * q));
         } else {
             r.v[it] = make_uint4(0u, 0u, 0u, 0u);
-            if (in) r.v[it] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(src) + e + 8 * q);
+            if (in) r.v[it] = ksr_ld_stream(reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(src) + e + 8 * q));
         }
     }
 }

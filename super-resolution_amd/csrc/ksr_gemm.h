@@ -260,7 +260,7 @@ __device__ __forceinline__ void ksr_co_fetch(const void* __restrict__ base, long
             for (int i = 0; i < 8; ++i) {
                 const int row = 4 * i + r4;
                 t.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < nvalid) t.v[i] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * ld + c0 + c4);
+                if (row < nvalid) t.v[i] = ksr_ld_stream(reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (n0 + row) * ld + c0 + c4));
             }
         } else {
             const int r8 = lane >> 3, c8 = (lane & 7) * 8;
@@ -268,7 +268,7 @@ __device__ __forceinline__ void ksr_co_fetch(const void* __restrict__ base, long
             for (int i = 0; i < 4; ++i) {
                 const int row = 8 * i + r8;
                 t.v[i] = make_uint4(0u, 0u, 0u, 0u);
-                if (row < nvalid) t.v[i] = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * ld + c0 + c8);
+                if (row < nvalid) t.v[i] = ksr_ld_stream(reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (n0 + row) * ld + c0 + c8));
             }
         }
         return;
@@ -283,7 +283,7 @@ __device__ __forceinline__ void ksr_co_fetch(const void* __restrict__ base, long
         for (int i = 0; i < 8; ++i) {
             const int row = 4 * i + r4;
             const bool ok = row < nvalid;
-            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (nb + (ok ? row : 0)) * ld + c0 + c4);
+            const float4 v = ksr_ld_stream(reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (nb + (ok ? row : 0)) * ld + c0 + c4));
             t.v[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     } else {
@@ -292,7 +292,7 @@ __device__ __forceinline__ void ksr_co_fetch(const void* __restrict__ base, long
         for (int i = 0; i < 4; ++i) {
             const int row = 8 * i + r8;
             const bool ok = row < nvalid;
-            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (nb + (ok ? row : 0)) * ld + c0 + c8);
+            const uint4 v = ksr_ld_stream(reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (nb + (ok ? row : 0)) * ld + c0 + c8));
             t.v[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
         }
     }
@@ -426,7 +426,7 @@ __device__ __forceinline__ void ksr_co16_fetch(const void* __restrict__ base, lo
         for (int i = 0; i < 4; ++i) {
             const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
             const bool ok = row < nvalid;
-            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (nb + (ok ? row : 0)) * 32 + c4);
+            const float4 v = ksr_ld_stream(reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (nb + (ok ? row : 0)) * 32 + c4));
             t.v[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
         }
     } else {
@@ -434,7 +434,7 @@ __device__ __forceinline__ void ksr_co16_fetch(const void* __restrict__ base, lo
         for (int i = 0; i < 2; ++i) {
             const int idx = i * 64 + lane, row = idx >> 2, c8 = (idx & 3) * 8;
             const bool ok = row < nvalid;
-            const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (nb + (ok ? row : 0)) * 32 + c8);
+            const uint4 v = ksr_ld_stream(reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (nb + (ok ? row : 0)) * 32 + c8));
             t.v[i] = make_uint4(ok ? v.x : 0u, ok ? v.y : 0u, ok ? v.z : 0u, ok ? v.w : 0u);
         }
     }

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dstbuf + (i * 256 + wv * 64) * EPP),
-                                             16, 0, 0);
+                                             16, 0, 2 /* nt: operands are read once */);
         }
     };
 
