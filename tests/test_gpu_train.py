@@ -359,3 +359,67 @@ def test_dropout_masks_change_with_the_device_step_counter():
     ts.steps = 0
     c = float(ts.step(x, tgt))
     assert a != b and a == c
+
+
+def test_gradient_exchange_schedule_order():
+    """The two-bucket exchange of the GazeTR step, with a recording stand-in for the communicator and the library
+    calls logged in launch order: bucket 1 (feed + transformer layers + final norm) is issued after the last launch
+    that writes into it (layer 0's in_proj weight gradient) and before the first launch of the conv-trunk backward
+    (ffn4's gate_pw backward); bucket 2 after the last backward launch; Adam after both.  The buckets are the two
+    halves [0, tail_end) and [tail_end, total) of the flat gradient buffer."""
+    from kan_sr import _lib
+    from kan_sr.train import TrainStep
+    log = []
+
+    class Recorder:
+        world_size = 2                                   # the step then scales the summed gradients by 1/2
+
+        def allreduce_sum(self, t, hip_stream):
+            log.append(("allreduce", t.data_ptr(), t.numel(), int(hip_stream.value or 0)))
+
+        def close(self):
+            pass
+
+    m, _ = _model(4, seed=2)
+    m = m.cuda().eval()
+    ts = TrainStep(m, world_size=2, rank=0, comm=Recorder(), loss="l1+ssim")
+    proxy = _lib.lib()
+    orig_getattr = type(proxy).__getattr__
+
+    def logging_getattr(self, name):
+        fn = orig_getattr(self, name)
+        if not name.startswith("ksr_") or name in ("ksr_last_error",):
+            return fn
+
+        def wrapped(*a):
+            log.append((name,))
+            return fn(*a)
+        return wrapped
+
+    type(proxy).__getattr__ = logging_getattr
+    try:
+        x, tgt = torch.rand(2, 3, 16, 32).cuda(), torch.rand(2, 3, 64, 128).cuda()
+        ts.step(x, tgt)
+        torch.cuda.synchronize()
+    finally:
+        type(proxy).__getattr__ = orig_getattr
+    names = [e[0] for e in log]
+    ar = [i for i, n in enumerate(names) if n == "allreduce"]
+    assert len(ar) == 2
+    b1, b2 = log[ar[0]], log[ar[1]]
+    assert b1[1] == ts.flat_g.data_ptr() and b1[2] == ts.tail_end
+    assert b2[1] == ts.flat_g.data_ptr() + 4 * ts.tail_end and b2[2] == ts.flat_g.numel() - ts.tail_end
+    assert b1[3] == b2[3] == ts.side.cuda_stream != torch.cuda.current_stream().cuda_stream
+    in_proj_bwd = [i for i, n in enumerate(names) if n == "ksr_in_proj_bwd"]
+    assert len(in_proj_bwd) == 2
+    last_tail_wgrad = max(i for i, n in enumerate(names) if n == "ksr_wgrad" and i < in_proj_bwd[1])
+    first_trunk = min(i for i, n in enumerate(names) if n in ("ksr_gate_pw_bwd", "ksr_gate_pw_bwd_wg"))
+    assert last_tail_wgrad < in_proj_bwd[1] < ar[0]          # after every launch that writes a bucket-1 gradient
+    assert ar[0] < first_trunk, (ar[0], first_trunk)
+    backward_launches = [i for i, n in enumerate(names) if n.endswith(("_bwd", "_wgrad", "_wg", "outer2"))]
+    assert ar[1] > max(backward_launches)
+    adam = names.index("ksr_adam_step")
+    assert adam > ar[1] and adam == len(names) - 1
+    # the 1/world scaling is applied by Adam: a second, exchange-free step on the same data with doubled gradients
+    # is not needed here; the gloo test in test_host_logic.py covers the arithmetic
+    ts.close()
