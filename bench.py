@@ -42,28 +42,37 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
     pk = PEAK_MFMA_BF16_TFLOPS if bf16 else PEAK_MFMA_F32_TFLOPS
     f32 = pk                       # the attention products follow the operand mode as well
     k = act_bytes / 4.0            # byte counts below are written for fp32 activations
-    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64 + 64 * 64 + 192 * 64) + (64 * 64 + 128 * 64) + 2 * 64 * 64 + 64 * 64
-    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64) + (64 + 64) + (192 + 64)) + (64 * 3 + 128 + 64)
-                    + 2 * (64 + 64) + 64 * 3)
+    # bf16 storage: the fn_2 (ffn2, ffn4) and ffn3.pointwise2 weight gradients are accumulated inside their data-gradient
+    # kernels (ksr_gate_pw_bwd_wg, ksr_pw2_bwd_wg) and leave ksr_wgrad
+    fused = act_bytes == 2
+    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64 + 64 * 64 + 192 * 64) + 128 * 64 + 64 * 64 + (0 if fused else 3 * 64 * 64)
+    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64) + (64 + 64) + (192 + 64)) + (128 + 64) + (64 + 64)
+                    + (0 if fused else 2 * 64 * 3 + (64 + 64)))
     lin_post = 2 * (64 * 64 + 64 * 32 + 32 * 64)
     models = {
         # forward
         "ksr_stem_fwd": ("hbm", 2 * 64 * 128 + 150, 4 + 512 + 4, pk),
-        "ksr_gate_pw_fwd": ("hbm", 2 * (2 * 64 * 64 + 2 * 9 * 64 + 64), 2 * (512 + 256 + 256), pk),
-        "ksr_pointwise_fwd": ("hbm", 2 * 64 * 64 + 2 * 64 * 128 + 2 * 2 * 64 * 192, (256 + 256) + (256 + 512) + 2 * (256 + 768), pk),
+        # ffn1 + ffn2 + ffn3.pointwise1 from the Y plane: writes t [N,128], gate, x3, t3 [N,64] and v [N]
+        "ksr_stem_gate_fwd": ("hbm", 2 * 2 * 64 * 64 + 2 * 9 * 64 * 3 + 400, 4 + 4 + 512 + 3 * 256, pk),
+        "ksr_gate_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64 + 64, 512 + 256 + 256, pk),            # ffn4's tail
+        "ksr_pointwise_fwd": ("hbm", 2 * 64 * 128 + 2 * 2 * 64 * 192, (256 + 512) + 2 * (256 + 768), pk),
         "ksr_dwrelu_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 256 + 256 + 256, pk),
         "ksr_batch_tx_layer_fwd": ("mfma", 2 * (2 * 64 * 192 + lin_post + 256 * S), 2 * 512, pk),
-        "ksr_batch_attn_fwd": ("mfma", 2 * 256 * S, 2 * (768 + 256), f32),
+        # attention: the bf16-operand kernels are bound by memory and vector arithmetic (masks, exp, dropout hash), the
+        # matrix pipe is < 10 % busy: priced against HBM; the exact fp32 kernels against the fp32 MFMA peak
+        "ksr_batch_attn_fwd": ("hbm" if bf16 else "mfma", 2 * 256 * S, 2 * (768 + 256), f32),
         "ksr_batch_tx_layer_post_fwd": ("hbm", 2 * lin_post, 1664 + 1920, pk),
         "ksr_feed_kan_fwd": ("mfma" if not bf16 else "hbm", 2 * 64 * P + 400, 256 + 4 + 4 * 16, pk),
         "ksr_bilinear_up": ("hbm", 0, 8 + 8 * 16, pk),
         # backward
         "ksr_feed_kan_bwd": ("hbm", 2 * 64 * P + 800, 64 + 4 + 128 + 256 + 4 * P, pk),
         "ksr_batch_tx_layer_bwd_token": ("hbm", 2 * lin_post, 2304 + 2304, pk),     # LayerNorm gain / shift sums are fused in
-        "ksr_batch_attn_bwd": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
-        "ksr_batch_tx_layer_bwd_attn": ("mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
+        "ksr_batch_attn_bwd": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
+        "ksr_batch_tx_layer_bwd_attn": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
         "ksr_in_proj_bwd": ("hbm", 2 * 2 * 192 * 64, 2 * (768 + 256 + 256 + 256), pk),
         "ksr_gate_pw_bwd": ("hbm", 2 * 2 * 64 * 64, 2 * 1280, pk),
+        "ksr_gate_pw_bwd_wg": ("hbm", 2 * 2 * 2 * 64 * 64, 2 * 1280, pk),          # + the fn_2 weight gradient, same bytes
+        "ksr_pw2_bwd_wg": ("hbm", 2 * 2 * 64 * 64, 768, pk),
         "ksr_fn1_bwd": ("hbm", 2 * (2 * 128 * 64 + 2 * 9 * 64), 2 * 1280 - 512, pk),   # the stem call writes neither dx nor dt[:, 64:]
         "ksr_pw2_bwd": ("hbm", 2 * 64 * 64, 768, pk),
         "ksr_pw1_bwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 1024, pk),
@@ -78,7 +87,8 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
     }
     # activation bytes scale with the storage type; the image-side tensors of these entry points stay fp32
     fixed = {"ksr_ssim_fwd": 16 * 36, "ksr_ssim_y_grad": 16 * 28, "ksr_l1_y_loss": 16 * 12, "ksr_stem_fwd": 8, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_feed_kan_bwd": 64 + 4 + 128, "ksr_bilinear_up": 8 + 8 * 16,
-             "ksr_gate_pw_fwd": 256 if act_bytes != 4 else 0, "ksr_batch_tx_layer_post_fwd": 128 if act_bytes != 4 else 0}
+             "ksr_gate_pw_fwd": 256 if act_bytes != 4 else 0, "ksr_batch_tx_layer_post_fwd": 128 if act_bytes != 4 else 0,
+             "ksr_stem_gate_fwd": 8}
     out = {}
     for name, (bound, fl, by, peak) in models.items():
         fx = fixed.get(name, 0)
@@ -95,6 +105,7 @@ ENTRY_KERNEL = {
     "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<2>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<2, true, true>",
     "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<2, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<2, 4, 8, 3>",
     "ksr_gate_pw_fwd": "conv_fwd_kernel<2, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<2, 64, 0, 3>",
+    "ksr_gate_pw_bwd_wg": "dgrad_kernel<2, 64, 0, 3, true>", "ksr_stem_gate_fwd": "stem_gate_fwd_kernel<2>",
     "ksr_wgrad": "entry:ksr_wgrad",      # launch-weighted average over the wgrad_kernel instances + the slab reduction
 }
 
@@ -355,7 +366,7 @@ def main():
             roofline.update(price(dom))
         if args.workload == "train" and args.precision == "bf16s" and B == 64:
             roofline["traffic"] = measured_traffic(dom)
-            roofline["traffic_source"] = "profiles/r01_train_b64_bf16s_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
+            roofline["traffic_source"] = "profiles/r02_train_b64_bf16s_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
             roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
         if unet and B == 8:
             roofline["traffic"] = measured_traffic_unet(dom)

@@ -166,7 +166,11 @@ __device__ __forceinline__ bool ksr_attn_keep(unsigned base, int key_b, float ke
     return half < (unsigned)(keep * 65536.0f);
 }
 
-__device__ __forceinline__ float ksr_silu(float x) { return x / (1.f + expf(-x)); }
-__device__ __forceinline__ float ksr_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+// 1 / (1 + exp(-x)) with the hardware exp2 and reciprocal (1 ulp each) instead of expf and an IEEE division: about 5
+// instructions instead of 15 per value, in kernels that are bound by instruction issue
+__device__ __forceinline__ float ksr_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float ksr_silu(float x) { return x * ksr_sigmoid(x); }
 
 #endif  // __HIPCC__

@@ -240,11 +240,21 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
     ksr_stage_dw<false>(sm.dww, a.gw, tid);
     if (tid < 64) sm.dwb[tid] = a.gb[tid];
     if (tid < 128) {
+        // row tid of fn_1's weight as 16 independent 16-byte loads (one memory latency, not 64)
+        float4 wr[16], pw[16], pb[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            wr[q] = reinterpret_cast<const float4*>(a.fn1w + tid * 64)[q];
+            pw[q] = reinterpret_cast<const float4*>(a.p2w)[q];
+            pb[q] = reinterpret_cast<const float4*>(a.p2b)[q];
+        }
         float sa = 0.f, sb = 0.f;
-        for (int k = 0; k < 64; ++k) {
-            const float w = a.fn1w[tid * 64 + k];
-            sa = fmaf(w, a.p2w[k], sa);
-            sb = fmaf(w, a.p2b[k], sb);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            sa = fmaf(wr[q].x, pw[q].x, sa); sb = fmaf(wr[q].x, pb[q].x, sb);
+            sa = fmaf(wr[q].y, pw[q].y, sa); sb = fmaf(wr[q].y, pb[q].y, sb);
+            sa = fmaf(wr[q].z, pw[q].z, sa); sb = fmaf(wr[q].z, pb[q].z, sb);
+            sa = fmaf(wr[q].w, pw[q].w, sa); sb = fmaf(wr[q].w, pb[q].w, sb);
         }
         sm.A[tid] = sa;
         sm.Bc[tid] = sb + a.fn1b[tid];
@@ -260,6 +270,23 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
     const long ntiles = (long)a.B * tiles_y * tiles_x;
     float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
 
+    // the Y window of a tile (8 x 36 values, at most two per thread) is requested one tile ahead: the only global
+    // reads of the kernel would otherwise expose their full latency once per tile
+    float ynext[2];
+    auto fetch_y = [&](long t) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const int b = (int)(t / ((long)tiles_x * tiles_y));
+        const float* Y = a.img + (long)b * a.img_bstride;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tid + 256 * k;
+            const int yy = ty * 4 - 2 + i / SG_YW, xx = tx * 32 - 2 + i % SG_YW;
+            const bool in = i < SG_YH * SG_YW && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            ynext[k] = in ? w1 * Y[(long)yy * a.W + xx] + b1 : 0.f;
+        }
+    };
+    if ((long)blockIdx.x < ntiles) fetch_y(blockIdx.x);
+
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const int b = (int)(tile / ((long)tiles_x * tiles_y));
@@ -267,13 +294,10 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
         const int y = y0 + wv, x = x0 + tok;
         const bool live = (y < a.H) && (x < a.W);
         const long n = (long)b * HW + (long)y * a.W + x;
-        const float* Y = a.img + (long)b * a.img_bstride;
         __syncthreads();                       // the previous tile's readers of u / v are done
-        for (int i = tid; i < SG_YH * SG_YW; i += 256) {
-            const int yy = y0 - 2 + i / SG_YW, xx = x0 - 2 + i % SG_YW;
-            const bool in = yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
-            sm.u[i] = in ? w1 * Y[(long)yy * a.W + xx] + b1 : 0.f;
-        }
+        sm.u[tid] = ynext[0];
+        if (tid + 256 < SG_YH * SG_YW) sm.u[tid + 256] = ynext[1];
+        if (tile + gridDim.x < ntiles) fetch_y(tile + gridDim.x);     // in flight during this tile
         __syncthreads();
         if (tid < SG_VH * SG_VW) {
             const int vy = tid / SG_VW, vx = tid % SG_VW;
@@ -305,17 +329,23 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const float vn = sm.v[(wv + dy) * SG_VW + tok + dx];
-                    const bool in = vn >= 0.f;
                     const float* wp = &sm.dww[(dy * 3 + dx) * 64 + 32 * h];
+                    if (dy == 1 && dx == 1) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const f32x4 wq = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+                        for (int i = 0; i < 32; ++i) tg[i] = 0.f;
+                    }
+                    // a neighbour outside the image contributes nothing (t is zero-padded): one branch per tap, taken by
+                    // the lanes whose neighbour exists, instead of a select per channel
+                    if (vn >= 0.f) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t = fmaf(Ag[4 * q + e], vn, Bg[4 * q + e]);
-                            t = (in && t > 0.f) ? t : 0.f;
-                            if (dy == 1 && dx == 1) tg[4 * q + e] = t;
-                            g[4 * q + e] += wq[e] * t;
+                        for (int q = 0; q < 8; ++q) {
+                            const f32x4 wq = *reinterpret_cast<const f32x4*>(wp + 4 * q);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float t = fmaxf(fmaf(Ag[4 * q + e], vn, Bg[4 * q + e]), 0.f);
+                                if (dy == 1 && dx == 1) tg[4 * q + e] = t;
+                                g[4 * q + e] = fmaf(wq[e], t, g[4 * q + e]);
+                            }
                         }
                     }
                 }

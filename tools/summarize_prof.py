@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Turns the rocprofv3 output of tools/profile_r01.sh (gpurun_out/prof_r01s/) into the summaries kept under
+"""Turns the rocprofv3 output of tools/profile_r02.sh (gpurun_out/prof_r02/{train,infer}/) into the summaries kept under
 profiles/: kernel stats, the bench line printed under the profiler, HBM bytes per launch per kernel (separate
 FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE is in KB and counts half of the bytes of wide reads on gfx950, so
 read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE in KB is exact).
 
-Usage: python tools/summarize_prof.py [src_dir] [tag]      (defaults: gpurun_out/prof_r01s, r01_train_b64_bf16s)"""
+Usage: python tools/summarize_prof.py [src_dir] [tag]      (defaults: gpurun_out/prof_r02/train, r02_train_b64_bf16s)"""
 import collections
 import csv
 import json
@@ -14,8 +14,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r01s")
-TAG = sys.argv[2] if len(sys.argv) > 2 else "r01_train_b64_bf16s"
+SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r02", "train")
+TAG = sys.argv[2] if len(sys.argv) > 2 else "r02_train_b64_bf16s"
 OUT = os.path.join(ROOT, "profiles")
 
 
@@ -64,6 +64,7 @@ wg = [r for r in rows if r[0].startswith("wgrad_kernel<")]
 if wg:
     per_kernel["entry:ksr_wgrad"] = int(sum(r[6] * r[1] for r in wg) / sum(r[1] for r in wg) + per_kernel.get("reduce_kernel", 0))
 # bench.py reads the default workload's file; other tags keep their own
-with open(os.path.join(OUT, "pmc_hbm_bytes_per_launch.json" if TAG == "r01_train_b64_bf16s" else f"{TAG}_pmc_hbm_bytes_per_launch.json"), "w") as fh:
+with open(os.path.join(OUT, "pmc_hbm_bytes_per_launch.json" if TAG == "r02_train_b64_bf16s" else f"{TAG}_pmc_hbm_bytes_per_launch.json"), "w") as fh:
     json.dump(per_kernel, fh, indent=1)
-print(f"wrote {len(rows)} kernels to profiles/{TAG}_*")
+total = sum(r[6] * r[1] for r in rows)
+print(f"wrote {len(rows)} kernels to profiles/{TAG}_*; HBM bytes over the PMC pass: {total / 1e9:.2f} GB")
