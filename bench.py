@@ -324,6 +324,7 @@ def main():
     roofline = None
     cpu = None
     inference = None
+    by_precision = None
     # ---- per-kernel live timing (events on the launch stream), separate short run.  Every rank steps (the training
     # step contains the gradient all-reduce, a collective); only rank 0 records.
     nlaunch = max(3, min(args.steps, 10))
@@ -376,8 +377,6 @@ def main():
         roofline["launches_per_step"] = len(prof[dom]) // nlaunch
         roofline["ms_per_step_by_entry_point"] = {k: round(v, 4) for k, v in sorted(totals.items())}
         roofline["frac_by_entry_point"] = {k: [price(k)["bound"], price(k)["frac"]] for k in sorted(totals) if k in models}
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline("train-unet" if unet else args.workload)
         if world == 1 and args.workload == "train" and not unet:
             # second half of the headline metric: 1-GPU x4 inference of one 960x540 -> 3840x2160 frame
             model.eval()
@@ -405,6 +404,28 @@ def main():
             inference = {"value": round(3840 * 2160 / 1e6 / ti, 1), "unit": "MP/s", "ms_per_frame": round(ti * 1e3, 4),
                          "ms_per_frame_rgb_in_rgb_out": round(tr * 1e3, 4),
                          "workload": "x4 SR inference fp32 eval, 960x540 -> 3840x2160, 1 GPU (BASELINE configs[1])"}
+            # the same step in the other precision modes (fresh model and step each; 3 warm-up + 10 timed steps), so that
+            # the run that reports the bf16-storage headline also records the fp32-storage and exact-fp32 times
+            by_precision = {args.precision: round(dt / args.steps * 1e3, 4)}
+            for prec in ("bf16s", "bf16", "fp32"):
+                if prec in by_precision:
+                    continue
+                m2 = build_model().to(dev).train()
+                m2.precision = prec
+                ts2 = TrainStep(m2, loss=args.loss)
+                for _ in range(3):
+                    ts2.step(x, tgt)
+                torch.cuda.synchronize()
+                tp = time.perf_counter()
+                for _ in range(10):
+                    ts2.step(x, tgt)
+                torch.cuda.synchronize()
+                by_precision[prec] = round((time.perf_counter() - tp) / 10 * 1e3, 4)
+                ts2.close()
+                del ts2, m2
+            torch.cuda.empty_cache()
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline("train-unet" if unet else args.workload)     # last: its threads stay out of the GPU timings
 
     if args.workload == "train":
         ts.close()                      # every rank: destroys the gradient communicator
@@ -419,7 +440,7 @@ def main():
             "dtype": "bf16" if (args.workload == "train" and args.precision != "fp32") else "f32",
             "data": "synthetic", "config": {"workload": wl, "upscale": 4, "grid_size": 5, "spline_order": 3,
                                             "per_gpu_batch": B, "lr_patch": [H, W]},
-            "roofline": roofline, "cpu_baseline": cpu, "inference": inference}))
+            "roofline": roofline, "cpu_baseline": cpu, "inference": inference, "ms_per_step_by_precision": by_precision}))
 
 
 if __name__ == "__main__":

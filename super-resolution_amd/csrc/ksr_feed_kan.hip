@@ -55,11 +55,12 @@ struct FeedCfg {
     static constexpr int NB = (NH + 15) / 16;
 };
 
-template <int NB>
+template <int NB, bool COAL>
 struct __attribute__((aligned(16))) FeedSmem {
     float frag[NB * 32 * 64];
     float biasfrag[NB * 32];
     float knots[KSR_MAX_KNOTS];
+    float xpose[COAL ? 4 * KSR_XPOSE_FLOATS : 4];     // per-wave transposers of the coalesced feature loads
 };
 
 template <int PREC, int R, int KC, int KORD>
@@ -67,7 +68,11 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
     using C = FeedCfg<R, KC>;
     constexpr int NB = C::NB;
     using ST = typename KsrStore<PREC>::T;
-    __shared__ FeedSmem<NB> sm;
+    // bf16 storage: the wave's 32 feature rows are fetched with lane-linear 16-byte loads one tile ahead of their use
+    // (the kernel is bound by memory latency there).  fp32 storage (the exact mode is bound by the fp32 matrix pipe and
+    // runs three waves per SIMD): every lane loads its own 128 bytes, which needs neither the LDS nor the registers.
+    constexpr bool COAL = sizeof(ST) == 2;
+    __shared__ FeedSmem<NB, COAL> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
     ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.w, 64, a.bias, MapKan{C::O, KC}, MapHL{32}, tid, 256);
@@ -77,6 +82,14 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
     const int HW = a.H * a.W;
     const long N = (long)a.B * HW;
     const long ntiles = (N + 127) / 128;
+    float* xb = sm.xpose + (COAL ? wv * KSR_XPOSE_FLOATS : 0);
+    KsrTile<ST> ahead;
+    auto fetch_tile = [&](long t) {
+        const long r0 = t * 128 + wv * 32;
+        const int nv = (N - r0) < 32 ? (int)(N - r0 > 0 ? N - r0 : 0) : 32;
+        ksr_co_fetch<ST, true>(a.feat, r0, nv, 64, 0, lane, ahead);
+    };
+    if (COAL && (long)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long n = tile * 128 + wv * 32 + tok;
         const bool live = n < N;
@@ -85,10 +98,15 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
         const int y = hw / a.W, x = hw % a.W;
 
         float f[32];
-        if (live) ksr_loadn<ST, 32>(a.feat, n * 64 + 32 * h, f);
-        else {
+        if constexpr (COAL) {
+            ksr_co_finish<ST>(xb, lane, ahead, f);
+            if (tile + gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
+        } else {
+            if (live) ksr_loadn<ST, 32>(a.feat, n * 64 + 32 * h, f);
+            else {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) f[i] = 0.f;
+                for (int i = 0; i < 32; ++i) f[i] = 0.f;
+            }
         }
         f32x16 acc[NB];
         ksr_wave_gemm<PREC, 32, NB>(sm.frag, sm.biasfrag, f, acc, lane);
@@ -99,22 +117,30 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
         dense_basis<KC>(m, Nv, KORD, bv);
         const float sl = ksr_silu(xv);
 
-        float yv[C::OH];
+        float yv[C::OH], us[2 * C::OH];
 #pragma unroll
         for (int ol = 0; ol < C::OH; ++ol) {
             float S = 0.f;
 #pragma unroll
             for (int g = 0; g < KC; ++g) {
-                constexpr int dummy = 0; (void)dummy;
                 const int e = ol * C::PER + g;
                 S += bv[g] * acc[e / 16][e % 16];
             }
             const int eu = ol * C::PER + KC, er = eu + 1;
             const float uw = acc[eu / 16][eu % 16], rw = acc[er / 16][er % 16];
             yv[ol] = rw * sl + uw * S;
-            if (a.save_us && live) {
-                a.save_us[(n * C::O + h * C::OH + ol) * 2 + 0] = uw;
-                a.save_us[(n * C::O + h * C::OH + ol) * 2 + 1] = S;
+            us[2 * ol] = uw; us[2 * ol + 1] = S;
+        }
+        if (a.save_us && live) {
+            // (uw, S) of this lane's OH outputs: 2 * OH consecutive floats
+            float* sp = a.save_us + (n * C::O + h * C::OH) * 2;
+            if constexpr ((2 * C::OH) % 4 == 0) {
+#pragma unroll
+                for (int q = 0; q < 2 * C::OH / 4; ++q)
+                    reinterpret_cast<float4*>(sp)[q] = make_float4(us[4 * q], us[4 * q + 1], us[4 * q + 2], us[4 * q + 3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2 * C::OH; ++q) sp[q] = us[q];
             }
         }
         if (live) {
