@@ -423,3 +423,46 @@ def test_gradient_exchange_schedule_order():
     # the 1/world scaling is applied by Adam: a second, exchange-free step on the same data with doubled gradients
     # is not needed here; the gloo test in test_host_logic.py covers the arithmetic
     ts.close()
+
+
+def test_ddp_comm_hook_through_rccl_single_rank():
+    """torch DistributedDataParallel (what Lightning's DDP strategy wraps) with ksr_allreduce_hook: every gradient bucket
+    goes through libksr's RCCL communicator; with one rank the result must equal the plain module's gradients bit for
+    bit, and an optimizer step on the wrapped module trains the same parameters."""
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    from kan_sr.ddp import KsrCommState, ksr_allreduce_hook
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29547", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    state = None
+    try:
+        torch.manual_seed(3)
+        x = torch.rand(2, 3, 8, 32).cuda()
+        gy = torch.randn(2, 3, 32, 128).cuda()
+        ma, _ = _model(4, seed=5)
+        mb, _ = _model(4, seed=5)
+        ma, mb = ma.cuda().eval(), mb.cuda().eval()
+        ma(x).backward(gy)
+        ddp = DDP(mb, device_ids=[0])
+        state = KsrCommState(0, 1)
+        ddp.register_comm_hook(state, ksr_allreduce_hook)
+        ddp(x).backward(gy)
+        torch.cuda.synchronize()
+        assert state.buckets_reduced >= 1
+        for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            assert torch.equal(pa.grad, pb.grad), n
+    finally:
+        if state is not None:
+            state.close()
+        dist.destroy_process_group()
+
+
+def test_lightning_strategy_reports_missing_package():
+    from kan_sr._lib import KsrError
+    from kan_sr.ddp import lightning_strategy
+    try:
+        import lightning  # noqa: F401
+    except ImportError:
+        with pytest.raises(KsrError, match="lightning"):
+            lightning_strategy()
