@@ -197,6 +197,15 @@ int ksr_batch_attn_bwd(const float* qkv, const float* ctx, const float* dctx, fl
 int ksr_in_proj_bwd(const float* dqkv, const float* in_w, const float* resid, const float* y_saved, float* ds, int B,
                     int H, int W, ksr_stream_t stream);
 
+/* ksr_in_proj_bwd and the in-projection's weight / bias gradient (ksr_wgrad(dqkv, x_in)) in one pass over dqkv, the widest
+ * tensor of the transformer backward: bf16 storage mode (ksr_set_precision(2)) only, other modes return
+ * KSR_ERR_UNSUPPORTED.  x_in [N,64] is the layer's input; sigmoid_input != 0: ds is also multiplied by x_in (1 - x_in) (the
+ * first layer, whose input is a sigmoid output, gazetr.py:107).  slab: ksr_in_proj_bwd_wg_slab_floats() floats of
+ * workspace; dW [192,64], db [192].  Deterministic. */
+int64_t ksr_in_proj_bwd_wg_slab_floats(void);
+int ksr_in_proj_bwd_wg(const float* dqkv, const float* in_w, const float* resid, const float* x_in, int sigmoid_input,
+                       float* ds, float* slab, float* dW, float* db, int64_t N, ksr_stream_t stream);
+
 /* GatedFFN tail backward (backward of ksr_gate_pw_fwd without its sigmoid, which the producer of dz has
  * already applied): dA = dz * fn_2.weight; dt_value = dA * gate * (t[:, :64] > 0) written to channels 0..63
  * of dt [N,128]; dgate [N,64] = dA * t[:, :64]. */

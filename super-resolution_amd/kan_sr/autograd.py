@@ -104,10 +104,12 @@ class _Ws:
         return engine.act_dtype() is torch.bfloat16
 
     def fused_slab(self):
-        """Workspace of the fused weight gradients.  One per call site would allow overlap; the launches that use it are
-        ordered on one stream, and each call's reduction has consumed the rows before the next call's kernel starts."""
+        """Workspace of the weight gradients that data-gradient kernels accumulate themselves.  All of those launches are
+        on the caller's stream, in order, and each call's reduction has consumed the rows before the next call's kernel
+        starts; it must stay apart from slab(), which the reductions on the second stream use concurrently."""
         if self._fused_slab is None:
-            self._fused_slab = torch.empty(int(lib().ksr_fused_wgrad_slab_floats()), device=self.dev, dtype=torch.float32)
+            n = max(int(lib().ksr_fused_wgrad_slab_floats()), int(lib().ksr_in_proj_bwd_wg_slab_floats()))
+            self._fused_slab = torch.empty(n, device=self.dev, dtype=torch.float32)
         return self._fused_slab
 
     def sums_slab(self):
@@ -197,9 +199,17 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     check(attn_bwd(ptr(sv["qkv"]), ptr(sv["ctx"]), ptr(dctx), ptr(dqkv), c_int(g.B), c_int(g.H * g.W), c_float(p_drop),
                    c_uint64(lseed), stream()), "attention backward")
     gw, gb = ws.grad(q + "self_attn.in_proj_weight", 192, 64), ws.grad(q + "self_attn.in_proj_bias", 192)
-    _wgrad(ws, dqkv, 192, 0, 192, sv["in"], 64, 0, 64, N, gw, gb)
     grads[q + "self_attn.in_proj_weight"], grads[q + "self_attn.in_proj_bias"] = gw, gb
     dsin = ws.act(N, 64)
+    if ws.fused_wgrad():
+        # bf16 storage: data gradient and weight gradient of the in-projection share one pass over dqkv
+        assert y_in_sigmoid is None or y_in_sigmoid.data_ptr() == sv["in"].data_ptr()
+        slab = ws.fused_slab()      # not ws.slab(): that one belongs to the reductions on the second stream
+        check(L.ksr_in_proj_bwd_wg(ptr(dqkv), ptr(p[q + "self_attn.in_proj_weight"]), ptr(du1), ptr(sv["in"]),
+                                   c_int(0 if y_in_sigmoid is None else 1), ptr(dsin), ptr(slab), ptr(gw), ptr(gb),
+                                   c_int64(N), stream()), "ksr_in_proj_bwd_wg")
+        return dsin
+    _wgrad(ws, dqkv, 192, 0, 192, sv["in"], 64, 0, 64, N, gw, gb)
     check(L.ksr_in_proj_bwd(ptr(dqkv), ptr(p[q + "self_attn.in_proj_weight"]), ptr(du1), ptr(y_in_sigmoid), ptr(dsin),
                             *_dims(g), stream()), "ksr_in_proj_bwd")
     return dsin

@@ -511,3 +511,44 @@ def test_fused_weight_gradient_equals_separate_wgrad(B, H, W):
         assert rc == -2
     finally:
         engine.set_precision("fp32")
+
+
+@pytest.mark.parametrize("N", [32, 1000, 128 * 128 * 16 + 5])
+@pytest.mark.parametrize("sig", [0, 1])
+def test_fused_in_proj_backward_equals_separate_kernels(N, sig):
+    """bf16 storage mode: ksr_in_proj_bwd_wg (data gradient + weight / bias gradient of the attention in-projection in one
+    pass over dqkv) against ksr_in_proj_bwd + ksr_wgrad on the same bf16 tensors, and against an fp64 evaluation."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(N + sig)
+    L = lib()
+    bf = lambda *s: torch.randn(*s, device="cuda").bfloat16()
+    dqkv, resid = bf(N, 192), bf(N, 64)
+    xin = torch.rand(N, 64, device="cuda").bfloat16()
+    w = torch.randn(192, 64, device="cuda") * 0.1
+    engine.set_precision("bf16s")
+    try:
+        ds0, ds1 = torch.empty(N, 64, device="cuda").bfloat16(), torch.full((N, 64), float("nan"), device="cuda").bfloat16()
+        dW0, db0, dW1, db1 = (torch.empty(s, device="cuda") for s in ((192, 64), (192,), (192, 64), (192,)))
+        ws = torch.empty(int(L.ksr_wgrad_slab_floats(c_int(192), c_int(64))), device="cuda")
+        slab = torch.empty(int(L.ksr_in_proj_bwd_wg_slab_floats()), device="cuda")
+        check(L.ksr_in_proj_bwd(ptr(dqkv), ptr(w), ptr(resid), ptr(xin) if sig else None, ptr(ds0), c_int(1), c_int(1), c_int(N),
+                                stream()), "in_proj_bwd")
+        check(L.ksr_wgrad(ptr(dqkv), c_int(192), c_int(0), c_int(192), ptr(xin), c_int(64), c_int(0), c_int(64), None, c_int(0),
+                          c_int(0), c_int64(N), ptr(ws), ptr(dW0), ptr(db0), c_int(0), c_int(0), stream()), "wgrad")
+        check(L.ksr_in_proj_bwd_wg(ptr(dqkv), ptr(w), ptr(resid), ptr(xin), c_int(sig), ptr(ds1), ptr(slab), ptr(dW1), ptr(db1),
+                                   c_int64(N), stream()), "in_proj_bwd_wg")
+        ref = resid.double() + dqkv.double() @ w.bfloat16().double()
+        if sig:
+            ref = ref * xin.double() * (1 - xin.double())
+        assert rel_l2(ds1.float().cpu(), ref.cpu()) <= 4e-3          # bf16 output rounding
+        assert rel_l2(ds1.float().cpu(), ds0.float().cpu()) <= 3e-3
+        assert rel_l2(dW1.cpu(), (dqkv.double().T @ xin.double()).cpu()) <= 1e-5
+        assert rel_l2(dW1.cpu(), dW0.cpu()) <= 1e-5
+        assert rel_l2(db1.cpu(), dqkv.double().sum(0).cpu()) <= 1e-5 and rel_l2(db1.cpu(), db0.cpu()) <= 1e-5
+        dW2, db2, ds2 = torch.empty_like(dW1), torch.empty_like(db1), torch.empty_like(ds1)
+        check(L.ksr_in_proj_bwd_wg(ptr(dqkv), ptr(w), ptr(resid), ptr(xin), c_int(sig), ptr(ds2), ptr(slab), ptr(dW2), ptr(db2),
+                                   c_int64(N), stream()), "in_proj_bwd_wg")
+        assert torch.equal(dW1, dW2) and torch.equal(db1, db2) and torch.equal(ds1.view(torch.int16), ds2.view(torch.int16))
+    finally:
+        engine.set_precision("fp32")
