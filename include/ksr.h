@@ -95,10 +95,11 @@ int ksr_stem_fwd(const float* x_img, int64_t img_batch_stride, const float* pw1_
  * params[14]: ffn1.pointwise1 {weight, bias}, ffn1.depthwise {weight [9], bias}, ffn1.pointwise2 {weight [64], bias},
  * ffn2.fn_1.0 {weight [128,64], bias}, ffn2.gate {weight [64,9], bias}, ffn2.fn_2 {weight [64,64], bias},
  * ffn3.pointwise1 {weight [64,64], bias}.  t3_out [N,64] = ffn3.pointwise1(sigmoid(ffn2(ffn1(Y)))).
- * Training passes all four saves: v [N] (fp32), t [N,128] = relu(fn_1(x1)), gate [N,64], x3 [N,64] = sigmoid(ffn2);
- * inference passes none. */
+ * Training passes v [N] (fp32), gate [N,64], x3 [N,64] = sigmoid(ffn2) and t [N,128] = relu(fn_1(x1)) and / or ab [256]
+ * (fp32: A [128] | B [128]): the backward entry points with a `_v` suffix rebuild t from (v, ab) and do not need the
+ * tensor.  Inference passes none. */
 int ksr_stem_gate_fwd(const float* x_img, int64_t img_batch_stride, const float* const* params, float* t3_out,
-                      float* save_v, float* save_t, float* save_gate, float* save_x3, int B, int H, int W,
+                      float* save_v, float* save_t, float* save_gate, float* save_x3, float* save_ab, int B, int H, int W,
                       ksr_stream_t stream);
 
 /* 1x1 conv 64 -> n_out with activation act (0 none, 1 ReLU): FFN.pointwise1 (n_out 64, act 0;
@@ -243,6 +244,20 @@ int ksr_gate_pw_bwd_wg(const float* dz, const float* fn2_w, const float* gate_sa
                        ksr_stream_t stream);
 int ksr_pw2_bwd_wg(const float* dy, const float* pw2_w, const float* operand_saved, float* ds, float* slab, float* dW,
                    float* db, int B, int H, int W, ksr_stream_t stream);
+
+/* First gated block (ffn2, whose input is ffn1): variants of ksr_gate_pw_bwd(_wg), ksr_fn1_bwd (stem form with column sums)
+ * and ksr_dwconv_wgrad that rebuild the saved tensor t [N,128] = relu(fn_1(ffn1(Y))) from the per-pixel scalar v_saved [N]
+ * and ab = A [128] | B [128] (both written by ksr_stem_gate_fwd): t[n][c] = relu(A[c] v[n] + B[c]).  The tensor is then
+ * neither written by the forward nor read by the backward.  ksr_gate_pw_bwd_v: slab/dW/db non-NULL (bf16 storage mode)
+ * also accumulates fn_2's weight gradient as ksr_gate_pw_bwd_wg does; NULL = data gradient only, any mode. */
+int ksr_gate_pw_bwd_v(const float* dz, const float* fn2_w, const float* gate_saved, const float* v_saved, const float* ab,
+                      float* dt_value, float* dgate, float* slab, float* dW, float* db, int B, int H, int W,
+                      ksr_stream_t stream);
+int ksr_fn1_bwd_stem_v(float* dt, const float* dgate, const float* gate_w, const float* v_saved, const float* ab,
+                       const float* fn1_w, const float* pw2_w, float* dpre, float* sums_slab, float* dt_sums, float* dx_sums,
+                       int dx_row_stride, int B, int H, int W, ksr_stream_t stream);
+int ksr_dwconv_wgrad_v(const float* v_saved, const float* ab, const float* ds, int ds_ld, int ds_c0, float* slab, float* dW,
+                       float* db, int B, int H, int W, ksr_stream_t stream);
 
 /* Weight gradient of a 1x1 conv / linear layer: dW[j][k] = sum_n dz[n, dz_c0+j] * a1[n, a1_c0+k]
  * (* a2[n, a2_c0+k] when a2 != NULL), db[j] = sum_n dz[n, dz_c0+j].  J % 32 == 0, K in {32, 64}.

@@ -28,6 +28,7 @@ struct BwdArgs {
     const float* v; const float* p2w; float* dpre;   // STEM epilogue
     float* sums_slab;                           // STEM, optional: [3][gridDim.x][2][64] per-workgroup column sums
     float* wg_slab;                             // WGF: [gridDim.x][KSR_WGF_ROW] partial weight / bias gradients of the 1x1 conv
+    const float* aff_v; const float* aff_ab;    // AFF: the 128-channel tensor t (e2 / mask_src) is relu(A[c] v[n] + B[c]): v [N], A|B [256]
     int B, H, W;
 };
 
@@ -36,6 +37,7 @@ struct __attribute__((aligned(16))) BwdSmem {
     float frag[2 * (KIN / 2) * 64 / (PREC != KSR_F32 ? 2 : 1)];
     float dww[BPRO == BPRO_PLAIN ? 4 : 9 * 64];
     float p2w[64];
+    float aff[256];
     float halo[BPRO == BPRO_PLAIN ? 4 : HALO_FLOATS];
     // per-wave LDS transposers of the coalesced loads / stores (the stencil variants reuse the halo tile)
     float xpose[BPRO == BPRO_PLAIN ? 4 * KSR_XPOSE_FLOATS : 4];
@@ -44,8 +46,12 @@ static_assert(4 * KSR_XPOSE_FLOATS <= HALO_FLOATS, "transposers must fit in the 
 
 // WGF: the kernel also accumulates the weight and bias gradient of the forward 1x1 conv whose output gradient is dz
 // (KIN = 64; the conv's input is an operand of the epilogue: value * gate, the ReLU operand, or the sigmoid output).
-template <int PREC, int KIN, int BPRO, int BEPI, bool WGF = false>
+// AFF: the saved 128-channel tensor of the first gated block is not read but rebuilt from one scalar per pixel,
+// t[n][c] = relu(A[c] v[n] + B[c]) (see stem_gate_fwd_kernel): the value half in the GATE epilogue, the sign of the
+// gate half as the CONVT_G mask.
+template <int PREC, int KIN, int BPRO, int BEPI, bool WGF = false, bool AFF = false>
 __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
+    static_assert(!AFF || BEPI == BEPI_GATE || BPRO == BPRO_CONVT_G, "AFF replaces e2 (GATE) or mask_src (CONVT_G)");
     static_assert(!WGF || (KIN == 64 && PREC == KSR_BF16S && BPRO == BPRO_PLAIN && (BEPI == BEPI_GATE || BEPI == BEPI_RELUMASK)),
                   "fused weight gradient: 64 -> 64 convs, bf16 storage mode, no stencil prologue (register budget)");
     constexpr int KH = KIN / 2;
@@ -56,6 +62,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.wt, 64, nullptr, MapHL{32}, MapHL{KH}, tid, 256);
     if (BPRO != BPRO_PLAIN) ksr_stage_dw<true>(sm.dww, a.dw_w, tid);
     if (BEPI == BEPI_STEM && tid < 64) sm.p2w[tid] = a.p2w[tid];
+    if (AFF) sm.aff[tid] = a.aff_ab[tid];
     __syncthreads();
 
     const int HW = a.H * a.W;
@@ -69,7 +76,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     // has been unpacked, the epilogue operands after the previous epilogue has consumed its own (wide inputs only)
     constexpr bool PRE_R = BPRO == BPRO_PLAIN && (BEPI == BEPI_RESID || BEPI == BEPI_RESID_SIGGRAD);
     constexpr bool PRE_E1 = BPRO == BPRO_PLAIN && (BEPI == BEPI_RELUMASK || BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD || BEPI == BEPI_GATE);
-    constexpr bool PRE_E2 = BPRO == BPRO_PLAIN && BEPI == BEPI_GATE;
+    constexpr bool PRE_E2 = BPRO == BPRO_PLAIN && BEPI == BEPI_GATE && !AFF;
     constexpr bool AHEAD = BPRO == BPRO_PLAIN && sizeof(ST) == 2 && KIN > 64;     // the 64-wide instances keep 3 waves per SIMD without it
     KsrTile<ST> f[KIN / 64], pf_r, pf_e1, pf_e2;
     auto fetch_dz = [&](long t) {
@@ -148,7 +155,13 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             __syncthreads();       // every wave is done with the halo tile: it now serves as the transposers
             if (BPRO == BPRO_CONVT_G) {
                 float mk[32], t[32];
-                ksr_load32_co<ST>(xb, a.mask_src, n0w, nvalid, a.mask_ld, a.mask_c0, lane, mk);
+                if constexpr (AFF) {
+                    const float vv = live ? a.aff_v[n] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) mk[i] = live ? fmaf(sm.aff[64 + 32 * h + i], vv, sm.aff[192 + 32 * h + i]) : 0.f;   // t is 0 outside the image
+                } else {
+                    ksr_load32_co<ST>(xb, a.mask_src, n0w, nvalid, a.mask_ld, a.mask_c0, lane, mk);
+                }
 #pragma unroll
                 for (int i = 0; i < 32; ++i) g[i] = mk[i] > 0.f ? g[i] : 0.f;
                 ksr_load32_co<ST>(xb, a.dz, n0w, nvalid, a.dz_ld, 0, lane, t);
@@ -221,7 +234,11 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             float gte[32], val[32], o2[32];
             if constexpr (PRE_E1) ksr_co_finish<ST>(xb, lane, pf_e1, gte);
             else ksr_load32_co<ST>(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, gte);
-            if constexpr (PRE_E2) ksr_co_finish<ST>(xb, lane, pf_e2, val);
+            if constexpr (AFF) {
+                const float vv = live ? a.aff_v[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) val[i] = live ? fmaxf(fmaf(sm.aff[32 * h + i], vv, sm.aff[128 + 32 * h + i]), 0.f) : 0.f;
+            } else if constexpr (PRE_E2) ksr_co_finish<ST>(xb, lane, pf_e2, val);
             else ksr_load32_co<ST>(xb, a.e2, n0w, nvalid, a.e2_ld, a.e2_c0, lane, val);
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
@@ -297,31 +314,31 @@ unsigned dgrad_grid(const BwdArgs& a, bool spatial) {
     return (unsigned)(ntiles < cap ? ntiles : cap);
 }
 
-template <int PREC, int KIN, int BPRO, int BEPI>
+template <int PREC, int KIN, int BPRO, int BEPI, bool AFF = false>
 int launch_dgrad_p(const BwdArgs& a, hipStream_t s) {
     const long N = (long)a.B * a.H * a.W;
     const bool spatial = BPRO != BPRO_PLAIN;
     const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
     const long cap = spatial ? 512 : 768;
-    hipLaunchKernelGGL((dgrad_kernel<PREC, KIN, BPRO, BEPI>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dgrad_kernel<PREC, KIN, BPRO, BEPI, false, AFF>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("dgrad");
     return KSR_OK;
 }
 
 // Data gradient + fused weight gradient of a 64 -> 64 conv (bf16 storage mode), then the reduction of the partial rows.
-template <int BPRO, int BEPI>
+template <int BPRO, int BEPI, bool AFF = false>
 int launch_dgrad_wgf(const BwdArgs& a, float* dW, float* db, hipStream_t s) {
     KSR_CHECK_ARG(a.wg_slab && dW && db, "fused weight gradient: null pointer");
     KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "fused weight gradient: bf16 storage mode only (the other modes use ksr_wgrad)");
     const unsigned grid = dgrad_grid(a, BPRO != BPRO_PLAIN);
-    hipLaunchKernelGGL((dgrad_kernel<KSR_BF16S, 64, BPRO, BEPI, true>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((dgrad_kernel<KSR_BF16S, 64, BPRO, BEPI, true, AFF>), dim3(grid), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("dgrad(fused weight gradient)");
     return ksr_slab_reduce(a.wg_slab, (int)grid, 64, 64, dW, db, s);
 }
 
-template <int KIN, int BPRO, int BEPI>
+template <int KIN, int BPRO, int BEPI, bool AFF = false>
 int launch_dgrad(const BwdArgs& a, hipStream_t s) {
-#define KSR_CALL(P) return launch_dgrad_p<P, KIN, BPRO, BEPI>(a, s)
+#define KSR_CALL(P) return launch_dgrad_p<P, KIN, BPRO, BEPI, AFF>(a, s)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     return KSR_OK;
@@ -458,4 +475,37 @@ extern "C" int ksr_pw2_bwd_wg(const float* dy, const float* pw2_w, const float* 
     a.dz = dy; a.dz_ld = 64; a.wt = pw2_w; a.e1 = operand_saved; a.e1_ld = 64; a.out1 = ds; a.out1_ld = 64;
     a.wg_slab = slab; a.B = B; a.H = H; a.W = W;
     return launch_dgrad_wgf<BPRO_PLAIN, BEPI_RELUMASK>(a, dW, db, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// First gated block (ffn2, whose input is ffn1): the saved tensor t [N,128] = relu(fn_1(ffn1(Y))) is rebuilt from the
+// per-pixel scalar v and the coefficients ab = A [128] | B [128] that ksr_stem_gate_fwd wrote, t[n][c] = relu(A[c] v[n] +
+// B[c]), instead of being read (and, in the forward, written): the `_v` variants of the three backward entry points
+// that consume it.
+extern "C" int ksr_gate_pw_bwd_v(const float* dz, const float* fn2_w, const float* gate_saved, const float* v_saved,
+                                 const float* ab, float* dt_value, float* dgate, float* slab, float* dW, float* db, int B,
+                                 int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dz && fn2_w && gate_saved && v_saved && ab && dt_value && dgate, "gate_pw_bwd_v: null pointer");
+    if (int rc = dims_ok(B, H, W, "gate_pw_bwd_v")) return rc;
+    BwdArgs a{};
+    a.dz = dz; a.dz_ld = 64; a.wt = fn2_w; a.e1 = gate_saved; a.e1_ld = 64; a.aff_v = v_saved; a.aff_ab = ab;
+    a.out1 = dt_value; a.out1_ld = 128; a.out1_c0 = 0; a.out2 = dgate; a.wg_slab = slab; a.B = B; a.H = H; a.W = W;
+    if (slab) return launch_dgrad_wgf<BPRO_PLAIN, BEPI_GATE, true>(a, dW, db, stream);     // bf16 storage: + fn_2's weight gradient
+    return launch_dgrad<64, BPRO_PLAIN, BEPI_GATE, true>(a, stream);
+}
+
+extern "C" int ksr_fn1_bwd_stem_v(float* dt, const float* dgate, const float* gate_w, const float* v_saved, const float* ab,
+                                  const float* fn1_w, const float* pw2_w, float* dpre, float* sums_slab, float* dt_sums,
+                                  float* dx_sums, int dx_row_stride, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dt && dgate && gate_w && v_saved && ab && fn1_w && pw2_w && dpre && sums_slab && dt_sums && dx_sums &&
+                  dx_row_stride >= 64, "fn1_bwd_stem_v: bad argument");
+    if (int rc = dims_ok(B, H, W, "fn1_bwd_stem_v")) return rc;
+    BwdArgs a{};
+    a.dz = dt; a.dz_ld = 128; a.halo_src = dgate; a.dw_w = gate_w; a.aff_v = v_saved; a.aff_ab = ab;
+    a.wt = fn1_w; a.B = B; a.H = H; a.W = W; a.v = v_saved; a.p2w = pw2_w; a.dpre = dpre; a.sums_slab = sums_slab;
+    if (int rc = launch_dgrad<128, BPRO_CONVT_G, BEPI_STEM, true>(a, stream)) return rc;
+    ColRedArgs r{sums_slab, (int)dgrad_grid(a, true), {dt_sums, dt_sums + 64, dx_sums}, {128, 128, dx_row_stride}};
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(3, 4), dim3(1024), 0, stream, r);
+    KSR_LAUNCH_CHECK("fn1_bwd_stem_v(column sums)");
+    return KSR_OK;
 }

@@ -210,7 +210,8 @@ struct StemGateArgs {
     const float *fn2w, *fn2b;                                  // ffn2.fn_2 [64,64], [64]
     const float *pw1w, *pw1b;                                  // ffn3.pointwise1 [64,64], [64]
     float* t3;                                                 // [N,64] ffn3.pointwise1 output
-    float *sv_v, *sv_t, *sv_g, *sv_x3;                         // training saves: v [N], t [N,128], gate [N,64], x3 [N,64]
+    float *sv_v, *sv_t, *sv_g, *sv_x3;                         // training saves: v [N], t [N,128] (optional), gate [N,64], x3 [N,64]
+    float* sv_ab;                                              // training, optional: A [128] | B [128] of t = relu(A v + B)
     int B, H, W;
 };
 
@@ -258,6 +259,7 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
         }
         sm.A[tid] = sa;
         sm.Bc[tid] = sb + a.fn1b[tid];
+        if (a.sv_ab && blockIdx.x == 0) { a.sv_ab[tid] = sa; a.sv_ab[128 + tid] = sb + a.fn1b[tid]; }
     }
     const float w1 = a.p1w[0], b1 = a.p1b[0], db1 = a.dw1b[0];
     float k1[9];
@@ -367,8 +369,10 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
         const int nvalid = (y < a.H) ? (a.W - x0 < 32 ? a.W - x0 : 32) : 0;
         if (a.sv_v) {
             if (live && h == 0) a.sv_v[n] = vc;
-            ksr_store32_co<ST>(xb, a.sv_t, n0w, nvalid, 128, 0, lane, val);
-            ksr_store32_co<ST>(xb, a.sv_t, n0w, nvalid, 128, 64, lane, tg);
+            if (a.sv_t) {
+                ksr_store32_co<ST>(xb, a.sv_t, n0w, nvalid, 128, 0, lane, val);
+                ksr_store32_co<ST>(xb, a.sv_t, n0w, nvalid, 128, 64, lane, tg);
+            }
             ksr_store32_co<ST>(xb, a.sv_g, n0w, nvalid, 64, 0, lane, g);
         }
         f32x16 acc[2];
@@ -479,19 +483,19 @@ extern "C" int ksr_gate_pw_fwd(const float* t_in, const float* gate_w, const flo
 }
 
 extern "C" int ksr_stem_gate_fwd(const float* x_img, int64_t img_batch_stride, const float* const* params, float* t3_out,
-                                 float* save_v, float* save_t, float* save_gate, float* save_x3, int B, int H, int W,
-                                 hipStream_t stream) {
+                                 float* save_v, float* save_t, float* save_gate, float* save_x3, float* save_ab, int B, int H,
+                                 int W, hipStream_t stream) {
     KSR_CHECK_ARG(x_img && params && t3_out, "stem_gate_fwd: null pointer");
     for (int i = 0; i < 14; ++i) KSR_CHECK_ARG(params[i] != nullptr, "stem_gate_fwd: params[%d] is null", i);
-    const bool any = save_v || save_t || save_gate || save_x3, all = save_v && save_t && save_gate && save_x3;
-    KSR_CHECK_ARG(!any || all, "stem_gate_fwd: pass all four save tensors (training) or none (inference)");
+    const bool any = save_v || save_t || save_gate || save_x3 || save_ab, all = save_v && save_gate && save_x3 && (save_t || save_ab);
+    KSR_CHECK_ARG(!any || all, "stem_gate_fwd: training passes save_v, save_gate, save_x3 and save_t and / or save_ab; inference none");
     if (int rc = check_dims(B, H, W, "stem_gate_fwd")) return rc;
     StemGateArgs a{};
     a.img = x_img; a.img_bstride = img_batch_stride;
     a.p1w = params[0]; a.p1b = params[1]; a.dw1w = params[2]; a.dw1b = params[3]; a.p2w = params[4]; a.p2b = params[5];
     a.fn1w = params[6]; a.fn1b = params[7]; a.gw = params[8]; a.gb = params[9]; a.fn2w = params[10]; a.fn2b = params[11];
     a.pw1w = params[12]; a.pw1b = params[13];
-    a.t3 = t3_out; a.sv_v = save_v; a.sv_t = save_t; a.sv_g = save_gate; a.sv_x3 = save_x3;
+    a.t3 = t3_out; a.sv_v = save_v; a.sv_t = save_t; a.sv_g = save_gate; a.sv_x3 = save_x3; a.sv_ab = save_ab;
     a.B = B; a.H = H; a.W = W;
 #define KSR_CALL(P) return launch_stem_gate_p<P>(a, stream)
     KSR_DISPATCH_PREC(KSR_CALL);

@@ -389,11 +389,12 @@ struct DwgArgs {
     const float* ds; int ds_ld, ds_c0;     // gradient of the conv output, 64 channels from ds_c0
     float* slab;                           // [grid][10][64]: 9 taps + bias
     int B, H, W;
+    const float* aff_v; const float* aff_ab;   // AFF: in[n][c] = relu(A[64 + c] v[n] + B[64 + c]) (v [N], A|B [256]) instead of a tensor
 };
 
-template <class T>   // storage type of in and ds
+template <class T, bool AFF = false>   // storage type of in and ds; AFF: the conv input is rebuilt from one scalar per pixel
 __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
-    __shared__ __attribute__((aligned(16))) float halo[HALO_FLOATS];
+    __shared__ __attribute__((aligned(16))) float halo[AFF ? HALO_H * HALO_W : HALO_FLOATS];
     __shared__ float red[10][4][64];
     const int tid = threadIdx.x, c = tid & 63, row = tid >> 6;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
@@ -406,6 +407,7 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
     // its share of the halo tile (rows / columns outside the image are loaded from a clamped address and zeroed later)
     KsrHalo<T> hr;
     T dnext[32];
+    float vnext = 0.f;
     auto fetch = [&](long t) {
         const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
         const int b = (int)(t / ((long)tiles_x * tiles_y));
@@ -419,8 +421,16 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
             const int cc = col < xmax ? col : xmax - 1;
             dnext[col] = dsp[(long)cc * a.ds_ld];
         }
-        ksr_halo_fetch<T>(a.in, a.in_ld, a.in_c0, b, y0, x0, a.H, a.W, tid, hr);
+        if constexpr (AFF) {
+            // this thread's pixel of the 6 x 34 window of v (-1 marks a pixel outside the image; v >= 0 inside)
+            const int hy = tid / HALO_W, hx = tid % HALO_W, gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+            const bool in = tid < HALO_H * HALO_W && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            vnext = in ? a.aff_v[(long)b * HW + (long)gy * a.W + gx] : -1.f;
+        } else {
+            ksr_halo_fetch<T>(a.in, a.in_ld, a.in_c0, b, y0, x0, a.H, a.W, tid, hr);
+        }
     };
+    const float Ac = AFF ? a.aff_ab[64 + c] : 0.f, Bc = AFF ? a.aff_ab[192 + c] : 0.f;
     if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
@@ -431,7 +441,8 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
 #pragma unroll
         for (int col = 0; col < 32; ++col) dv[col] = (float)dnext[col];
         __syncthreads();
-        ksr_halo_commit<T>(halo, tid, hr);
+        if constexpr (AFF) { if (tid < HALO_H * HALO_W) halo[tid] = vnext; }
+        else ksr_halo_commit<T>(halo, tid, hr);
         __syncthreads();
         if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
         {
@@ -443,11 +454,15 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
             // sliding 3-wide window along the row: 34 LDS reads per tap row instead of 96
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                const float* hp = halo + (row + dy) * HALO_W * HALO_LD + c;
-                float h0 = hp[0], h1 = hp[HALO_LD];
+                const float* hp = AFF ? halo + (row + dy) * HALO_W : halo + (row + dy) * HALO_W * HALO_LD + c;
+                auto at = [&](int k) -> float {
+                    if constexpr (AFF) { const float vv = hp[k]; return vv >= 0.f ? fmaxf(fmaf(Ac, vv, Bc), 0.f) : 0.f; }
+                    else return hp[k * HALO_LD];
+                };
+                float h0 = at(0), h1 = at(1);
 #pragma unroll
                 for (int col = 0; col < 32; ++col) {
-                    const float h2 = hp[(col + 2) * HALO_LD];
+                    const float h2 = at(col + 2);
                     acc[dy * 3 + 0] += dv[col] * h0;
                     acc[dy * 3 + 1] += dv[col] * h1;
                     acc[dy * 3 + 2] += dv[col] * h2;
@@ -694,13 +709,27 @@ extern "C" int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b,
 extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0,
                                 float* slab, float* dW, float* db, int B, int H, int W, hipStream_t stream) {
     KSR_CHECK_ARG(in && ds && slab && dW && db && B > 0 && H > 0 && W > 0 && ds_ld >= 64, "dwconv_wgrad: bad argument");
-    DwgArgs d{in, in_ld, in_c0, ds, ds_ld, ds_c0, slab, B, H, W};
+    DwgArgs d{in, in_ld, in_c0, ds, ds_ld, ds_c0, slab, B, H, W, nullptr, nullptr};
     long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
     const long g = ntiles < 512 ? ntiles : 512;
     if (ksr_prec() == KSR_BF16S) hipLaunchKernelGGL(dwgrad_kernel<__bf16>, dim3((unsigned)g), dim3(256), 0, stream, d);
     else hipLaunchKernelGGL(dwgrad_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, d);
     KSR_LAUNCH_CHECK("dwconv_wgrad");
     // slab rows: tap t (J = 9) x channel (K = 64) then the bias row handled as a 10th row via two calls
+    if (int rc = launch_reduce(slab, (int)g, 9, 64, 640, dW, 1, 9, nullptr, 0, 0, 0, stream)) return rc;
+    return launch_reduce(slab + 576, (int)g, 1, 64, 640, db, 64, 1, nullptr, 0, 0, 0, stream);
+}
+
+// The same for the first gated block's depthwise conv, whose input (the gate half of t) is rebuilt from (v, ab).
+extern "C" int ksr_dwconv_wgrad_v(const float* v_saved, const float* ab, const float* ds, int ds_ld, int ds_c0, float* slab,
+                                  float* dW, float* db, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(v_saved && ab && ds && slab && dW && db && B > 0 && H > 0 && W > 0 && ds_ld >= 64, "dwconv_wgrad_v: bad argument");
+    DwgArgs d{nullptr, 0, 0, ds, ds_ld, ds_c0, slab, B, H, W, v_saved, ab};
+    long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
+    const long g = ntiles < 512 ? ntiles : 512;
+    if (ksr_prec() == KSR_BF16S) hipLaunchKernelGGL((dwgrad_kernel<__bf16, true>), dim3((unsigned)g), dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((dwgrad_kernel<float, true>), dim3((unsigned)g), dim3(256), 0, stream, d);
+    KSR_LAUNCH_CHECK("dwconv_wgrad_v");
     if (int rc = launch_reduce(slab, (int)g, 9, 64, 640, dW, 1, 9, nullptr, 0, 0, 0, stream)) return rc;
     return launch_reduce(slab + 576, (int)g, 1, 64, 640, db, 64, 1, nullptr, 0, 0, 0, stream);
 }

@@ -215,15 +215,19 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     return dsin
 
 
-def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, grads, x_in, stem_saves=None, x_img=None):
+def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, grads, x_in, stem_saves=None, x_img=None,
+                    stem_ab=None):
     """GatedFFN backward.  dz: gradient of fn_2's output (sigmoid' already applied) [N,64]; t = relu(fn_1(x_in))
-    [N,128].  Returns the gradient of the block input x_in [N,64]."""
+    [N,128] (None for the first block, where it is rebuilt from stem_saves = v [N] and stem_ab = A|B [256]).  Returns
+    the gradient of the block input x_in [N,64]."""
     L = lib()
     N = g.N
     q = pre + name + "."
     dt = ws.act(N, 128)
     dgate = ws.act(N, 64)
     gw, gb = ws.grad(q + "fn_2.weight", 64, 64, 1, 1), ws.grad(q + "fn_2.bias", 64)
+    if stem_saves is not None and t is None:
+        return _stem_gated_backward(ws, dz, dt, dgate, gw, gb, q, p, pre, g, gate_saved, grads, stem_saves, stem_ab, x_img)
     if ws.fused_wgrad():
         # bf16 storage: the kernel that turns dz into dt / dgate holds both operands of fn_2's weight gradient
         check(L.ksr_gate_pw_bwd_wg(ptr(dz), ptr(p[q + "fn_2.weight"]), ptr(gate_saved), ptr(t), ptr(dt), ptr(dgate),
@@ -255,6 +259,44 @@ def _gated_backward(ws: _Ws, dz, name: str, p, pre, g: Geometry, t, gate_saved, 
     check(L.ksr_fn1_bwd(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(t), ptr(p[q + "fn_1.0.weight"]), ptr(None),
                         c_int(1), ptr(v), ptr(p[f + "pointwise2.weight"]), ptr(dpre), ptr(ws.sums_slab()), ptr(rc), ptr(r2),
                         c_int(64), *_dims(g), stream()), "ksr_fn1_bwd")
+    return _stem_parameter_gradients(ws, q, p, pre, g, grads, v, dpre, rc, r2, x_img)
+
+
+def _stem_gated_backward(ws: _Ws, dz, dt, dgate, gw, gb, q, p, pre, g: Geometry, gate_saved, grads, v, ab, x_img):
+    """Backward of the first gated block (ffn2) and of ffn1 behind it.  The block's 128-channel tensor t is rebuilt
+    inside the kernels from the per-pixel scalar v and the coefficients ab (t = relu(A v + B)); the block input is
+    x1[n, k] = pw2_w[k] * v[n] + pw2_b[k]."""
+    L = lib()
+    N = g.N
+    fused = ws.fused_wgrad()
+    check(L.ksr_gate_pw_bwd_v(ptr(dz), ptr(p[q + "fn_2.weight"]), ptr(gate_saved), ptr(v), ptr(ab), ptr(dt), ptr(dgate),
+                              ptr(ws.fused_slab() if fused else None), ptr(gw if fused else None), ptr(gb if fused else None),
+                              *_dims(g), stream()), "ksr_gate_pw_bwd_v")
+    assert fused, "the modes without bf16 storage keep t materialised (engine.encoder_forward) and take _gated_backward"
+    grads[q + "fn_2.weight"], grads[q + "fn_2.bias"] = gw, gb
+    dWg, dbg = ws.grad(q + "gate.weight", 64, 1, 3, 3), ws.grad(q + "gate.bias", 64)
+    slab = ws.slab(512 * 640)
+    with ws.side(v, ab, dgate, slab, dWg, dbg):
+        check(L.ksr_dwconv_wgrad_v(ptr(v), ptr(ab), ptr(dgate), c_int(64), c_int(0), ptr(slab), ptr(dWg), ptr(dbg), *_dims(g),
+                                   stream()), "ksr_dwconv_wgrad_v")
+    grads[q + "gate.weight"], grads[q + "gate.bias"] = dWg, dbg
+    f = pre + "ffn1."
+    dpre = ws.new(N)
+    # the kernel reduces the column sums of dt and dx (times v) that the stem's parameter gradients need; dx and the
+    # gate half of dt, which nothing else reads, are not written
+    rc = ws.new(2, 128)
+    r2 = ws.grad_pair(f + "pointwise2.weight", f + "pointwise2.bias", 64)
+    check(L.ksr_fn1_bwd_stem_v(ptr(dt), ptr(dgate), ptr(p[q + "gate.weight"]), ptr(v), ptr(ab), ptr(p[q + "fn_1.0.weight"]),
+                               ptr(p[f + "pointwise2.weight"]), ptr(dpre), ptr(ws.sums_slab()), ptr(rc), ptr(r2), c_int(64),
+                               *_dims(g), stream()), "ksr_fn1_bwd_stem_v")
+    return _stem_parameter_gradients(ws, q, p, pre, g, grads, v, dpre, rc, r2, x_img)
+
+
+def _stem_parameter_gradients(ws: _Ws, q, p, pre, g: Geometry, grads, v, dpre, rc, r2, x_img):
+    """Parameter gradients of ffn2.fn_1 and ffn1 from the column sums rc / r2 and dpre that the fn_1 backward kernel
+    produced (the input of fn_1 is u * v + w with one scalar v per pixel)."""
+    L = lib()
+    f = pre + "ffn1."
     gw, gb = ws.grad(q + "fn_1.0.weight", 128, 64, 1, 1), ws.grad(q + "fn_1.0.bias", 128)
     with ws.side(rc, gw, gb):
         check(L.ksr_outer2(ptr(gw), c_void_p(rc.data_ptr()), ptr(p[f + "pointwise2.weight"]),
@@ -347,7 +389,7 @@ def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, t
     _wgrad(ws, dt3, 64, 0, 64, sv["x3"], 64, 0, 64, N, gw, gb)
     grads[q + "pointwise1.weight"], grads[q + "pointwise1.bias"] = gw, gb
     # ---- ffn2 (gated) + ffn1 ----
-    _gated_backward(ws, dz2, "ffn2", p, pre, g, sv["t2"], sv["g2"], grads, None, stem_saves=sv["v"], x_img=x)
+    _gated_backward(ws, dz2, "ffn2", p, pre, g, sv["t2"], sv["g2"], grads, None, stem_saves=sv["v"], x_img=x, stem_ab=sv["ab"])
 
 
 class _ConvSepKanFn(torch.autograd.Function):

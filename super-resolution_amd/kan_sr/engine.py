@@ -94,9 +94,11 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
     new = lambda *shape: torch.empty(*shape, device=dev, dtype=adt)                  # activations [N, C]
     new32 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)      # per-pixel scalars
     keep = saves is not None
-    # ffn1 + ffn2 + ffn3.pointwise1 in one kernel that reads only the Y plane (relu(fn_1(ffn1(Y))) is affine in one scalar
-    # per pixel): the [N,128] tensor t2 is written only when the backward needs it
-    t2 = new(N, 128) if keep else None
+    # ffn1 + ffn2 + ffn3.pointwise1 in one kernel that reads only the Y plane: t2 = relu(fn_1(ffn1(Y))) is relu(A v + B) per
+    # channel with one scalar v per pixel.  The [N,128] tensor itself is never needed: the backward rebuilds it from v and
+    # the coefficients ab, as the forward does (saves["_keep_t2"] = True materialises it for inspection).
+    t2 = new(N, 128) if (keep and (adt == torch.float32 or saves.get("_keep_t2"))) else None     # bf16 storage: rebuilt from v
+    ab = new32(256) if keep else None
     v = new32(N) if keep else None
     g2 = new(N, 64) if keep else None
     x3 = new(N, 64) if keep else None
@@ -106,7 +108,7 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
                "ffn2.gate.weight", "ffn2.gate.bias", "ffn2.fn_2.weight", "ffn2.fn_2.bias",
                "ffn3.pointwise1.weight", "ffn3.pointwise1.bias")
     check(L.ksr_stem_gate_fwd(ptr(x), c_int64(3 * g.H * g.W), _ptr_array([p[pre + n] for n in names14]), ptr(t3),
-                              ptr(v), ptr(t2), ptr(g2), ptr(x3), *_dims(g), stream()), "ksr_stem_gate_fwd")
+                              ptr(v), ptr(t2), ptr(g2), ptr(x3), ptr(ab), *_dims(g), stream()), "ksr_stem_gate_fwd")
     x4 = new(N, 64)
     a4 = new(N, 64) if keep else None
     check(L.ksr_dwrelu_pw_fwd(ptr(t3), ptr(p[pre + "ffn3.depthwise.weight"]), ptr(p[pre + "ffn3.depthwise.bias"]),
@@ -124,7 +126,7 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
                             ptr(p[pre + "ffn4.fn_2.weight"]), ptr(p[pre + "ffn4.fn_2.bias"]), ptr(x6), ptr(g6), ptr(x6_f32),
                             *_dims(g), stream()), "ksr_gate_pw_fwd")
     if keep:
-        saves.update(v=v, t2=t2, g2=g2, x3=x3, t3=t3, a4=a4, x4=x4, t5=t5, g6=g6, x6=x6)
+        saves.update(v=v, ab=ab, t2=t2, g2=g2, x3=x3, t3=t3, a4=a4, x4=x4, t5=t5, g6=g6, x6=x6)
     s = x6
     for li in range(2):
         q = f"{pre}encoder.layers.{li}."

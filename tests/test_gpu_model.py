@@ -552,3 +552,54 @@ def test_fused_in_proj_backward_equals_separate_kernels(N, sig):
         assert torch.equal(dW1, dW2) and torch.equal(db1, db2) and torch.equal(ds1.view(torch.int16), ds2.view(torch.int16))
     finally:
         engine.set_precision("fp32")
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 9, 11), (1, 37, 70), (3, 8, 64)])
+def test_backward_kernels_that_rebuild_t_from_v_equal_the_tensor_reading_ones(B, H, W):
+    """The `_v` backward entry points of the first gated block rebuild t = relu(A v + B) [N,128] from the per-pixel scalar v
+    instead of reading the tensor.  In the exact fp32 mode, with t materialised from the same (v, A, B), they must agree
+    with ksr_gate_pw_bwd / ksr_dwconv_wgrad / ksr_fn1_bwd (stem form) to fp32 round-off."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(B * 10 + H)
+    L = lib()
+    N = B * H * W
+    dims = (c_int(B), c_int(H), c_int(W))
+    dev = "cuda"
+    v = torch.rand(N, device=dev) * (torch.rand(N, device=dev) > 0.2)
+    ab = torch.randn(256, device=dev) * 0.5
+    t = torch.relu(torch.addcmul(ab[None, 128:], v[:, None], ab[None, :128])).contiguous()      # fma-free reference: A v + B
+    t = torch.relu(v[:, None] * ab[None, :128] + ab[None, 128:]).contiguous()
+    dz, gate = torch.randn(N, 64, device=dev), torch.randn(N, 64, device=dev)
+    w2, gw, w1, p2w = (torch.randn(*s, device=dev) * 0.1 for s in ((64, 64), (64, 9), (128, 64), (64,)))
+    engine.set_precision("fp32")
+    # gate_pw backward
+    dt0, dg0 = torch.zeros(N, 128, device=dev), torch.empty(N, 64, device=dev)
+    dt1, dg1 = torch.zeros(N, 128, device=dev), torch.empty(N, 64, device=dev)
+    check(L.ksr_gate_pw_bwd(ptr(dz), ptr(w2), ptr(gate), ptr(t), ptr(dt0), ptr(dg0), *dims, stream()), "gate_pw_bwd")
+    check(L.ksr_gate_pw_bwd_v(ptr(dz), ptr(w2), ptr(gate), ptr(v), ptr(ab), ptr(dt1), ptr(dg1), None, None, None, *dims, stream()),
+          "gate_pw_bwd_v")
+    assert rel_l2(dt1[:, :64].cpu(), dt0[:, :64].cpu()) <= 1e-6 and rel_l2(dg1.cpu(), dg0.cpu()) <= 1e-6
+    # depthwise weight gradient of the gate conv
+    slab = torch.empty(512 * 640, device=dev)
+    dW0, db0, dW1, db1 = (torch.empty(s, device=dev) for s in ((64, 9), (64,), (64, 9), (64,)))
+    check(L.ksr_dwconv_wgrad(ptr(t), c_int(128), c_int(64), ptr(dg0), c_int(64), c_int(0), ptr(slab), ptr(dW0), ptr(db0), *dims,
+                             stream()), "dwconv_wgrad")
+    check(L.ksr_dwconv_wgrad_v(ptr(v), ptr(ab), ptr(dg0), c_int(64), c_int(0), ptr(slab), ptr(dW1), ptr(db1), *dims, stream()),
+          "dwconv_wgrad_v")
+    assert rel_l2(dW1.cpu(), dW0.cpu()) <= 1e-5 and rel_l2(db1.cpu(), db0.cpu()) <= 1e-6
+    # fn_1 backward, stem form with column sums
+    sums = torch.empty(3 * 512 * 128, device=dev)
+    outs = []
+    for use_v in (False, True):
+        dt = dt0.clone()
+        dpre, rc, r2 = torch.empty(N, device=dev), torch.empty(2, 128, device=dev), torch.empty(2, 64, device=dev)
+        if use_v:
+            check(L.ksr_fn1_bwd_stem_v(ptr(dt), ptr(dg0), ptr(gw), ptr(v), ptr(ab), ptr(w1), ptr(p2w), ptr(dpre), ptr(sums), ptr(rc),
+                                       ptr(r2), c_int(64), *dims, stream()), "fn1_bwd_stem_v")
+        else:
+            check(L.ksr_fn1_bwd(ptr(dt), ptr(dg0), ptr(gw), ptr(t), ptr(w1), None, c_int(1), ptr(v), ptr(p2w), ptr(dpre), ptr(sums),
+                                ptr(rc), ptr(r2), c_int(64), *dims, stream()), "fn1_bwd")
+        outs.append((dpre.cpu(), rc.cpu(), r2.cpu()))
+    for a, b in zip(outs[0], outs[1]):
+        assert rel_l2(b, a) <= 1e-5
