@@ -43,17 +43,17 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
     f32 = pk                       # the attention products follow the operand mode as well
     k = act_bytes / 4.0            # byte counts below are written for fp32 activations
     # bf16 storage: the fn_2 (ffn2, ffn4) and ffn3.pointwise2 weight gradients are accumulated inside their data-gradient
-    # kernels (ksr_gate_pw_bwd_wg, ksr_pw2_bwd_wg) and leave ksr_wgrad
+    # kernels (ksr_gate_pw_bwd_wg / _v, ksr_pw2_bwd_wg), the in-projection's in ksr_in_proj_bwd_wg: they leave ksr_wgrad
     fused = act_bytes == 2
-    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64 + 64 * 64 + 192 * 64) + 128 * 64 + 64 * 64 + (0 if fused else 3 * 64 * 64)
-    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64) + (64 + 64) + (192 + 64)) + (128 + 64) + (64 + 64)
-                    + (0 if fused else 2 * 64 * 3 + (64 + 64)))
+    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64 + 64 * 64) + 128 * 64 + 64 * 64 + (0 if fused else 3 * 64 * 64 + 2 * 192 * 64)
+    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64) + (64 + 64)) + (128 + 64) + (64 + 64)
+                    + (0 if fused else 2 * 64 * 3 + (64 + 64) + 2 * (192 + 64)))
     lin_post = 2 * (64 * 64 + 64 * 32 + 32 * 64)
     models = {
         # forward
         "ksr_stem_fwd": ("hbm", 2 * 64 * 128 + 150, 4 + 512 + 4, pk),
         # ffn1 + ffn2 + ffn3.pointwise1 from the Y plane: writes t [N,128], gate, x3, t3 [N,64] and v [N]
-        "ksr_stem_gate_fwd": ("hbm", 2 * 2 * 64 * 64 + 2 * 9 * 64 * 3 + 400, 4 + 4 + 512 + 3 * 256, pk),
+        "ksr_stem_gate_fwd": ("hbm", 2 * 2 * 64 * 64 + 2 * 9 * 64 * 3 + 400, 4 + 4 + (0 if fused else 512) + 3 * 256, pk),
         "ksr_gate_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64 + 64, 512 + 256 + 256, pk),            # ffn4's tail
         "ksr_pointwise_fwd": ("hbm", 2 * 64 * 128 + 2 * 2 * 64 * 192, (256 + 512) + 2 * (256 + 768), pk),
         "ksr_dwrelu_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 256 + 256 + 256, pk),
@@ -70,15 +70,22 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         "ksr_batch_attn_bwd": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
         "ksr_batch_tx_layer_bwd_attn": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
         "ksr_in_proj_bwd": ("hbm", 2 * 2 * 192 * 64, 2 * (768 + 256 + 256 + 256), pk),
+        # data gradient + weight gradient of the in-projection in one pass: dqkv, x, resid in, ds out (both layers)
+        "ksr_in_proj_bwd_wg": ("hbm", 2 * 2 * 2 * 192 * 64, 2 * (768 + 256 + 256 + 256), pk),
+        # first gated block with t rebuilt from v: no [N,128] tensor is read
+        "ksr_gate_pw_bwd_v": ("hbm", 2 * 2 * 64 * 64, 256 + 256 + 4 + 256 + 256, pk),
+        "ksr_fn1_bwd_stem_v": ("hbm", 2 * 128 * 64 + 2 * 9 * 64, 256 + 256 + 4 + 4, pk),
+        "ksr_dwconv_wgrad_v": ("hbm", 2 * 10 * 64, 256 + 4, pk),
         "ksr_gate_pw_bwd": ("hbm", 2 * 2 * 64 * 64, 2 * 1280, pk),
-        "ksr_gate_pw_bwd_wg": ("hbm", 2 * 2 * 2 * 64 * 64, 2 * 1280, pk),          # + the fn_2 weight gradient, same bytes
+        "ksr_gate_pw_bwd_wg": ("hbm", 2 * 2 * 64 * 64, 1280, pk),                  # ffn4: + the fn_2 weight gradient, same bytes
         "ksr_pw2_bwd_wg": ("hbm", 2 * 2 * 64 * 64, 768, pk),
-        "ksr_fn1_bwd": ("hbm", 2 * (2 * 128 * 64 + 2 * 9 * 64), 2 * 1280 - 512, pk),   # the stem call writes neither dx nor dt[:, 64:]
+        "ksr_fn1_bwd": (("hbm", 2 * 128 * 64 + 2 * 9 * 64, 1280, pk) if fused else
+                        ("hbm", 2 * (2 * 128 * 64 + 2 * 9 * 64), 2 * 1280 - 512, pk)),   # the stem call writes neither dx nor dt[:, 64:]
         "ksr_pw2_bwd": ("hbm", 2 * 64 * 64, 768, pk),
         "ksr_pw1_bwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 1024, pk),
         "ksr_wgrad": ("hbm", 2 * wg_jk, wg_bytes, pk),
         "ksr_colreduce": ("hbm", 0, 3 * 260, pk),        # ffn1.pointwise2 only (three per-pixel-scalar reductions)
-        "ksr_dwconv_wgrad": ("hbm", 3 * 2 * 10 * 64, 3 * 512, pk),
+        "ksr_dwconv_wgrad": ("hbm", (2 if fused else 3) * 2 * 10 * 64, (2 if fused else 3) * 512, pk),
         # loss (per LR pixel = 16 HR pixels): SSIM reads pred + tgt of 3 channels and writes 3 luma maps; the gradient
         # reads the maps, pred, tgt, and updates gy
         "ksr_ssim_fwd": ("hbm", 0, 16 * (3 * 8 + 12), pk),
@@ -88,7 +95,7 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
     # activation bytes scale with the storage type; the image-side tensors of these entry points stay fp32
     fixed = {"ksr_ssim_fwd": 16 * 36, "ksr_ssim_y_grad": 16 * 28, "ksr_l1_y_loss": 16 * 12, "ksr_stem_fwd": 8, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_feed_kan_bwd": 64 + 4 + 128, "ksr_bilinear_up": 8 + 8 * 16,
              "ksr_gate_pw_fwd": 256 if act_bytes != 4 else 0, "ksr_batch_tx_layer_post_fwd": 128 if act_bytes != 4 else 0,
-             "ksr_stem_gate_fwd": 8}
+             "ksr_stem_gate_fwd": 8, "ksr_gate_pw_bwd_v": 4, "ksr_fn1_bwd_stem_v": 8, "ksr_dwconv_wgrad_v": 4}
     out = {}
     for name, (bound, fl, by, peak) in models.items():
         fx = fixed.get(name, 0)

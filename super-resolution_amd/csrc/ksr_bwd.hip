@@ -135,6 +135,9 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             nvalid = (N - n0w) < 32 ? (int)(N - n0w > 0 ? N - n0w : 0) : 32;
         }
         float* xb = (spatial ? sm.halo : sm.xpose) + wv * KSR_XPOSE_FLOATS;
+        // AFF: this pixel's scalar, requested before the tile's other work so that its latency is covered
+        float aff_vv = 0.f;
+        if constexpr (AFF) aff_vv = live ? a.aff_v[n] : 0.f;
 
         float dz[KH];
         if (BPRO == BPRO_PLAIN) {
@@ -156,7 +159,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             if (BPRO == BPRO_CONVT_G) {
                 float mk[32], t[32];
                 if constexpr (AFF) {
-                    const float vv = live ? a.aff_v[n] : 0.f;
+                    const float vv = aff_vv;
 #pragma unroll
                     for (int i = 0; i < 32; ++i) mk[i] = live ? fmaf(sm.aff[64 + 32 * h + i], vv, sm.aff[192 + 32 * h + i]) : 0.f;   // t is 0 outside the image
                 } else {
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
             if constexpr (PRE_E1) ksr_co_finish<ST>(xb, lane, pf_e1, gte);
             else ksr_load32_co<ST>(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, gte);
             if constexpr (AFF) {
-                const float vv = live ? a.aff_v[n] : 0.f;
+                const float vv = aff_vv;
 #pragma unroll
                 for (int i = 0; i < 32; ++i) val[i] = live ? fmaxf(fmaf(sm.aff[32 * h + i], vv, sm.aff[128 + 32 * h + i]), 0.f) : 0.f;
             } else if constexpr (PRE_E2) ksr_co_finish<ST>(xb, lane, pf_e2, val);
