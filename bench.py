@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train", "train-unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="train: skip the inference and other-precision measurements (profiler passes: every launch in the "
+                         "trace then belongs to the headline step)")
     ap.add_argument("--scaling", default=os.environ.get("KSR_BENCH_SCALING", "weak"), choices=["weak", "strong"],
                     help="train: weak = 64 patches per GPU (default); strong = a global batch of 64 patches split over the GPUs")
     ap.add_argument("--per-gpu-batch", type=int, default=0, help="train: override the per-GPU batch (tools / sweeps)")
@@ -384,7 +387,7 @@ def main():
         roofline["launches_per_step"] = len(prof[dom]) // nlaunch
         roofline["ms_per_step_by_entry_point"] = {k: round(v, 4) for k, v in sorted(totals.items())}
         roofline["frac_by_entry_point"] = {k: [price(k)["bound"], price(k)["frac"]] for k in sorted(totals) if k in models}
-        if world == 1 and args.workload == "train" and not unet:
+        if world == 1 and args.workload == "train" and not unet and not args.headline_only:
             # second half of the headline metric: 1-GPU x4 inference of one 960x540 -> 3840x2160 frame
             model.eval()
             model.precision = "fp32"

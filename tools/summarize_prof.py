@@ -4,7 +4,8 @@ profiles/: kernel stats, the bench line printed under the profiler, HBM bytes pe
 FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE is in KB and counts half of the bytes of wide reads on gfx950, so
 read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE in KB is exact).
 
-Usage: python tools/summarize_prof.py [src_dir] [tag]      (defaults: gpurun_out/prof_r02/train, r02_train_b64_bf16s)"""
+Usage: python tools/summarize_prof.py [src_dir] [tag] [steps_in_pmc_pass]
+       (defaults: gpurun_out/prof_r02/train, r02_train_b64_bf16s, 6; the last one only scales the printed per-step total)"""
 import collections
 import csv
 import json
@@ -16,6 +17,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r02", "train")
 TAG = sys.argv[2] if len(sys.argv) > 2 else "r02_train_b64_bf16s"
+STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 OUT = os.path.join(ROOT, "profiles")
 
 
@@ -67,4 +69,5 @@ if wg:
 with open(os.path.join(OUT, "pmc_hbm_bytes_per_launch.json" if TAG == "r02_train_b64_bf16s" else f"{TAG}_pmc_hbm_bytes_per_launch.json"), "w") as fh:
     json.dump(per_kernel, fh, indent=1)
 total = sum(r[6] * r[1] for r in rows)
-print(f"wrote {len(rows)} kernels to profiles/{TAG}_*; HBM bytes over the PMC pass: {total / 1e9:.2f} GB")
+print(f"wrote {len(rows)} kernels to profiles/{TAG}_*; HBM bytes over the PMC pass: {total / 1e9:.2f} GB "
+      f"= {total / 1e9 / STEPS:.3f} GB per step over {STEPS} steps")
