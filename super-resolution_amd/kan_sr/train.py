@@ -133,13 +133,11 @@ class TrainStep:
         layer = model.layers[li].encoder.encoder
         named = dict(layer.named_parameters())
         dev = next(model.parameters()).device
-        # The GazeTR encoder has a hand-scheduled backward that writes into the flat gradient buffer in completion
-        # order.  Any other backbone (UNet) runs its backward through the autograd tape; its parameters are laid out in
-        # module order and their .grad tensors are views of the flat buffer, exchanged in one bucket.
-        self.tape_backward = getattr(model, "backbone", "gazetr") != "gazetr"
-        if not self.tape_backward and getattr(model, "attention", False):
-            raise KsrError("TrainStep covers the plain `feed` head; a model with attention=True trains through "
-                           "autograd (loss.backward() + a torch optimizer)")
+        # The GazeTR encoder with the plain `feed` head has a hand-scheduled backward that writes into the flat gradient
+        # buffer in completion order.  Any other model (UNet backbone, channel-attention head) runs its backward through
+        # the autograd tape (every node a HIP kernel sequence); its parameters are laid out in module order and their
+        # .grad tensors are views of the flat buffer, exchanged in one bucket.
+        self.tape_backward = getattr(model, "backbone", "gazetr") != "gazetr" or bool(getattr(model, "attention", False))
         for n, prm in named.items():
             if prm.dtype is not torch.float32:
                 raise KsrError(f"TrainStep needs float32 parameters, {n} is {prm.dtype}")

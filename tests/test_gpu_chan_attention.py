@@ -169,3 +169,54 @@ def test_model_with_attention_head(r, G, B, H, W):
             continue
         ref = p_ref[n].grad
         assert rel_l2(prm.grad.cpu(), ref) <= 2e-4 or float((prm.grad.cpu() - ref).norm()) <= 1e-7, (n, rel_l2(prm.grad.cpu(), ref))
+
+
+@pytest.mark.parametrize("loss,precision", [("l1", "fp32"), ("l1+ssim", "fp32"), ("l1+ssim", "bf16")])
+def test_attention_head_train_step_vs_oracle_adam(loss, precision):
+    """TrainStep on ConvSepKan(..., attention=True) (BASELINE configs[3]: G = 16, channel-attention head; tape backward
+    into the flat buffer, one exchange bucket, fused Adam): loss value, gradients of the first step and the parameters
+    after three steps against oracle + autograd + torch.optim.Adam on the CPU.  Dropout is off (eval mode), as in the
+    other oracle comparisons of the step.  bf16 MFMA operands: loss within 2e-2, parameters after three steps within
+    the swing of three Adam steps."""
+    from kan_sr.module import ConvSepKan
+    from kan_sr.train import TrainStep
+    from kan_sr import engine
+    torch.manual_seed(77)
+    r, G = 4, 16
+    m = ConvSepKan([1], [r * r], [3], G, 3, 0.1, [-1, 1], r, attention=True).eval()
+    with torch.no_grad():
+        for n, prm in m.named_parameters():
+            if "norm" in n:
+                prm.add_(0.1 * torch.randn_like(prm))
+    m.precision = precision
+    p0 = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    pr = {n: v.clone().requires_grad_() for n, v in p0.items()}
+    opt = torch.optim.Adam(list(pr.values()), lr=1e-3)
+    ts = TrainStep(m.cuda(), lr=1e-3, loss=loss)
+    assert ts.tape_backward and ts.flat_p.numel() == sum(q.numel() for q in m.parameters())
+    exact = precision == "fp32"
+    for it in range(3):
+        x, tgt = torch.rand(3, 3, 12, 16), torch.rand(3, 3, 12 * r, 16 * r)
+        opt.zero_grad()
+        y = orc.conv_sep_kan_forward(x, pr, out_channels=[r * r], grid_size=G, spline_order=3, grid_range=[-1, 1],
+                                     upscale=r, attention=True)
+        loss_ref = orc.training_loss(y, tgt) if loss == "l1+ssim" else (y[:, :1] - tgt[:, :1]).abs().mean()
+        loss_ref.backward()
+        got = ts.step(x.cuda(), tgt.cuda())
+        lr_ = float(loss_ref.detach())
+        assert abs(float(got) - lr_) <= ((1e-5 + 1e-4 * abs(lr_)) if exact else 2e-2 * abs(lr_))
+        if it == 0 and exact:
+            for n, v in pr.items():
+                if ".a_dw." in n:
+                    assert float(ts.arena[n].abs().max()) == 0.0
+                    continue
+                have = ts.arena[n].cpu()
+                assert rel_l2(have, v.grad) <= 2e-4 or float((have - v.grad).norm()) <= 1e-7, (n, rel_l2(have, v.grad))
+        opt.step()
+    for n, prm in m.named_parameters():
+        want, have = pr[n].detach() - p0[n], prm.detach().cpu() - p0[n]
+        assert float((have - want).abs().max()) <= (2.1e-3 if exact else 6.1e-3), n
+        if exact:
+            assert rel_l2(prm.detach().cpu(), pr[n].detach()) <= 5e-3, n
+    engine.set_precision("fp32")
+    ts.close()
