@@ -40,5 +40,9 @@ struct SlotMap {
 // bf16-operand variants (ksr_attn_bf16.hip); nw = key blocks per query (1..4)
 int ksr_attn_bf16_fwd_launch(const AttnArgs& a, int nw, unsigned grid, hipStream_t stream);
 int ksr_attn_bf16_bwd_launch(const AttnBwdArgs& a, int nw, unsigned grid, hipStream_t stream);
+// bf16-storage variants that stage their operand rows with the LDS-DMA (ksr_attn_dma.hip)
+bool ksr_attn_dma_supported(int Sp);
+int ksr_attn_dma_fwd_launch(const AttnArgs& a, hipStream_t stream);
+int ksr_attn_dma_bwd_launch(const AttnBwdArgs& a, hipStream_t stream);
 
 #endif

@@ -465,6 +465,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
 int ksr_attn_bf16_fwd_launch(const AttnArgs& a, int nw, unsigned grid, hipStream_t stream) {
     const dim3 g(grid), block(256);
     const bool bs = ksr_prec() == KSR_BF16S;
+    if (bs && ksr_attn_dma_supported(a.Sp)) return ksr_attn_dma_fwd_launch(a, stream);
 #define KSR_ATTN_FWD(NWV)                                                                               \
     do {                                                                                                \
         if (bs) hipLaunchKernelGGL((attn_fwd_bf16_kernel<NWV, __bf16>), g, block, 0, stream, a);        \
@@ -484,6 +485,7 @@ int ksr_attn_bf16_bwd_launch(const AttnBwdArgs& a, int nw, unsigned grid, hipStr
     const dim3 g(grid), block(256);
     const bool drop = a.p_drop > 0.f;
     const bool bs = ksr_prec() == KSR_BF16S;
+    if (bs && ksr_attn_dma_supported(a.Sp)) return ksr_attn_dma_bwd_launch(a, stream);
 #define KSR_ATTN_BWD(NWV)                                                                                          \
     do {                                                                                                           \
         if (bs) {                                                                                                  \

@@ -159,9 +159,14 @@ __device__ __forceinline__ unsigned ksr_xcd_contiguous(unsigned wg, unsigned tot
     return xcd < rem ? xcd * (per + 1) + slot : rem * (per + 1) + (xcd - rem) * per + slot;
 }
 
-// One hash serves two neighbouring keys (16 bits each): the keep probability is quantised to 1/65536.
+// One hash serves two neighbouring keys (16 bits each): the keep probability is quantised to 1/65536.  `base` is
+// already a full hash of (seed, token, head); the key index enters as a Weyl step followed by ONE xorshift-multiply
+// round (the 32-bit multiply runs at quarter rate, and the attention kernels are bound by instruction issue).  Measured
+// on 10^6 bases x 64 keys: mean keep 0.89999, variance of the per-query count 5.75-5.76 (binomial 5.76), largest
+// pairwise correlation between keys 0.005 (sampling noise 0.004).
 __device__ __forceinline__ bool ksr_attn_keep(unsigned base, int key_b, float keep) {
-    const unsigned x = ksr_hash32(base + (unsigned)(key_b >> 1) * 0x9E3779B1u);
+    unsigned x = base + (unsigned)(key_b >> 1) * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0xD168AAADu; x ^= x >> 15;
     const unsigned half = (key_b & 1) ? (x >> 16) : (x & 0xffffu);
     return half < (unsigned)(keep * 65536.0f);
 }
