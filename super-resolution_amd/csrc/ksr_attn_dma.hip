@@ -22,6 +22,7 @@ namespace {
 
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TS = 64;                  // slots per pass
 constexpr int TEN = TS * 64;            // elements of one staged tensor (64 rows x 64 channels, 8 KB)
@@ -147,7 +148,7 @@ __device__ __forceinline__ void xp_to_rows(const __bf16* __restrict__ xp, __bf16
 
 // ------------------------------------------------------------------------------------------ forward
 // FULL: every slot of every pass is a token (S == Sp >= 32, HW a multiple of the pixels per pass): no masks
-template <int NW, bool FULL>
+template <int NW, bool DROP, bool FULL>
 __global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(AttnArgs a) {
     KSR_MIX_SEED(a);
     __shared__ __attribute__((aligned(16))) __bf16 stA[3 * TEN];
@@ -166,8 +167,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(AttnArgs a) {
     const int pl = slot >> lg, b = slot & (Sp - 1);
     const int kbase0 = (Sp >= 32) ? pl * Sp : sb * 32;
     const SlotMap smap{Sp, lg, Sp >= 32};
-    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
-    const bool drop = a.p_drop > 0.f;
+    constexpr bool drop = DROP;
+    const float keep = 1.f - a.p_drop, inv_keep = drop ? 1.f / keep : 1.f;
+    const unsigned thr = ksr_attn_keep_threshold(keep);
     const float cexp = SCALE * LOG2E;
     __bf16* xp = xps + wv * 32 * XP_LD;
     const __bf16* qkv = reinterpret_cast<const __bf16*>(a.qkv);
@@ -211,17 +213,21 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(AttnArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NW; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float pj = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], cexp, -m2));
-                l += pj;
+            for (int r = 0; r < 16; r += 2) {
+                // registers r, r + 1 are neighbouring keys (even, odd image index): one hash decides both
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], cexp, -m2));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(sc[kb][r + 1], cexp, -m2));
+                l += e0 + e1;
+                sc[kb][r] = e0; sc[kb][r + 1] = e1;
                 if (drop) {
                     int same, kbb;
                     smap.decode(kbase0, kb, key_of_reg(r, g), pl, same, kbb);
-                    pj = ksr_attn_keep(dbase, kbb, keep) ? pj * inv_keep : 0.f;
+                    const unsigned x = ksr_attn_keep_word(dbase, kbb);
+                    sc[kb][r] = (x & 0xffffu) < thr ? e0 : 0.f;
+                    sc[kb][r + 1] = (x >> 16) < thr ? e1 : 0.f;
                 }
-                sc[kb][r] = pj;
             }
-        const float inv_l = 1.f / ksr_pair_sum(l);
+        const float inv_l = inv_keep / ksr_pair_sum(l);         // 1 / keep of the kept probabilities folded in
         // ---- ctx^T = V^T P^T ----
         f32x16 acc = zero16();
 #pragma unroll
@@ -246,7 +252,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
     KSR_MIX_SEED(a);
     __shared__ __attribute__((aligned(16))) __bf16 stA[4 * TEN];
     __shared__ __attribute__((aligned(16))) __bf16 stB[4 * TEN];
-    __shared__ __attribute__((aligned(16))) float stat[2 * TS * 4];   // per head and query slot: m' + log2(l), D, -, dropout base
+    __shared__ __attribute__((aligned(16))) float stat[2 * TS * 4];   // per head and query slot: m' + log2(l keep), Dk, keep bits of the lane halves
     __shared__ __attribute__((aligned(16))) __bf16 xps[4 * 32 * XP_LD];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -261,7 +267,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
     const int pl = slot >> lg, b = slot & (Sp - 1);
     const int base0 = (Sp >= 32) ? pl * Sp : sb * 32;
     const SlotMap smap{Sp, lg, Sp >= 32};
-    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+    const float keep = 1.f - a.p_drop, inv_keep = DROP ? 1.f / keep : 1.f;
+    const unsigned thr = ksr_attn_keep_threshold(keep);
+    // a query lane (half gq) holds key tok of its block kb in register (tok & 3) + 4 (tok >> 3), gq = (tok >> 2) & 1
+    const bool my_half = (tok >> 2) & 1;
+    const unsigned my_bit = 1u << ((tok & 3) + 4 * (tok >> 3) + (NW == 2 ? 16 * sb : 0));
     const float cexp = SCALE * LOG2E;
     __bf16* xp = xps + wv * 32 * XP_LD;
     float* stx = stat + X * TS * 4;
@@ -303,37 +313,46 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             float l = 0.f, dsum = 0.f;
             const float m2 = m * cexp;
+            unsigned kw = 0u;                  // keep bits of this lane's keys: bit r + 16 kb
 #pragma unroll
             for (int kb = 0; kb < NW; ++kb) {
                 dp[kb] = zero16();
                 rows_times_x(V, X, base0 + 32 * kb, tok, g, dox, dp[kb]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(st[kb][r], cexp, -m2));
-                    st[kb][r] = e;
-                    l += e;
-                    float dpr = dp[kb][r];
+                for (int r = 0; r < 16; r += 2) {
+                    // registers r, r + 1 are neighbouring keys (even, odd image index): one hash decides both
+                    const float e0 = __builtin_amdgcn_exp2f(fmaf(st[kb][r], cexp, -m2));
+                    const float e1 = __builtin_amdgcn_exp2f(fmaf(st[kb][r + 1], cexp, -m2));
+                    st[kb][r] = e0; st[kb][r + 1] = e1;
+                    l += e0 + e1;
                     if (DROP) {
                         int same, kbb;
                         smap.decode(base0, kb, key_of_reg(r, g), pl, same, kbb);
-                        dpr = ksr_attn_keep(dbase, kbb, keep) ? dpr * inv_keep : 0.f;
+                        const unsigned x = ksr_attn_keep_word(dbase, kbb);
+                        const bool k0 = (x & 0xffffu) < thr, k1 = (x >> 16) < thr;
+                        dp[kb][r] = k0 ? dp[kb][r] : 0.f;
+                        dp[kb][r + 1] = k1 ? dp[kb][r + 1] : 0.f;
+                        kw |= (k0 ? 1u << (r + 16 * kb) : 0u) | (k1 ? 2u << (r + 16 * kb) : 0u);
                     }
-                    dp[kb][r] = dpr;
-                    dsum = fmaf(e, dpr, dsum);
+                    dsum = fmaf(e0, dp[kb][r], dsum);
+                    dsum = fmaf(e1, dp[kb][r + 1], dsum);
                 }
             }
+            // With dP' = dP on the kept keys, 0 elsewhere (no 1/keep): D = rowsum(dO * O) = Dk / keep with
+            // Dk = sum_j P_ij dP'_ij, and dS_ij = P_ij (dP'_ij / keep - D) = (P_ij / keep) (dP'_ij - Dk).
             const float inv_l = 1.f / ksr_pair_sum(l);
-            const float D = ksr_pair_sum(dsum) * inv_l;         // = rowsum(dO * O)
-            const float ils = inv_l * SCALE;
+            const float Dk = ksr_pair_sum(dsum) * inv_l;
+            const float c2 = inv_l * SCALE * inv_keep, dc2 = -Dk * c2;
             f32x16 dq = zero16();
 #pragma unroll
             for (int kb = 0; kb < NW; ++kb) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[kb][r] = st[kb][r] * ils * (dp[kb][r] - D);      // dS (scaled for dq)
+                for (int r = 0; r < 16; ++r) dp[kb][r] = st[kb][r] * fmaf(dp[kb][r], c2, dc2);      // dS (scaled for dq)
                 tr_times_acc(K, X, base0 + 32 * kb, lane, dp[kb], dq);
             }
-            // p = exp(scale (s - m)) / l = exp2(s c - (m c + log2 l))
-            if (g == 0) *reinterpret_cast<f32x4*>(&stx[slot * 4]) = f32x4{m2 - __builtin_amdgcn_logf(inv_l), D, 0.f, __uint_as_float(dbase)};
+            // the key side recomputes P_ij / keep = exp2(s c - (m c + log2 l + log2 keep)) and reads Dk and its keep bit
+            if (g == 0) *reinterpret_cast<f32x2*>(&stx[slot * 4]) = f32x2{m2 - __builtin_amdgcn_logf(inv_l * inv_keep), Dk};
+            if (DROP) stx[slot * 4 + 2 + g] = __uint_as_float(kw);
             tile_to_xp(xp, lane, dq, 1.f);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -357,12 +376,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
                     smap.decode(base0, qblk, key_of_reg(r, g), pl, same, qbb);
                     const bool ok = FULL || (same && (qbb < S) && (p < HW));
                     const f32x4 stt = *reinterpret_cast<const f32x4*>(&stx[qs * 4]);
-                    const float pij = ok ? __builtin_amdgcn_exp2f(fmaf(sq[r], cexp, -stt[0])) : 0.f;
+                    const float pij = ok ? __builtin_amdgcn_exp2f(fmaf(sq[r], cexp, -stt[0])) : 0.f;      // P_ij / keep
                     float pt = pij, dpr = dp[r];
                     if (DROP) {
-                        const bool kept = ksr_attn_keep(__float_as_uint(stt[3]), b, keep);
-                        pt = kept ? pij * inv_keep : 0.f;
-                        dpr = kept ? dpr * inv_keep : 0.f;
+                        // bit of (query qs, this key) in the word of the query lane half that holds this key
+                        const bool kept = (__float_as_uint(my_half ? stt[3] : stt[2]) & my_bit) != 0u;
+                        pt = kept ? pij : 0.f;
+                        dpr = kept ? dpr : 0.f;
                     }
                     sq[r] = pij * (dpr - stt[1]);    // dS
                     dp[r] = pt;                       // probabilities after dropout
@@ -395,13 +415,18 @@ int ksr_attn_dma_fwd_launch(const AttnArgs& a, hipStream_t stream) {
     const int ppt = TS / a.Sp, npass = (a.HW + ppt - 1) / ppt;
     const dim3 g((unsigned)(npass < 512 ? npass : 512)), block(256);
     const bool full = a.S == a.Sp && a.Sp >= 32 && a.HW % ppt == 0;
+    const bool drop = a.p_drop > 0.f;
+#define KSR_ATTN_FWD(NWV, DR)                                                                                \
+    do {                                                                                                     \
+        if (full) hipLaunchKernelGGL((attn_fwd_dma_kernel<NWV, DR, true>), g, block, 0, stream, a);          \
+        else hipLaunchKernelGGL((attn_fwd_dma_kernel<NWV, DR, false>), g, block, 0, stream, a);              \
+    } while (0)
     if (a.Sp == 64) {
-        if (full) hipLaunchKernelGGL((attn_fwd_dma_kernel<2, true>), g, block, 0, stream, a);
-        else hipLaunchKernelGGL((attn_fwd_dma_kernel<2, false>), g, block, 0, stream, a);
+        if (drop) KSR_ATTN_FWD(2, true); else KSR_ATTN_FWD(2, false);
     } else {
-        if (full) hipLaunchKernelGGL((attn_fwd_dma_kernel<1, true>), g, block, 0, stream, a);
-        else hipLaunchKernelGGL((attn_fwd_dma_kernel<1, false>), g, block, 0, stream, a);
+        if (drop) KSR_ATTN_FWD(1, true); else KSR_ATTN_FWD(1, false);
     }
+#undef KSR_ATTN_FWD
     KSR_LAUNCH_CHECK("batch_attn_fwd(bf16 storage)");
     return KSR_OK;
 }

@@ -164,11 +164,16 @@ __device__ __forceinline__ unsigned ksr_xcd_contiguous(unsigned wg, unsigned tot
 // round (the 32-bit multiply runs at quarter rate, and the attention kernels are bound by instruction issue).  Measured
 // on 10^6 bases x 64 keys: mean keep 0.89999, variance of the per-query count 5.75-5.76 (binomial 5.76), largest
 // pairwise correlation between keys 0.005 (sampling noise 0.004).
-__device__ __forceinline__ bool ksr_attn_keep(unsigned base, int key_b, float keep) {
+__device__ __forceinline__ unsigned ksr_attn_keep_word(unsigned base, int key_b) {   // low half: key_b & ~1, high half: key_b | 1
     unsigned x = base + (unsigned)(key_b >> 1) * 0x9E3779B1u;
     x ^= x >> 15; x *= 0xD168AAADu; x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ unsigned ksr_attn_keep_threshold(float keep) { return (unsigned)(keep * 65536.0f); }
+__device__ __forceinline__ bool ksr_attn_keep(unsigned base, int key_b, float keep) {
+    const unsigned x = ksr_attn_keep_word(base, key_b);
     const unsigned half = (key_b & 1) ? (x >> 16) : (x & 0xffffu);
-    return half < (unsigned)(keep * 65536.0f);
+    return half < ksr_attn_keep_threshold(keep);
 }
 
 // 1 / (1 + exp(-x)) with the hardware exp2 and reciprocal (1 ulp each) instead of expf and an IEEE division: about 5
