@@ -67,7 +67,8 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         # backward
         "ksr_feed_kan_bwd": ("hbm", 2 * 64 * P + 800, 64 + 4 + 128 + 256 + 4 * P, pk),
         "ksr_batch_tx_layer_bwd_token": ("hbm", 2 * lin_post, 2304 + 2304, pk),     # LayerNorm gain / shift sums are fused in
-        "ksr_batch_attn_bwd": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
+        # bf16 storage: the forward's output is not read (rowsum(dO * O) comes from the recomputed probabilities)
+        "ksr_batch_attn_bwd": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + (0 if fused else 64) + 64 + 192), f32),
         "ksr_batch_tx_layer_bwd_attn": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
         "ksr_in_proj_bwd": ("hbm", 2 * 2 * 192 * 64, 2 * (768 + 256 + 256 + 256), pk),
         # data gradient + weight gradient of the in-projection in one pass: dqkv, x, resid in, ds out (both layers)
@@ -107,12 +108,13 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
 # entry point -> device kernel of the default (bf16s training, S = 64) workload, for looking up the HBM bytes per
 # launch measured with the rocprofv3 PMC passes (profiles/pmc_hbm_bytes_per_launch.json)
 ENTRY_KERNEL = {
-    "ksr_batch_attn_bwd": "_ZN12_GLOBAL__N_120attn_bwd_bf16_kernelILi2ELb1EDF16bEEv11AttnBwdArgs",
-    "ksr_batch_attn_fwd": "_ZN12_GLOBAL__N_120attn_fwd_bf16_kernelILi2EDF16bEEv8AttnArgs",
-    "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<2>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<2, true, true>",
+    "ksr_batch_attn_bwd": "attn_bwd_dma_kernel<2, true, true>", "ksr_batch_attn_fwd": "attn_fwd_dma_kernel<2, true, true>",
+    "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<2>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<2, true, 1>",
+    "ksr_in_proj_bwd_wg": "inproj_bwd_fused_kernel<false>",
     "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<2, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<2, 4, 8, 3>",
-    "ksr_gate_pw_fwd": "conv_fwd_kernel<2, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<2, 64, 0, 3>",
-    "ksr_gate_pw_bwd_wg": "dgrad_kernel<2, 64, 0, 3, true>", "ksr_stem_gate_fwd": "stem_gate_fwd_kernel<2>",
+    "ksr_gate_pw_fwd": "conv_fwd_kernel<2, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<2, 64, 0, 3, false, false>",
+    "ksr_gate_pw_bwd_wg": "dgrad_kernel<2, 64, 0, 3, true, false>", "ksr_gate_pw_bwd_v": "dgrad_kernel<2, 64, 0, 3, true, true>",
+    "ksr_stem_gate_fwd": "stem_gate_fwd_kernel<2>", "ksr_ssim_fwd": "ssim_fwd_kernel",
     "ksr_wgrad": "entry:ksr_wgrad",      # launch-weighted average over the wgrad_kernel instances + the slab reduction
 }
 
