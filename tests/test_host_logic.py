@@ -279,3 +279,22 @@ def test_unet_gather_tables_on_host():
     assert torch.equal(gdst["up3.up.weight"], KG["up3.up"][:, :16].reshape(2, 2, 16, 8).permute(2, 3, 0, 1))
     assert torch.equal(gdst["reproj.conv.weight"].reshape(40, 4), KG["reproj"][:4].t())
     assert torch.equal(gdst[key + ".double_conv.0.weight"], KG[key + ".0"].reshape(3, 3, 8, 16).permute(3, 2, 0, 1))
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/conv_sep_kan/seemore.py"), reason="reference tree not present")
+def test_reference_seemore_cannot_be_constructed():
+    """The reference's SeemoRe class (conv_sep_kan/seemore.py:13-77) raises on construction with its defaults and with
+    every valid `lr_space`: there is no reference behaviour for that backbone to reproduce."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("seemore_ref", "/root/reference/conv_sep_kan/seemore.py")
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode, old = True, sys.dont_write_bytecode
+    try:
+        spec.loader.exec_module(mod)
+    finally:
+        sys.dont_write_bytecode = old
+    with pytest.raises(NotImplementedError, match="lr_space"):
+        mod.SeemoRe()                                              # default lr_space = 1 (seemore.py:24 vs :219-226)
+    for lr_space in ("linear", "exp", "double"):
+        with pytest.raises(TypeError, match="mlp_ratio"):
+            mod.SeemoRe(lr_space=lr_space)                         # RME passes mlp_ratio to GatedFFN (:176 vs :355-358)
