@@ -361,10 +361,15 @@ def test_bf16_mfma_mode_golden(r, G, k, precision):
 
 
 @pytest.mark.parametrize("storage", ["fp32", "bf16"])
-@pytest.mark.parametrize("S,HW,p_drop", [(3, 50, 0.0), (8, 40, 0.1), (32, 9, 0.0), (64, 130, 0.1), (100, 7, 0.1), (128, 5, 0.0)])
+@pytest.mark.parametrize("S,HW,p_drop", [(3, 50, 0.0), (8, 40, 0.1), (32, 9, 0.0), (64, 130, 0.1), (100, 7, 0.1), (128, 5, 0.0),
+                                         (64, 1500, 0.1), (32, 1300, 0.1), (12, 2101, 0.1), (48, 600, 0.1), (64, 1030, 0.0),
+                                         (17, 1027, 0.0)])
 def test_bf16_attention_matches_fp32_attention(S, HW, p_drop, storage):
     """bf16-operand attention kernels against the fp32 ones on the same inputs and dropout masks.  Stated
-    tolerance (bf16 operands, fp32 softmax and accumulation): rel-L2 <= 2e-2 forward and backward."""
+    tolerance (bf16 operands, fp32 softmax and accumulation): rel-L2 <= 2e-2 forward and backward.  The second
+    row of cases gives every persistent workgroup of the bf16-storage kernels several passes (both staging buffers,
+    the deferred stores) at each slot width (16, 32, 64), with and without absent slots (S below its padded width,
+    a pixel count that does not fill the last pass)."""
     from kan_sr import engine
     from kan_sr._lib import lib, ptr, stream, check
     torch.manual_seed(7 * S + HW)
