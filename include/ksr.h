@@ -140,6 +140,12 @@ int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* const* para
  * (and the final norm).  params / saves as for ksr_batch_tx_layer_fwd (params[0..1], saves[0..1] unused). */
 int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, float p_drop, uint64_t seed,
                        ksr_stream_t stream);
+/* ksr_pointwise_fwd(n_out = 192) + ksr_batch_attn_fwd in one launch (MultiheadAttention's in_proj and attention,
+ * gazetr.py:110-115 through torch's multi_head_attention_forward): qkv [N,192] is written when not NULL (the backward
+ * reads it) and never read.  The fused kernel exists for bf16 storage with 9 <= S <= 64; other cases run the two
+ * kernels and need the qkv buffer. */
+int ksr_batch_qkv_attn_fwd(const float* in, const float* in_proj_weight, const float* in_proj_bias, float* qkv,
+                           float* ctx, int S, int HW, float p_drop, uint64_t seed, ksr_stream_t stream);
 int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, float* out, const float* const* params,
                                 float* const* saves, int64_t N, float eps, float p_drop, uint64_t seed,
                                 const float* in_f32_copy, ksr_stream_t stream);

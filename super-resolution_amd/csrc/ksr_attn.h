@@ -44,5 +44,8 @@ int ksr_attn_bf16_bwd_launch(const AttnBwdArgs& a, int nw, unsigned grid, hipStr
 bool ksr_attn_dma_supported(int Sp);
 int ksr_attn_dma_fwd_launch(const AttnArgs& a, hipStream_t stream);
 int ksr_attn_dma_bwd_launch(const AttnBwdArgs& a, hipStream_t stream);
+int ksr_qkv_attn_dma_fwd_launch(const float* x, const float* w, const float* bias, float* qkv, float* ctx, int S, int Sp,
+                                int HW, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                                hipStream_t stream);
 
 #endif

@@ -12,6 +12,9 @@
 // statistics need one exchange between the two lanes of a query.
 #include "ksr_attn.h"
 
+extern "C" int ksr_pointwise_fwd(const float* in, const float* w, const float* bias, float* out, int n_out, int act, int B,
+                                 int H, int W, hipStream_t stream);      // ksr_conv.hip
+
 namespace {
 
 constexpr int KLD = 68;      // K rows: 64 channels + 4 pad
@@ -394,6 +397,22 @@ extern "C" int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, f
     }
     KSR_LAUNCH_CHECK("batch_attn_fwd");
     return KSR_OK;
+}
+
+// in_proj + attention in one launch: qkv [N,192] = x [N,64] * in_w^T + in_b (written when qkv is not null: the
+// backward's saved tensor) and ctx as ksr_batch_attn_fwd.  bf16 storage with 9 <= S <= 64 runs the fused kernel
+// (ksr_attn_dma.hip); every other case is ksr_pointwise_fwd followed by ksr_batch_attn_fwd and needs the qkv buffer.
+extern "C" int ksr_batch_qkv_attn_fwd(const float* x, const float* in_w, const float* in_b, float* qkv, float* ctx, int S,
+                                      int HW, float p_drop, uint64_t seed, hipStream_t stream) {
+    KSR_CHECK_ARG(x && in_w && in_b && ctx && S > 0 && HW > 0, "batch_qkv_attn_fwd: bad argument");
+    KSR_UNSUPPORTED(S > 128, "batch_qkv_attn_fwd: local batch %d > 128 not supported", S);
+    KSR_CHECK_ARG(p_drop >= 0.f && p_drop < 1.f, "batch_qkv_attn_fwd: dropout p must be in [0,1)");
+    const int Sp = padded_S(S);
+    if (ksr_prec() == KSR_BF16S && ksr_attn_dma_supported(Sp))
+        return ksr_qkv_attn_dma_fwd_launch(x, in_w, in_b, qkv, ctx, S, Sp, HW, p_drop, seed, ksr_seed_dev(), stream);
+    KSR_CHECK_ARG(qkv, "batch_qkv_attn_fwd: this precision / batch size needs the qkv buffer");
+    if (int rc = ksr_pointwise_fwd(x, in_w, in_b, qkv, 192, 0, S, 1, HW, stream)) return rc;
+    return ksr_batch_attn_fwd(qkv, ctx, S, HW, p_drop, seed, stream);
 }
 
 // Backward of ksr_batch_attn_fwd / of the attention inside ksr_batch_tx_layer_fwd: dqkv [N,192] from

@@ -246,6 +246,182 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(AttnArgs a) {
     if ((int)blockIdx.x < npass) xp_to_rows<FULL>(xp, ctx, pend, 64, 32 * X, lane);
 }
 
+// ------------------------------------------------------------------------------------------ in-projection + forward
+// The layer's in-projection inside the attention forward: a pass stages the 64 tokens' INPUT rows (8 KB instead of the
+// 24 KB of their q, k, v rows), every wave forms q, k, v of its head for its 32 tokens on the matrix cores (12 products,
+// bias in the accumulator's initial value), rounds them to bf16 into the q / k / v tile that the attention part reads,
+// and the tile is stored to qkv [N,192] (the backward's saved tensor) from LDS.  qkv is written once and never read.
+struct QkvAttnArgs {
+    const __bf16* x;      // [N,64]
+    const float* w;       // [192,64] in_proj_weight
+    const float* bias;    // [192]
+    __bf16* qkv;          // [N,192] or null
+    __bf16* ctx;          // [N,64]
+    int S, Sp, HW;
+    float p_drop;
+    unsigned long long seed;
+    const unsigned long long* seed_dev;
+};
+
+// element offset of chunk c (8 bf16, c < 8) of row r of a staged input tile: rows of 128 bytes, chunk position
+// c ^ ((r >> 1) & 7) (16 consecutive rows reading the same chunk touch 16 different bank quads)
+__device__ __forceinline__ int x_off(int r, int c) { return r * 64 + 8 * (c ^ ((r >> 1) & 7)); }
+
+template <bool FULL>
+__device__ __forceinline__ void issue_x(__bf16* __restrict__ st, const __bf16* __restrict__ x, const PassMap& pm, int pass,
+                                        int wv, int lane) {
+    const int r8 = lane >> 3, cp = lane & 7;
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2) {
+        const int grp = h2 * 4 + wv, r = grp * 8 + r8;
+        long n = pm.row<FULL>(pass, r);
+        if (!FULL && n < 0) n = 0;
+        const int c = cp ^ ((r >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + n * 64 + 8 * c),
+                                         (__attribute__((address_space(3))) void*)(st + grp * 512), 16, 0, 0);
+    }
+}
+
+template <int NW, bool DROP, bool FULL>
+__global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a) {
+    KSR_MIX_SEED(a);
+    __shared__ __attribute__((aligned(16))) __bf16 xsA[TEN];
+    __shared__ __attribute__((aligned(16))) __bf16 xsB[TEN];
+    __shared__ __attribute__((aligned(16))) __bf16 tile[3 * TEN];           // q, k, v of the pass (d_off layout)
+    __shared__ __attribute__((aligned(16))) __bf16 wfrag[6 * 4 * 64 * 8];   // [out block][k step][lane][8]
+    __shared__ __attribute__((aligned(16))) float bfrag[6 * 2 * 16];        // [out block][lane half][register]
+    __shared__ __attribute__((aligned(16))) __bf16 xps[4 * 32 * XP_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tok = lane & 31, g = lane >> 5;
+    const int X = wv & 1, sb = wv >> 1;
+    const int S = a.S, Sp = a.Sp, HW = a.HW;
+    int lg = 0;
+    while ((1 << lg) < Sp) ++lg;
+    const PassMap pm{Sp, lg, S, HW, TS / Sp};
+    const int npass = (HW + pm.PPT - 1) / pm.PPT;
+    const int slot = 32 * sb + tok;
+    const int pl = slot >> lg, b = slot & (Sp - 1);
+    const int kbase0 = (Sp >= 32) ? pl * Sp : sb * 32;
+    const SlotMap smap{Sp, lg, Sp >= 32};
+    const float keep = 1.f - a.p_drop, inv_keep = DROP ? 1.f / keep : 1.f;
+    const unsigned thr = ksr_attn_keep_threshold(keep);
+    const float cexp = SCALE * LOG2E;
+    __bf16* xp = xps + wv * 32 * XP_LD;
+    const int G = gridDim.x;
+
+    // element i of lane (row = ln & 31, half ln >> 5) in step s of out block ob = W[32 ob + row][16 s + 8 half + i]
+    for (int idx = tid; idx < 6 * 4 * 64 * 8; idx += 256) {
+        const int i = idx & 7, ln = (idx >> 3) & 63, s4 = (idx >> 9) & 3, ob = idx >> 11;
+        wfrag[idx] = (__bf16)a.w[(32 * ob + (ln & 31)) * 64 + 16 * s4 + 8 * (ln >> 5) + i];
+    }
+    for (int idx = tid; idx < 6 * 2 * 16; idx += 256)
+        bfrag[idx] = a.bias[32 * (idx >> 5) + key_of_reg(idx & 15, (idx >> 4) & 1)];
+
+    long pend[2] = {-1, -1};
+    auto body = [&](const __bf16* __restrict__ cur, __bf16* __restrict__ nxt, int pass, bool first) {
+        dma_barrier();                     // cur has landed; every wave is done with the previous pass's tile
+        if (pass + G < npass) issue_x<FULL>(nxt, a.x, pm, pass + G, wv, lane);
+        if (!first) xp_to_rows<FULL>(xp, a.ctx, pend, 64, 32 * X, lane);
+        const int p = pass * pm.PPT + pl;
+        const bool live = FULL || ((b < S) && (p < HW));
+        const long n = live ? ((long)b * HW + p) : 0;
+        pend[0] = pm.row<FULL>(pass, 32 * sb + (lane >> 2));
+        pend[1] = pm.row<FULL>(pass, 32 * sb + 16 + (lane >> 2));
+        // ---- q, k, v of head X for this wave's 32 tokens ----
+        {
+            bf16x8 xb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xb[s] = *reinterpret_cast<const bf16x8*>(cur + x_off(slot, 2 * s + g));
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int ob = 2 * t + X;
+                f32x16 acc;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(&bfrag[(ob * 2 + g) * 16 + 4 * q]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[4 * q + i] = bv[i];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = mfma16(*reinterpret_cast<const bf16x8*>(&wfrag[((ob * 4 + s) * 64 + lane) * 8]), xb[s], acc);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bf16x4 w;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) w[i] = (__bf16)acc[4 * q + i];
+                    *reinterpret_cast<bf16x4*>(tile + t * TEN + d_off(X, slot, q) + 4 * g) = w;
+                }
+            }
+        }
+        lds_barrier();                     // the pass's q, k, v tile is complete
+        if (a.qkv) {
+            // tile -> qkv rows: piece f of the tile in LDS order = (tensor, 8-row group, head, row & 7, chunk position)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int f = i * 256 + tid;
+                const int t = f >> 9, r = ((f >> 6) & 7) * 8 + ((f >> 2) & 7), Xf = (f >> 5) & 1, c = (f & 3) ^ ((r >> 2) & 3);
+                const uint4 v = *reinterpret_cast<const uint4*>(tile + 8 * f);
+                const long nr = pm.row<FULL>(pass, r);
+                if (FULL || nr >= 0) *reinterpret_cast<uint4*>(a.qkv + nr * 192 + 64 * t + 32 * Xf + 8 * c) = v;
+            }
+        }
+        const __bf16 *Q = tile, *K = tile + TEN, *V = tile + 2 * TEN;
+        bf16x8 qx[2];
+        own_row(Q, X, slot, g, qx);
+        f32x16 sc[NW];
+        float m = -INFINITY;
+        const unsigned dbase = DROP ? ksr_attn_drop_base(a.seed, (unsigned long long)n, X) : 0u;
+#pragma unroll
+        for (int kb = 0; kb < NW; ++kb) {
+            sc[kb] = zero16();
+            rows_times_x(K, X, kbase0 + 32 * kb, tok, g, qx, sc[kb]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int same, kbb;
+                smap.decode(kbase0, kb, key_of_reg(r, g), pl, same, kbb);
+                sc[kb][r] = (FULL || (same && (kbb < S))) ? sc[kb][r] : -INFINITY;
+                m = fmaxf(m, sc[kb][r]);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        float l = 0.f;
+        const float m2 = m * cexp;
+#pragma unroll
+        for (int kb = 0; kb < NW; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const float e0 = __builtin_amdgcn_exp2f(fmaf(sc[kb][r], cexp, -m2));
+                const float e1 = __builtin_amdgcn_exp2f(fmaf(sc[kb][r + 1], cexp, -m2));
+                l += e0 + e1;
+                sc[kb][r] = e0; sc[kb][r + 1] = e1;
+                if (DROP) {
+                    int same, kbb;
+                    smap.decode(kbase0, kb, key_of_reg(r, g), pl, same, kbb);
+                    const unsigned x = ksr_attn_keep_word(dbase, kbb);
+                    sc[kb][r] = (x & 0xffffu) < thr ? e0 : 0.f;
+                    sc[kb][r + 1] = (x >> 16) < thr ? e1 : 0.f;
+                }
+            }
+        const float inv_l = inv_keep / ksr_pair_sum(l);
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int kb = 0; kb < NW; ++kb) tr_times_acc(V, X, kbase0 + 32 * kb, lane, sc[kb], acc);
+        tile_to_xp(xp, lane, acc, inv_l);
+    };
+
+    int pass = blockIdx.x;
+    if (pass < npass) issue_x<FULL>(xsA, a.x, pm, pass, wv, lane);
+    for (; pass < npass; pass += 2 * G) {
+        body(xsA, xsB, pass, pass == (int)blockIdx.x);
+        if (pass + G >= npass) break;
+        body(xsB, xsA, pass + G, false);
+    }
+    ksr_wave_fence();
+    if ((int)blockIdx.x < npass) xp_to_rows<FULL>(xp, a.ctx, pend, 64, 32 * X, lane);
+}
+
 // ------------------------------------------------------------------------------------------ backward
 template <int NW, bool DROP, bool FULL>
 __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
@@ -428,6 +604,30 @@ int ksr_attn_dma_fwd_launch(const AttnArgs& a, hipStream_t stream) {
     }
 #undef KSR_ATTN_FWD
     KSR_LAUNCH_CHECK("batch_attn_fwd(bf16 storage)");
+    return KSR_OK;
+}
+
+int ksr_qkv_attn_dma_fwd_launch(const float* x, const float* w, const float* bias, float* qkv, float* ctx, int S, int Sp,
+                                int HW, float p_drop, unsigned long long seed, const unsigned long long* seed_dev,
+                                hipStream_t stream) {
+    QkvAttnArgs a{reinterpret_cast<const __bf16*>(x), w, bias, reinterpret_cast<__bf16*>(qkv), reinterpret_cast<__bf16*>(ctx),
+                  S, Sp, HW, p_drop, seed, seed_dev};
+    const int ppt = TS / Sp, npass = (HW + ppt - 1) / ppt;
+    const dim3 g((unsigned)(npass < 512 ? npass : 512)), block(256);
+    const bool full = S == Sp && Sp >= 32 && HW % ppt == 0;
+    const bool drop = p_drop > 0.f;
+#define KSR_QKV_ATTN(NWV, DR)                                                                                    \
+    do {                                                                                                         \
+        if (full) hipLaunchKernelGGL((qkv_attn_fwd_dma_kernel<NWV, DR, true>), g, block, 0, stream, a);          \
+        else hipLaunchKernelGGL((qkv_attn_fwd_dma_kernel<NWV, DR, false>), g, block, 0, stream, a);              \
+    } while (0)
+    if (Sp == 64) {
+        if (drop) KSR_QKV_ATTN(2, true); else KSR_QKV_ATTN(2, false);
+    } else {
+        if (drop) KSR_QKV_ATTN(1, true); else KSR_QKV_ATTN(1, false);
+    }
+#undef KSR_QKV_ATTN
+    KSR_LAUNCH_CHECK("batch_qkv_attn_fwd(bf16 storage)");
     return KSR_OK;
 }
 

@@ -86,7 +86,7 @@ EXPORTS = [
     "ksr_version", "ksr_last_error", "ksr_set_precision", "ksr_get_precision",
     "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",
     "ksr_stem_fwd", "ksr_stem_gate_fwd", "ksr_pointwise_fwd", "ksr_dwrelu_pw_fwd", "ksr_gate_pw_fwd",
-    "ksr_batch_tx_layer_fwd", "ksr_batch_attn_fwd", "ksr_batch_tx_layer_post_fwd",
+    "ksr_batch_tx_layer_fwd", "ksr_batch_attn_fwd", "ksr_batch_qkv_attn_fwd", "ksr_batch_tx_layer_post_fwd",
     "ksr_feed_kan_supported", "ksr_feed_kan_fwd",
     "ksr_feed_kan_lane_len", "ksr_feed_kan_bwd", "ksr_batch_tx_layer_bwd_token", "ksr_batch_tx_layer_bwd_attn",
     "ksr_batch_attn_bwd",

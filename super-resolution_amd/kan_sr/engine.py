@@ -148,10 +148,8 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
             # large local batch: QKV projection, MFMA attention and the rest of the layer as three kernels
             qkv = sv["qkv"] if keep else new(N, 192)
             ctx = sv["ctx"] if keep else new(N, 64)
-            check(L.ksr_pointwise_fwd(ptr(s), ptr(plist[0]), ptr(plist[1]), ptr(qkv), c_int(192), c_int(0),
-                                      *_dims(g), stream()), "ksr_pointwise_fwd")
-            check(L.ksr_batch_attn_fwd(ptr(qkv), ptr(ctx), c_int(g.B), c_int(g.H * g.W), c_float(p_drop), lseed,
-                                       stream()), "ksr_batch_attn_fwd")
+            check(L.ksr_batch_qkv_attn_fwd(ptr(s), ptr(plist[0]), ptr(plist[1]), ptr(qkv), ptr(ctx), c_int(g.B),
+                                           c_int(g.H * g.W), c_float(p_drop), lseed, stream()), "ksr_batch_qkv_attn_fwd")
             sv_arr = _ptr_array([None, None] + [sv[k] for k in names[2:]]) if keep else None
             check(L.ksr_batch_tx_layer_post_fwd(ptr(s), ptr(ctx), ptr(out), _ptr_array(plist), sv_arr, c_int64(N),
                                                 c_float(LN_EPS), c_float(p_drop), lseed, ptr(s_f32), stream()),

@@ -608,3 +608,44 @@ def test_backward_kernels_that_rebuild_t_from_v_equal_the_tensor_reading_ones(B,
         outs.append((dpre.cpu(), rc.cpu(), r2.cpu()))
     for a, b in zip(outs[0], outs[1]):
         assert rel_l2(b, a) <= 1e-5
+
+
+@pytest.mark.parametrize("S,HW,p_drop,save", [(64, 1100, 0.1, True), (64, 130, 0.0, False), (32, 1301, 0.1, True), (12, 2101, 0.1, True),
+                                              (48, 64, 0.0, True), (5, 40, 0.1, True), (100, 9, 0.0, True)])
+def test_fused_in_projection_attention_equals_the_two_kernels(S, HW, p_drop, save):
+    """ksr_batch_qkv_attn_fwd (bf16 storage: in_proj inside the attention kernel, q / k / v formed in LDS) against
+    ksr_pointwise_fwd + ksr_batch_attn_fwd on the same input, weights and dropout stream: the same bf16-rounded q, k, v
+    up to the summation order of the fp32 accumulation (a few values land on the other side of a rounding boundary),
+    the same context.  S = 5 and S = 100 take the entry point's two-kernel route and must agree exactly."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(S + HW)
+    N = S * HW
+    L = lib()
+    w = torch.randn(192, 64, device="cuda") * 0.2
+    bias = torch.randn(192, device="cuda") * 0.1
+    try:
+        engine.set_precision("bf16s")
+        x = torch.randn(N, 64, device="cuda").bfloat16()
+        qkv_a = torch.full((N, 192), float("nan"), device="cuda").bfloat16()
+        ctx_a = torch.full((N, 64), float("nan"), device="cuda").bfloat16()
+        check(L.ksr_pointwise_fwd(ptr(x), ptr(w), ptr(bias), ptr(qkv_a), c_int(192), c_int(0), c_int(S), c_int(1), c_int(HW),
+                                  stream()), "pointwise")
+        check(L.ksr_batch_attn_fwd(ptr(qkv_a), ptr(ctx_a), c_int(S), c_int(HW), c_float(p_drop), c_uint64(9), stream()), "attn")
+        fused_route = 9 <= S <= 64
+        qkv_b = torch.full((N, 192), float("nan"), device="cuda").bfloat16() if (save or not fused_route) else None
+        ctx_b = torch.full((N, 64), float("nan"), device="cuda").bfloat16()
+        check(L.ksr_batch_qkv_attn_fwd(ptr(x), ptr(w), ptr(bias), ptr(qkv_b), ptr(ctx_b), c_int(S), c_int(HW), c_float(p_drop),
+                                       c_uint64(9), stream()), "fused")
+    finally:
+        engine.set_precision("fp32")
+    assert bool(torch.isfinite(ctx_b.float()).all())
+    if not fused_route:
+        assert torch.equal(ctx_a, ctx_b) and torch.equal(qkv_a, qkv_b)
+        return
+    if qkv_b is not None:
+        d = (qkv_a.float() - qkv_b.float()).abs()
+        assert float(d.max()) <= 2 ** -7 * float(qkv_a.float().abs().max())          # at most one bf16 step
+        assert float((d > 0).float().mean()) <= 0.02
+        assert rel_l2(qkv_b.float().cpu(), qkv_a.float().cpu()) <= 1e-3
+    assert rel_l2(ctx_b.float().cpu(), ctx_a.float().cpu()) <= 4e-3
