@@ -49,6 +49,31 @@ __device__ __forceinline__ f32x16 zero16() {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // as lds_barrier, and this wave's transfers (and stores) have completed before it arrives
 __device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// as dma_barrier, but the wave's YOUNGEST vector-memory instructions may still be in flight: vmcnt counts loads and
+// stores of a wave in issue order on this target (the compiler itself waits for a load past younger stores with
+// vmcnt(n > 0)), so "at most YOUNGER outstanding" means every transfer issued before them has landed.  Only usable
+// where the number of instructions issued after the transfers is exact (no store skipped by a branch).
+template <int YOUNGER>
+__device__ __forceinline__ void dma_barrier_but() {
+    static_assert(YOUNGER >= 0 && YOUNGER < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(YOUNGER) : "memory");
+}
+
+// One LDS-DMA instruction: lane l moves 16 bytes from its own global address to lds_wave_base + 16 l.  Issued from inline
+// assembly (M0 saved and restored around it): the compiler then keeps no record of transfers in flight, where it would
+// otherwise make every read of an LDS array that no transfer ever targets (statistics, transposer tiles) wait for ALL of
+// them.  Every wait for a transfer in this file is therefore explicit (dma_barrier, dma_barrier_but).
+template <bool NT>
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    unsigned keep_m0;
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_m0) : "s"(base), "v"(gsrc) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_m0) : "s"(base), "v"(gsrc) : "memory");
+}
 
 // token row of slot s of pass `pass`, or -1
 struct PassMap {
@@ -77,9 +102,7 @@ __device__ __forceinline__ void issue_pass(__bf16* __restrict__ st, const __bf16
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const __bf16* src = (t < 3) ? s3 + 64 * t : dctx + n * 64 + 32 * Xl + 8 * c;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(st + t * TEN + grp * 512),
-                                             16, 0, 2 /* nt: every row is read once */);
+            dma16<true>(src, st + t * TEN + grp * 512);      // nt: every row is read once
         }
     }
 }
@@ -134,14 +157,21 @@ __device__ __forceinline__ void tile_to_xp(__bf16* __restrict__ xp, int lane, co
 }
 // ... -> 64-byte pieces of rows n[0] (slot lane >> 2) and n[1] (slot 16 + (lane >> 2)) of a tensor with ld elements per
 // row, at channel c0
-template <bool FULL = false>
+template <bool FULL = false, bool NT = false>
 __device__ __forceinline__ void xp_to_rows(const __bf16* __restrict__ xp, __bf16* __restrict__ base, const long (&n)[2],
                                            int ld, int c0, int lane) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = 16 * i + (lane >> 2), c8 = (lane & 3) * 8;
         const uint4 v = *reinterpret_cast<const uint4*>(xp + row * XP_LD + c8);
-        if (FULL || n[i] >= 0) *reinterpret_cast<uint4*>(base + n[i] * ld + c0 + c8) = v;
+        if (FULL || n[i] >= 0) {
+            if constexpr (NT) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(base + n[i] * ld + c0 + c8));
+            } else {
+                *reinterpret_cast<uint4*>(base + n[i] * ld + c0 + c8) = v;
+            }
+        }
     }
     ksr_wave_fence();
 }
@@ -277,8 +307,7 @@ __device__ __forceinline__ void issue_x(__bf16* __restrict__ st, const __bf16* _
         long n = pm.row<FULL>(pass, r);
         if (!FULL && n < 0) n = 0;
         const int c = cp ^ ((r >> 1) & 7);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(x + n * 64 + 8 * c),
-                                         (__attribute__((address_space(3))) void*)(st + grp * 512), 16, 0, 0);
+        dma16<false>(x + n * 64 + 8 * c, st + grp * 512);
     }
 }
 
@@ -288,7 +317,6 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
     __shared__ __attribute__((aligned(16))) __bf16 xsA[TEN];
     __shared__ __attribute__((aligned(16))) __bf16 xsB[TEN];
     __shared__ __attribute__((aligned(16))) __bf16 tile[3 * TEN];           // q, k, v of the pass (d_off layout)
-    __shared__ __attribute__((aligned(16))) __bf16 wfrag[6 * 4 * 64 * 8];   // [out block][k step][lane][8]
     __shared__ __attribute__((aligned(16))) float bfrag[6 * 2 * 16];        // [out block][lane half][register]
     __shared__ __attribute__((aligned(16))) __bf16 xps[4 * 32 * XP_LD];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -310,17 +338,33 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
     __bf16* xp = xps + wv * 32 * XP_LD;
     const int G = gridDim.x;
 
-    // element i of lane (row = ln & 31, half ln >> 5) in step s of out block ob = W[32 ob + row][16 s + 8 half + i]
-    for (int idx = tid; idx < 6 * 4 * 64 * 8; idx += 256) {
-        const int i = idx & 7, ln = (idx >> 3) & 63, s4 = (idx >> 9) & 3, ob = idx >> 11;
-        wfrag[idx] = (__bf16)a.w[(32 * ob + (ln & 31)) * 64 + 16 * s4 + 8 * (ln >> 5) + i];
-    }
+    // this wave's weight fragments stay in registers (48): element i of step s of tensor t =
+    // W[64 t + 32 X + (lane & 31)][16 s + 8 (lane >> 5) + i]
+    bf16x8 wreg[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float* wp = a.w + (64 * t + 32 * X + tok) * 64 + 16 * s4 + 8 * g;
+            const float4 w0 = *reinterpret_cast<const float4*>(wp), w1 = *reinterpret_cast<const float4*>(wp + 4);
+            const float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wreg[t][s4][i] = (__bf16)wf[i];
+        }
     for (int idx = tid; idx < 6 * 2 * 16; idx += 256)
         bfrag[idx] = a.bias[32 * (idx >> 5) + key_of_reg(idx & 15, (idx >> 4) & 1)];
 
     long pend[2] = {-1, -1};
-    auto body = [&](const __bf16* __restrict__ cur, __bf16* __restrict__ nxt, int pass, bool first) {
-        dma_barrier();                     // cur has landed; every wave is done with the previous pass's tile
+    // since the transfers of this pass were issued (top of the previous pass) the wave has issued 2 stores of the context
+    // (not in the pass after the first) and 6 of qkv (if it is written): those may stay in flight
+    const bool save_qkv = a.qkv != nullptr;
+    auto body = [&](const __bf16* __restrict__ cur, __bf16* __restrict__ nxt, int pass, bool first, bool second) {
+        // cur has landed; every wave is done with the previous pass's tile
+        if (FULL && !first && !second) {
+            if (save_qkv) dma_barrier_but<8>(); else dma_barrier_but<2>();
+        } else {
+            dma_barrier();
+        }
         if (pass + G < npass) issue_x<FULL>(nxt, a.x, pm, pass + G, wv, lane);
         if (!first) xp_to_rows<FULL>(xp, a.ctx, pend, 64, 32 * X, lane);
         const int p = pass * pm.PPT + pl;
@@ -345,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
                 }
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    acc = mfma16(*reinterpret_cast<const bf16x8*>(&wfrag[((ob * 4 + s) * 64 + lane) * 8]), xb[s], acc);
+                    acc = mfma16(wreg[t][s], xb[s], acc);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     bf16x4 w;
@@ -356,7 +400,7 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
             }
         }
         lds_barrier();                     // the pass's q, k, v tile is complete
-        if (a.qkv) {
+        if (save_qkv) {
             // tile -> qkv rows: piece f of the tile in LDS order = (tensor, 8-row group, head, row & 7, chunk position)
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
@@ -364,7 +408,9 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
                 const int t = f >> 9, r = ((f >> 6) & 7) * 8 + ((f >> 2) & 7), Xf = (f >> 5) & 1, c = (f & 3) ^ ((r >> 2) & 3);
                 const uint4 v = *reinterpret_cast<const uint4*>(tile + 8 * f);
                 const long nr = pm.row<FULL>(pass, r);
-                if (FULL || nr >= 0) *reinterpret_cast<uint4*>(a.qkv + nr * 192 + 64 * t + 32 * Xf + 8 * c) = v;
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                if (FULL || nr >= 0)      // non-temporal: read next by the backward, a whole forward and loss later
+                    __builtin_nontemporal_store(u32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4*>(a.qkv + nr * 192 + 64 * t + 32 * Xf + 8 * c));
             }
         }
         const __bf16 *Q = tile, *K = tile + TEN, *V = tile + 2 * TEN;
@@ -414,9 +460,9 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
     int pass = blockIdx.x;
     if (pass < npass) issue_x<FULL>(xsA, a.x, pm, pass, wv, lane);
     for (; pass < npass; pass += 2 * G) {
-        body(xsA, xsB, pass, pass == (int)blockIdx.x);
+        body(xsA, xsB, pass, pass == (int)blockIdx.x, false);
         if (pass + G >= npass) break;
-        body(xsB, xsA, pass + G, false);
+        body(xsB, xsA, pass + G, false, pass == (int)blockIdx.x);
     }
     ksr_wave_fence();
     if ((int)blockIdx.x < npass) xp_to_rows<FULL>(xp, a.ctx, pend, 64, 32 * X, lane);
@@ -456,8 +502,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
     __bf16* dqkv = reinterpret_cast<__bf16*>(a.dqkv);
     const int G = gridDim.x;
 
-    auto body = [&](const __bf16* __restrict__ cur, __bf16* __restrict__ nxt, int pass) {
-        lds_barrier();                     // every wave is done with the previous pass: nxt (its stage) is free
+    auto body = [&](const __bf16* __restrict__ cur, __bf16* __restrict__ nxt, int pass, bool first) {
+        // cur has landed (its transfers were issued at the top of the previous pass; the 6 stores of that pass's results
+        // are younger and may stay in flight); every wave is done with the previous pass: nxt (its stage) is free
+        if (FULL && !first) dma_barrier_but<6>(); else dma_barrier();
         if (pass + G < npass) issue_pass<4, FULL>(nxt, qkv, dctx, pm, pass + G, wv, lane);
         const int p = pass * pm.PPT + pl;
         const bool live = FULL || ((b < S) && (p < HW));
@@ -532,7 +580,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
             tile_to_xp(xp, lane, dq, 1.f);
         }
         __builtin_amdgcn_sched_barrier(0);
-        dma_barrier();                     // the statistics are visible; the next pass's rows have landed
+        lds_barrier();                     // the statistics are visible
         xp_to_rows<FULL>(xp, dqkv, nrow, 192, 32 * X, lane);
         // ---------------- phase B: this lane is a key ----------------
         {
@@ -575,11 +623,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
 
     int pass = blockIdx.x;
     if (pass < npass) issue_pass<4, FULL>(stA, qkv, dctx, pm, pass, wv, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the first pass's rows: later passes wait at the mid-pass barrier
     for (; pass < npass; pass += 2 * G) {
-        body(stA, stB, pass);
+        body(stA, stB, pass, pass == (int)blockIdx.x);
         if (pass + G >= npass) break;
-        body(stB, stA, pass + G);
+        body(stB, stA, pass + G, false);
     }
 }
 

@@ -168,9 +168,9 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             if (PRO == PRO_DWRELU) {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) op[i] = g[i] > 0.f ? g[i] : 0.f;
-                if (a.save) ksr_store32_co<ST>(xb, a.save, n0w, nvalid, 64, 0, lane, op);
+                if (a.save) ksr_store32_co<ST, true, true>(xb, a.save, n0w, nvalid, 64, 0, lane, op);
             } else {
-                if (a.save) ksr_store32_co<ST>(xb, a.save, n0w, nvalid, 64, 0, lane, g);
+                if (a.save) ksr_store32_co<ST, true, true>(xb, a.save, n0w, nvalid, 64, 0, lane, g);
                 float val[32];
                 ksr_load32_co<ST>(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, val);
 #pragma unroll
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
                 o[16 + q] = apply_act<ACT>(acc[2 * grp + 1][q]);
             }
             ksr_store32_co<ST, !AHEAD>(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
-            if (a.out32) ksr_store32_co<float, !AHEAD>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            if (a.out32) ksr_store32_co<float, !AHEAD, true>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
         }
     }
 }
@@ -370,10 +370,10 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
         if (a.sv_v) {
             if (live && h == 0) a.sv_v[n] = vc;
             if (a.sv_t) {
-                ksr_store32_co<ST>(xb, a.sv_t, n0w, nvalid, 128, 0, lane, val);
-                ksr_store32_co<ST>(xb, a.sv_t, n0w, nvalid, 128, 64, lane, tg);
+                ksr_store32_co<ST, true, true>(xb, a.sv_t, n0w, nvalid, 128, 0, lane, val);
+                ksr_store32_co<ST, true, true>(xb, a.sv_t, n0w, nvalid, 128, 64, lane, tg);
             }
-            ksr_store32_co<ST>(xb, a.sv_g, n0w, nvalid, 64, 0, lane, g);
+            ksr_store32_co<ST, true, true>(xb, a.sv_g, n0w, nvalid, 64, 0, lane, g);
         }
         f32x16 acc[2];
         ksr_wave_gemm<PREC, 32, 2>(sm.frag1, sm.bias1, op, acc, lane);
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) { x3[q] = ksr_sigmoid(acc[0][q]); x3[16 + q] = ksr_sigmoid(acc[1][q]); }
         if (a.sv_x3) {
-            ksr_store32_co<ST>(xb, a.sv_x3, n0w, nvalid, 64, 0, lane, x3);
+            ksr_store32_co<ST, true, true>(xb, a.sv_x3, n0w, nvalid, 64, 0, lane, x3);
             if (sizeof(ST) == 2) {
                 // the backward and the next layer read x3 as stored: continue from the rounded values
 #pragma unroll

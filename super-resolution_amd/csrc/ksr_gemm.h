@@ -337,7 +337,7 @@ __device__ __forceinline__ void ksr_load32_co(float* __restrict__ xb, const void
     ksr_co_finish<T>(xb, lane, t, x);
 }
 // fp32 LDS tile -> rows [n0, n0 + nvalid) of the tensor (caller has written the tile and fenced)
-template <class T, bool TWO_PATH = true>
+template <class T, bool TWO_PATH = true, bool NT = false>
 __device__ __forceinline__ void ksr_co_from_lds(const float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                 int ld, int c0, int lane) {
     // full tiles (all but the last one of a tensor) take a path without per-row predicates; nvalid is wave-uniform.
@@ -352,7 +352,7 @@ __device__ __forceinline__ void ksr_co_from_lds(const float* __restrict__ xb, vo
         for (int i = 0; i < 8; ++i) {
             const int row = 4 * i + r4;
             const float4 v = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE_LD + c4);
-            if (!GUARD || row < nvalid) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4) = v;
+            if (!GUARD || row < nvalid) ksr_st16<NT>(reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4), v);
         }
     } else {
         const int r8 = lane >> 3, c8 = (lane & 7) * 8;
@@ -362,7 +362,7 @@ __device__ __forceinline__ void ksr_co_from_lds(const float* __restrict__ xb, vo
             const float* sp = xb + row * KSR_XPOSE_LD + c8;
             const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
             const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if (!GUARD || row < nvalid) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8) = ksr_pack8(x);
+            if (!GUARD || row < nvalid) ksr_st16<NT>(reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8), ksr_pack8(x));
         }
     }
     };
@@ -370,7 +370,7 @@ __device__ __forceinline__ void ksr_co_from_lds(const float* __restrict__ xb, vo
     else body(std::true_type{});
 }
 // The reverse of ksr_load32_co: x (half layout) -> rows [n0, n0 + nvalid).
-template <class T, bool TWO_PATH = true>
+template <class T, bool TWO_PATH = true, bool NT = false>
 __device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                int ld, int c0, int lane, const float (&x)[32]) {
     float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
@@ -378,13 +378,13 @@ __device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, void* __r
 #pragma unroll
     for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     ksr_wave_fence();
-    ksr_co_from_lds<T, TWO_PATH>(xb, base, n0, nvalid, ld, c0, lane);
+    ksr_co_from_lds<T, TWO_PATH, NT>(xb, base, n0, nvalid, ld, c0, lane);
 }
 
 // 32-channel rows (lane half h holds channels 16h .. 16h+15): same scheme with rows padded to 36 floats.
 constexpr int KSR_XPOSE16_LD = 36;
 // fp32 LDS tile [32][36] <-> rows of a tensor with ld elements per row, channels c0 .. c0+31
-template <class T, bool TWO_PATH = true>
+template <class T, bool TWO_PATH = true, bool NT = false>
 __device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                   int ld, int c0, int lane) {
     // full tiles (all but the last one of a tensor) take a path without per-row predicates; nvalid is wave-uniform.
@@ -398,7 +398,7 @@ __device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, 
         for (int i = 0; i < 4; ++i) {
             const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
             const float4 v = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE16_LD + c4);
-            if (!GUARD || row < nvalid) *reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4) = v;
+            if (!GUARD || row < nvalid) ksr_st16<NT>(reinterpret_cast<float4*>(reinterpret_cast<float*>(base) + (n0 + row) * ld + c0 + c4), v);
         }
     } else {
 #pragma unroll
@@ -407,7 +407,7 @@ __device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, 
             const float* sp = xb + row * KSR_XPOSE16_LD + c8;
             const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
             const float x[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            if (!GUARD || row < nvalid) *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8) = ksr_pack8(x);
+            if (!GUARD || row < nvalid) ksr_st16<NT>(reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(base) + (n0 + row) * ld + c0 + c8), ksr_pack8(x));
         }
     }
     };
@@ -475,7 +475,7 @@ __device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const void
     ksr_co16_fetch<T>(base, n0, nvalid, lane, t);
     ksr_co16_finish<T>(xb, lane, t, x);
 }
-template <class T, bool TWO_PATH = true>
+template <class T, bool TWO_PATH = true, bool NT = false>
 __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                int lane, const float (&x)[16]) {
     float* wp = xb + (lane & 31) * KSR_XPOSE16_LD + 16 * (lane >> 5);
@@ -483,7 +483,7 @@ __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     ksr_wave_fence();
-    ksr_co16_from_lds<T, TWO_PATH>(xb, base, n0, nvalid, 32, 0, lane);
+    ksr_co16_from_lds<T, TWO_PATH, NT>(xb, base, n0, nvalid, 32, 0, lane);
 }
 
 // Sum of v over the two lanes that share a token (lanes l and l^32).

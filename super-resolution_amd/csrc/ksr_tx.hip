@@ -162,6 +162,11 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
             if (POST) ksr_store32_co<ST, !AHEAD>(xb, base, n0w, nvalid, 64, 0, lane, v);
             else if (live) ksr_storen<ST, 32>(base, n * 64 + 32 * h, v);
         };
+        // tensors kept for the backward: non-temporal stores in the row-tiled mode
+        auto sv32 = [&](float* base, const float (&v)[32]) {
+            if (POST) ksr_store32_co<ST, !AHEAD, true>(xb, base, n0w, nvalid, 64, 0, lane, v);
+            else if (live) ksr_storen<ST, 32>(base, n * 64 + 32 * h, v);
+        };
 
         float s0[32];
         if (POST) {
@@ -270,8 +275,8 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
             const float rstd = ksr_layernorm64(u, xhat, a.eps);
             ln_affine(xhat, sm.ln[0], sm.ln[1], h, s1);
             if (TRAIN) {
-                if (a.sv_xhat1) st32(a.sv_xhat1, xhat);
-                if (a.sv_s1) st32(a.sv_s1, s1);
+                if (a.sv_xhat1) sv32(a.sv_xhat1, xhat);
+                if (a.sv_s1) sv32(a.sv_s1, s1);
                 if (live && a.sv_rstd1 && h == 0) a.sv_rstd1[n] = rstd;
             }
         }
@@ -290,7 +295,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
                     hm[i] = ksr_keep(a.seed, 2u, (unsigned long long)n * 32 + 16 * h, i, keep) ? hm[i] * inv_keep : 0.f;
             }
             if (TRAIN && a.sv_hmid) {
-                if (POST) ksr_store16_co<ST, !AHEAD>(xb, a.sv_hmid, n0w, nvalid, lane, hm);
+                if (POST) ksr_store16_co<ST, !AHEAD, true>(xb, a.sv_hmid, n0w, nvalid, lane, hm);
                 else if (live) ksr_storen<ST, 16>(a.sv_hmid, n * 32 + 16 * h, hm);
             }
             f32x16 acc2[2];
@@ -308,7 +313,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
             const float rstd = ksr_layernorm64(u, xhat, a.eps);
             ln_affine(xhat, sm.ln[2], sm.ln[3], h, s2);
             if (TRAIN) {
-                if (a.sv_xhat2) st32(a.sv_xhat2, xhat);
+                if (a.sv_xhat2) sv32(a.sv_xhat2, xhat);
                 if (live && a.sv_rstd2 && h == 0) a.sv_rstd2[n] = rstd;
             }
         }
@@ -319,7 +324,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
             const float rstd = ksr_layernorm64(s2, xhat, a.eps);
             ln_affine(xhat, sm.ln[4], sm.ln[5], h, y);
             if (TRAIN) {
-                if (a.sv_xhatf) st32(a.sv_xhatf, xhat);
+                if (a.sv_xhatf) sv32(a.sv_xhatf, xhat);
                 if (live && a.sv_rstdf && h == 0) a.sv_rstdf[n] = rstd;
             }
             st32(a.out, y);
