@@ -6,8 +6,8 @@
 //   S = (2 mu_p mu_t + c1)(2 cov + c2) / ((mu_p^2 + mu_t^2 + c1)(var_p + var_t + c2));
 //   only windows that lie entirely inside the image count (the (H-10) x (W-10) interior); mean over pixels,
 //   channels and images.
-// Forward: one 32 x 32 tile of windows per workgroup, separable filtering through LDS, per-workgroup partial sums
-// reduced in a fixed order.  Backward (luma plane only: the chroma planes do not depend on the parameters): the
+// Forward: column strips walked top to bottom (vertical filter in registers, horizontal filter through LDS, see
+// ssim_fwd_cols_kernel), per-workgroup partial sums reduced in a fixed order.  Backward (luma plane only: the chroma planes do not depend on the parameters): the
 // forward also writes dS/dmu_p, dS/dE[p^2], dS/dE[pt] per window; the gradient kernel filters those three maps
 // with the same window and combines them with p and t.
 #include "ksr_common.h"
@@ -31,139 +31,146 @@ struct SsimArgs {
 
 __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
 
-// Both filter passes hand one thread a run of SS_RUN outputs along the filter direction: the SS_RUN + 10 inputs of
-// the run are read from LDS once and slide through registers (2.25 LDS reads per output and quantity, not 11).
-constexpr int SS_GRID = 256 * 3;       // persistent workgroups: three fit a CU (LDS)
+// The gradient kernel's filter passes hand one thread a run of SS_RUN outputs along the filter direction: the SS_RUN + 10
+// inputs of the run are read from LDS once and slide through registers (2.25 LDS reads per output and quantity, not 11).
 constexpr int SS_RUN = 8, SS_RUNS = SS_T / SS_RUN, SS_SPAN = SS_RUN + SS_K - 1;   // 4 runs, 18 inputs each
 
-__global__ void __launch_bounds__(256) ssim_fwd_kernel(SsimArgs a, SsimWin w) {
-    __shared__ float ps[SS_IN][SS_IN + 1], ts[SS_IN][SS_IN + 1];
-    __shared__ float hs[5][SS_IN][SS_T + 1];
-    __shared__ float red[4];
+// ---------------------------------------------------------------------------------------------------------------
+// Forward, column-first.  A workgroup of 192 threads owns a strip of <= 192 input columns (<= 182 window columns) and a
+// band of 122 window rows, and walks down the band: thread = input column.  VERTICAL pass in registers: an input row
+// adds g[k] * (p, t, pp, tt, pt) to the running sums of the 11 window rows it belongs to (scatter form; the sums rotate
+// through 11 register sets, the loop over an 11-row batch is unrolled so that every index is static; the tap that
+// starts a window row overwrites its set) and completes one window row, whose five column sums go to LDS.  HORIZONTAL
+// pass after each batch: one thread per (row of the batch, run of 11 windows) slides over 21 columns (1.9 LDS reads per
+// window and quantity group) and evaluates S and, for the luma channel, the three derivative maps.  The next batch's
+// pixels are requested before the horizontal pass.  Against the tile version (32 x 32 windows from 42 x 42 pixels,
+// filter passes that keep 3 and 2 of 4 waves busy): no rows are filtered twice, 6 % of the columns are, every thread
+// works in both passes.
+constexpr int SV_T = 192;
+constexpr int SV_WO = SV_T - (SS_K - 1);        // window columns per strip at most
+constexpr int SV_R = SS_K;                      // input rows per batch
+constexpr int SV_BH = SS_K * SS_K + 1;          // window rows per band: 12 batches of input rows
+constexpr int SV_RUN = 11, SV_SPAN = SV_RUN + SS_K - 1;
+constexpr int SV_V1_LD = SV_T + 16;             // pitch of the e12 rows: the 4 batch rows of a wave fall on different banks
+constexpr int SV_GRID = 256 * 2;                // persistent workgroups: two fit a CU (registers)
+
+__global__ void __launch_bounds__(SV_T) ssim_fwd_cols_kernel(SsimArgs a, SsimWin w, int ns, int wo, int nb) {
+    __shared__ float4 v4[SV_R][SV_T];            // (mu_p, mu_t, E[pp], E[tt]) column sums of a batch's window rows
+    __shared__ float v1[SV_R][SV_V1_LD];         // E[pt]
+    __shared__ float red[SV_T / 64];
     const int Hi = a.H - 2 * SS_R, Wi = a.W - 2 * SS_R;
-    const int tiles_x = (Wi + SS_T - 1) / SS_T;
-    const int tiles = tiles_x * ((Hi + SS_T - 1) / SS_T), total = tiles * a.C * a.B;
-    // Persistent workgroups: each takes one contiguous range of (tile, channel, image) indices, tile fastest, and the
-    // ranges of one XCD are neighbours.  The next tile's pixels are fetched into registers while this one is filtered.
+    const int total = ns * nb * a.C * a.B;
     const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t_begin = (int)ksr_xcd_contiguous(blockIdx.x, gridDim.x) * chunk, t_end = min(total, t_begin + chunk);
     const long plane = (long)a.H * a.W;
-    constexpr int NIT = (SS_IN + 3) / 4;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float pv[NIT], tv[NIT];
-    // wave v loads rows v, v + 4, ... (lane = column): all loads of a tile are in flight together
-    auto fetch = [&](int t) {
-        const int tile = t % tiles, c = (t / tiles) % a.C, b = t / (tiles * a.C);
-        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-        const int y0 = ty * SS_T, x0 = tx * SS_T;
-        const float* P = a.pred + (long)b * a.pred_bs + (long)c * plane;
-        const float* T = a.tgt + (long)b * a.tgt_bs + (long)c * plane;
-        const bool col_in = lane < SS_IN && x0 + lane < a.W;
-        const long first = (long)(y0 + wv) * a.W + x0 + lane;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int r = wv + 4 * it;
-            const bool in = col_in && r < SS_IN && y0 + r < a.H;
-            pv[it] = in ? P[first + (long)(4 * it) * a.W] : 0.f;
-            tv[it] = in ? T[first + (long)(4 * it) * a.W] : 0.f;
-        }
-    };
+    const int tid = threadIdx.x;
+    const int nruns = (wo + SV_RUN - 1) / SV_RUN;
     const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
     float sum = 0.f;
-    if (t_begin < t_end) fetch(t_begin);
     for (int t = t_begin; t < t_end; ++t) {
-    const int tile = t % tiles, c = (t / tiles) % a.C, b = t / (tiles * a.C);
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    // the filter passes keep only the first waves busy: rotating the wave numbering with the tile index spreads that
-    // work over the four SIMDs of a CU, which holds several workgroups at a time
-    const int tid = (threadIdx.x + 64 * (t & 3)) & 255;
-    const int y0 = ty * SS_T, x0 = tx * SS_T;                  // first window of the tile = first pixel it reads
-    // ps / ts were last read before the barrier that follows the row pass of the previous tile
+        const int strip = t % ns, band = (t / ns) % nb, c = (t / (ns * nb)) % a.C, b = t / (ns * nb * a.C);
+        const int x0 = strip * wo, y0 = band * SV_BH;
+        const int xo_end = min(Wi, x0 + wo), yo_end = min(Hi, y0 + SV_BH);      // windows [y0, yo_end) x [x0, xo_end)
+        const int y_in_end = yo_end + SS_K - 1;                                  // input rows [y0, y_in_end)
+        const int nbatch = (y_in_end - y0 + SV_R - 1) / SV_R;
+        const int col = x0 + tid;
+        const bool col_in = col < xo_end + SS_K - 1;
+        const float* P = a.pred + (long)b * a.pred_bs + (long)c * plane + col;
+        const float* T = a.tgt + (long)b * a.tgt_bs + (long)c * plane + col;
+        float pv[SV_R], tv[SV_R];
+        auto fetch = [&](int m) {
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int r = wv + 4 * it;
-        if (lane < SS_IN && r < SS_IN) { ps[r][lane] = clamp01(pv[it]); ts[r][lane] = clamp01(tv[it]); }
-    }
-    if (t + 1 < t_end) fetch(t + 1);
-    __syncthreads();
-    // rows: item = (run j, row r), r fastest.  Sums are kept as (p, t), (pp, tt) pairs and pt: packed fp32 FMAs.
-    if (tid < SS_RUNS * SS_IN) {
-        const int j = tid / SS_IN, r = tid - j * SS_IN, q0 = j * SS_RUN;
-        f32x2 sa[SS_RUN], sb[SS_RUN];
-        float sc[SS_RUN];
-#pragma unroll
-        for (int o = 0; o < SS_RUN; ++o) { sa[o] = f32x2{0.f, 0.f}; sb[o] = f32x2{0.f, 0.f}; sc[o] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < SS_SPAN; ++i) {
-            const f32x2 x = {ps[r][q0 + i], ts[r][q0 + i]};
-            const f32x2 xx = x * x;
-            const float pt = x[0] * x[1];
-#pragma unroll
-            for (int o = 0; o < SS_RUN; ++o) {
-                if (i - o < 0 || i - o >= SS_K) continue;
-                const float g = w.g[i - o];
-                sa[o] += g * x; sb[o] += g * xx; sc[o] += g * pt;
+            for (int rr = 0; rr < SV_R; ++rr) {
+                const int y = y0 + SV_R * m + rr;
+                const bool in = col_in && y < y_in_end;
+                pv[rr] = in ? P[(long)y * a.W] : 0.f;
+                tv[rr] = in ? T[(long)y * a.W] : 0.f;
             }
-        }
+        };
+        fetch(0);
+        f32x2 sa[SS_K], sb[SS_K];
+        float sc[SS_K];
 #pragma unroll
-        for (int o = 0; o < SS_RUN; ++o) {
-            hs[0][r][q0 + o] = sa[o][0]; hs[1][r][q0 + o] = sa[o][1]; hs[2][r][q0 + o] = sb[o][0];
-            hs[3][r][q0 + o] = sb[o][1]; hs[4][r][q0 + o] = sc[o];
+        for (int j = 0; j < SS_K; ++j) { sa[j] = f32x2{0.f, 0.f}; sb[j] = f32x2{0.f, 0.f}; sc[j] = 0.f; }
+        for (int m = 0; m < nbatch; ++m) {
+            // ---- vertical: input row y0 + 11 m + rr is tap k of window row y - k, kept in register set (rr - k) mod 11
+#pragma unroll
+            for (int rr = 0; rr < SV_R; ++rr) {
+                const f32x2 x = {clamp01(pv[rr]), clamp01(tv[rr])};
+                const f32x2 xx = x * x;
+                const float pt = x[0] * x[1];
+#pragma unroll
+                for (int k = 0; k < SS_K; ++k) {
+                    const int j = (rr - k + SS_K) % SS_K;
+                    const float g = w.g[k];
+                    if (k == 0) { sa[j] = g * x; sb[j] = g * xx; sc[j] = g * pt; }
+                    else { sa[j] += g * x; sb[j] += g * xx; sc[j] += g * pt; }
+                }
+                const int jc = (rr + 1) % SS_K;             // window row y - 10 is complete
+                v4[rr][tid] = make_float4(sa[jc][0], sa[jc][1], sb[jc][0], sb[jc][1]);
+                v1[rr][tid] = sc[jc];
+            }
+            if (m + 1 < nbatch) fetch(m + 1);
+            __syncthreads();
+            // ---- horizontal: thread = (batch row rr, run j of 11 windows), j fastest
+            if (tid < SV_R * nruns) {
+                const int rr = tid / nruns, j = tid - rr * nruns, q0 = j * SV_RUN;
+                const int uy = y0 + SV_R * m + rr - (SS_K - 1);
+                if (uy >= y0 && uy < yo_end) {
+                    f32x2 ha[SV_RUN], hb[SV_RUN];
+                    float hc[SV_RUN];
+#pragma unroll
+                    for (int o = 0; o < SV_RUN; ++o) { ha[o] = f32x2{0.f, 0.f}; hb[o] = f32x2{0.f, 0.f}; hc[o] = 0.f; }
+#pragma unroll
+                    for (int i = 0; i < SV_SPAN; ++i) {
+                        // at most four columns' reads ahead of their use: hoisting all 21 costs 100 registers
+                        if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                        const int q = min(q0 + i, SV_T - 1);            // columns past the strip only feed windows past it
+                        const float4 v = v4[rr][q];
+                        const float vc = v1[rr][q];
+                        const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
+#pragma unroll
+                        for (int o = 0; o < SV_RUN; ++o) {
+                            if (i - o < 0 || i - o >= SS_K) continue;
+                            const float g = w.g[i - o];
+                            ha[o] += g * va; hb[o] += g * vb; hc[o] += g * vc;
+                        }
+                    }
+#pragma unroll
+                    for (int o = 0; o < SV_RUN; ++o) {
+                        const int ux = x0 + q0 + o;
+                        if (ux >= xo_end) continue;
+                        const float m1 = ha[o][0], m2 = ha[o][1], e11 = hb[o][0], e22 = hb[o][1], e12 = hc[o];
+                        const float vp_raw = e11 - m1 * m1, vt_raw = e22 - m2 * m2;
+                        const float vp = fmaxf(vp_raw, 0.f), vt = fmaxf(vt_raw, 0.f);
+                        const float cov = e12 - m1 * m2;
+                        const float N1 = 2.f * m1 * m2 + c1, D1 = m1 * m1 + m2 * m2 + c1;
+                        const float N2 = 2.f * cov + c2, D2 = vp + vt + c2;
+                        const float i1 = __builtin_amdgcn_rcpf(D1), i2 = __builtin_amdgcn_rcpf(D2);
+                        const float inv = i1 * i2;
+                        const float S = N1 * N2 * inv;
+                        sum += S;
+                        if (a.maps && c == 0) {
+                            const float vp_on = vp_raw > 0.f ? 1.f : 0.f;
+                            const float dC = 2.f * N1 * inv;
+                            const float dB = -S * i2 * vp_on;
+                            const float dA = 2.f * m2 * (N2 - N1) * inv - 2.f * m1 * S * (i1 - i2 * vp_on);
+                            const long mi = ((long)b * Hi + uy) * Wi + ux;
+                            const long ms = (long)a.B * Hi * Wi;
+                            a.maps[mi] = dA; a.maps[ms + mi] = dB; a.maps[2 * ms + mi] = dC;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);      // one window's temporaries at a time
+                    }
+                }
+            }
+            __syncthreads();       // the next batch's vertical pass overwrites v4 / v1
         }
     }
-    __syncthreads();
-    // columns: item = (run j, column q), q fastest
-    if (tid < SS_RUNS * SS_T) {
-        const int j = tid / SS_T, q = tid - j * SS_T, r0 = j * SS_RUN;
-        f32x2 sa[SS_RUN], sb[SS_RUN];
-        float sc[SS_RUN];
-#pragma unroll
-        for (int o = 0; o < SS_RUN; ++o) { sa[o] = f32x2{0.f, 0.f}; sb[o] = f32x2{0.f, 0.f}; sc[o] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < SS_SPAN; ++i) {
-            const f32x2 va = {hs[0][r0 + i][q], hs[1][r0 + i][q]}, vb = {hs[2][r0 + i][q], hs[3][r0 + i][q]};
-            const float vc = hs[4][r0 + i][q];
-#pragma unroll
-            for (int o = 0; o < SS_RUN; ++o) {
-                if (i - o < 0 || i - o >= SS_K) continue;
-                const float g = w.g[i - o];
-                sa[o] += g * va; sb[o] += g * vb; sc[o] += g * vc;
-            }
-        }
-        const int ux = x0 + q;
-#pragma unroll
-        for (int o = 0; o < SS_RUN; ++o) {
-            const int uy = y0 + r0 + o;
-            if (uy >= Hi || ux >= Wi) continue;
-            const float m1 = sa[o][0], m2 = sa[o][1], e11 = sb[o][0], e22 = sb[o][1], e12 = sc[o];
-            const float vp_raw = e11 - m1 * m1, vt_raw = e22 - m2 * m2;
-            const float vp = fmaxf(vp_raw, 0.f), vt = fmaxf(vt_raw, 0.f);
-            const float cov = e12 - m1 * m2;
-            const float N1 = 2.f * m1 * m2 + c1, D1 = m1 * m1 + m2 * m2 + c1;
-            const float N2 = 2.f * cov + c2, D2 = vp + vt + c2;
-            // hardware reciprocals (1 ulp) instead of four IEEE divisions per window
-            const float i1 = __builtin_amdgcn_rcpf(D1), i2 = __builtin_amdgcn_rcpf(D2);
-            const float inv = i1 * i2;
-            const float S = N1 * N2 * inv;
-            sum += S;
-            if (a.maps && c == 0) {
-                const float vp_on = vp_raw > 0.f ? 1.f : 0.f;              // derivative of the clamp at 0
-                const float dC = 2.f * N1 * inv;                            // dS/dE[pt]
-                const float dB = -S * i2 * vp_on;                           // dS/dE[p^2]
-                const float dA = 2.f * m2 * (N2 - N1) * inv - 2.f * m1 * S * (i1 - i2 * vp_on);
-                const long mi = ((long)b * Hi + uy) * Wi + ux;
-                const long ms = (long)a.B * Hi * Wi;
-                a.maps[mi] = dA; a.maps[ms + mi] = dB; a.maps[2 * ms + mi] = dC;
-            }
-        }
-    }
-    }   // tiles
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0)
-        a.slab[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) a.slab[blockIdx.x] = red[0] + red[1] + red[2];
 }
 
 // One workgroup: strided partial sums in double, a butterfly inside each wave, then the 16 wave sums in order
@@ -200,7 +207,7 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin 
     const int Hi = a.H - 2 * SS_R, Wi = a.W - 2 * SS_R;
     const int tiles_x = (a.W + SS_T - 1) / SS_T;
     const int tiles = tiles_x * ((a.H + SS_T - 1) / SS_T), total = tiles * a.B;
-    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;          // persistent, as in ssim_fwd_kernel
+    const int chunk = (total + (int)gridDim.x - 1) / (int)gridDim.x;          // persistent: one contiguous range of tiles per workgroup, neighbours on one XCD
     const int t_begin = (int)ksr_xcd_contiguous(blockIdx.x, gridDim.x) * chunk, t_end = min(total, t_begin + chunk);
     const long msz = (long)a.B * Hi * Wi;
     constexpr int NIT = (SS_IN + 3) / 4;
@@ -225,7 +232,7 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin 
     for (int t = t_begin; t < t_end; ++t) {
     const int tile = t % tiles, b = t / tiles;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int tid = (threadIdx.x + 64 * (t & 3)) & 255;     // see ssim_fwd_kernel
+    const int tid = (threadIdx.x + 64 * (t & 3)) & 255;     // the filter passes keep only the first waves busy: rotate the wave numbering with the tile
     const int py0 = ty * SS_T, px0 = tx * SS_T;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -321,10 +328,11 @@ extern "C" int ksr_ssim_fwd(const float* pred, int64_t pred_batch_stride, const 
     fill_window(w);
     SsimArgs a{pred, (long)pred_batch_stride, tgt, (long)tgt_batch_stride, maps, slab, C, B, H, W};
     const int Hi = H - 2 * SS_R, Wi = W - 2 * SS_R;
-    const unsigned tiles = (unsigned)(((Hi + SS_T - 1) / SS_T) * ((Wi + SS_T - 1) / SS_T));
-    KSR_CHECK_ARG((long)tiles * C * B < (1L << 31), "ssim_fwd: too many tiles for one launch");
-    const unsigned grid = (unsigned)std::min<long>((long)tiles * C * B, SS_GRID);
-    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(grid), dim3(256), 0, stream, a, w);
+    // strips of equal width (<= 182 window columns), bands of 122 window rows
+    const int ns = (Wi + SV_WO - 1) / SV_WO, wo = (Wi + ns - 1) / ns, nb = (Hi + SV_BH - 1) / SV_BH;
+    KSR_CHECK_ARG((long)ns * nb * C * B < (1L << 31), "ssim_fwd: too many strips for one launch");
+    const unsigned grid = (unsigned)std::min<long>((long)ns * nb * C * B, SV_GRID);
+    hipLaunchKernelGGL(ssim_fwd_cols_kernel, dim3(grid), dim3(SV_T), 0, stream, a, w, ns, wo, nb);
     KSR_LAUNCH_CHECK("ssim_fwd");
     hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, slab, (long)grid,
                        1.0 / ((double)B * C * Hi * Wi), ssim_out);

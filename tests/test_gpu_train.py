@@ -159,7 +159,7 @@ def test_rccl_path_single_rank_matches_no_comm_path():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 40, 52), (1, 33, 97), (3, 12, 11)])
+@pytest.mark.parametrize("B,H,W", [(2, 40, 52), (1, 33, 97), (3, 12, 11), (1, 270, 400), (2, 135, 203), (1, 133, 193)])
 def test_ssim_kernels_vs_oracle(B, H, W):
     """SSIM value and its luma gradient against autograd of the oracle's restatement (parity with torchmetrics itself
     is unpinned: the library is not available).  Values outside [0,1] exercise the clamp."""
@@ -208,8 +208,12 @@ def test_train_step_with_ssim_loss_vs_oracle():
     for n, prm in m.named_parameters():
         want = p_ref[n].detach() - before[n]
         have = prm.detach().cpu() - before[n]
-        # Adam's first step moves every element by ~lr * sign(grad): compare the update direction and size
-        assert (have - want).abs().max() <= 2e-4 * 1e-3 + 0.02 * want.abs().max(), n
+        # Adam's first step moves every element by lr * g / (|g| + 1e-8): compare the update where the gradient is well
+        # above eps (there the step is ~lr * sign(g)); where |g| is within a few hundred eps (the q / k rows of the
+        # in-projection: sums that cancel to ~1e-8) the step follows the last bits of g, so only its bound is checked
+        clear = p_ref[n].grad.abs() > 1e-6
+        assert (have - want)[clear].abs().max() <= 2e-4 * 1e-3 + 0.02 * want.abs().max() if bool(clear.any()) else True, n
+        assert (have - want).abs().max() <= 1.001e-3, n
 
 
 def test_training_trajectory_bf16_storage_tracks_fp32():
