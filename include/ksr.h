@@ -142,7 +142,7 @@ int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, float p_drop
                        ksr_stream_t stream);
 /* ksr_pointwise_fwd(n_out = 192) + ksr_batch_attn_fwd in one launch (MultiheadAttention's in_proj and attention,
  * gazetr.py:110-115 through torch's multi_head_attention_forward): qkv [N,192] is written when not NULL (the backward
- * reads it) and never read.  The fused kernel exists for bf16 storage with 9 <= S <= 64; other cases run the two
+ * reads it) and never read.  The fused kernel exists for bf16 storage with 3 <= S <= 64; other cases run the two
  * kernels and need the qkv buffer. */
 int ksr_batch_qkv_attn_fwd(const float* in, const float* in_proj_weight, const float* in_proj_bias, float* qkv,
                            float* ctx, int S, int HW, float p_drop, uint64_t seed, ksr_stream_t stream);

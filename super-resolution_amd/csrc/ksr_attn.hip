@@ -400,7 +400,7 @@ extern "C" int ksr_batch_attn_fwd(const float* qkv, float* ctx, int S, int HW, f
 }
 
 // in_proj + attention in one launch: qkv [N,192] = x [N,64] * in_w^T + in_b (written when qkv is not null: the
-// backward's saved tensor) and ctx as ksr_batch_attn_fwd.  bf16 storage with 9 <= S <= 64 runs the fused kernel
+// backward's saved tensor) and ctx as ksr_batch_attn_fwd.  bf16 storage with 3 <= S <= 64 runs the fused kernel
 // (ksr_attn_dma.hip); every other case is ksr_pointwise_fwd followed by ksr_batch_attn_fwd and needs the qkv buffer.
 extern "C" int ksr_batch_qkv_attn_fwd(const float* x, const float* in_w, const float* in_b, float* qkv, float* ctx, int S,
                                       int HW, float p_drop, uint64_t seed, hipStream_t stream) {

@@ -1,4 +1,4 @@
-// Batch-axis attention for bf16 STORAGE (mode KSR_BF16S), 16 <= Sp <= 64: the operand rows go from global memory
+// Batch-axis attention for bf16 STORAGE (mode KSR_BF16S), 4 <= Sp <= 64: the operand rows go from global memory
 // straight into LDS with the LDS-DMA (global_load_lds, 16 bytes per lane), one pass ahead of the arithmetic, and are
 // never held in registers as fetched tiles.  Same products, masks, softmax and dropout arithmetic as ksr_attn_bf16.hip;
 // what differs:
@@ -632,7 +632,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
 
 }  // namespace
 
-bool ksr_attn_dma_supported(int Sp) { return Sp >= 16 && Sp <= 64; }
+bool ksr_attn_dma_supported(int Sp) { return Sp >= 4 && Sp <= 64; }
 
 int ksr_attn_dma_fwd_launch(const AttnArgs& a, hipStream_t stream) {
     const int ppt = TS / a.Sp, npass = (a.HW + ppt - 1) / ppt;

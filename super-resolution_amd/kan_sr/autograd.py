@@ -195,7 +195,7 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     grads[q + "self_attn.out_proj.weight"], grads[q + "self_attn.out_proj.bias"] = gw, gb
     # attention
     dqkv = ws.act(N, 192)
-    attn_bwd = L.ksr_batch_attn_bwd if g.B > engine.SPLIT_ATTENTION_ABOVE else L.ksr_batch_tx_layer_bwd_attn
+    attn_bwd = L.ksr_batch_attn_bwd if engine.split_attention(g.B) else L.ksr_batch_tx_layer_bwd_attn
     check(attn_bwd(ptr(sv["qkv"]), ptr(sv["ctx"]), ptr(dctx), ptr(dqkv), c_int(g.B), c_int(g.H * g.W), c_float(p_drop),
                    c_uint64(lseed), stream()), "attention backward")
     gw, gb = ws.grad(q + "self_attn.in_proj_weight", 192, 64), ws.grad(q + "self_attn.in_proj_bias", 192)
