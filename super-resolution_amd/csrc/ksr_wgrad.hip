@@ -274,6 +274,134 @@ __global__ void __launch_bounds__(256, 2) wgrad_kernel(WgArgs a) {
     }
 }
 
+// The same accumulation for the shapes of the training step in bf16 storage (no product operand, no square sums, every
+// channel of dz valid, staged rows of RL4 16-byte pieces with RL4 a multiple of 4, one batch entry), with the bookkeeping
+// of the general kernel taken out of the chunk loop - that kernel spends half of its time issuing vector instructions
+// (address arithmetic of a run-time piece -> (row, tensor) map for every transfer, range masks, unpacking for the bias
+// sums): each thread's RL4 / 4 source pointers are formed once and advance by a constant per chunk; only a range's last
+// chunk takes the masked path; the bias sums are one more matrix product against a vector of ones.
+template <int RL4, int NP>
+__global__ void __launch_bounds__(256, 2) wgrad_fast_kernel(WgArgs a) {
+    typedef __bf16 T;
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    constexpr int WG_T = 64, RL = RL4 * 8, NPASS = RL4 / 4, NS = WG_T / 16;
+    extern __shared__ __attribute__((aligned(16))) float wlds_raw[];
+    T* wlds = reinterpret_cast<T*>(wlds_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 31, kk = lane >> 5;
+    const int NJB = a.J / 32, NKB = a.K / 32;
+    const int kb = wv % NKB, jb0 = wv / NKB, jbs = 4 / NKB;
+    int jcol[NP];
+    unsigned jm[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int jb = jb0 + p * jbs;
+        jcol[p] = 32 * (jb < NJB ? jb : jb0);
+        jm[p] = jb < NJB ? 0xffffffffu : 0u;
+    }
+    f32x16 acc[NP], bacc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { acc[p][q] = 0.f; bacc[p][q] = 0.f; }
+    const long per = (((a.N + gridDim.x - 1) / gridDim.x) + WG_T - 1) / WG_T * WG_T;
+    const long n0 = (long)blockIdx.x * per;
+    const long n1 = ((long)(blockIdx.x + 1) * per < a.N) ? n0 + per : a.N;
+    const int nchunks = n1 > n0 ? (int)((n1 - n0 + WG_T - 1) / WG_T) : 0;
+
+    // piece f = i * 256 + tid of a chunk: staged row f / RL4, 16-byte piece f % RL4 of [dz | a1]
+    const T* src[NPASS];
+    int trow[NPASS], adv[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; ++i) {
+        const int f = i * 256 + tid;
+        trow[i] = f / RL4;
+        const int q = (f - trow[i] * RL4) * 8;
+        const bool is_dz = q < a.J;
+        const int ld = is_dz ? a.dz_ld : a.a1_ld;
+        src[i] = (is_dz ? reinterpret_cast<const T*>(a.dz) + a.dz_c0 + q : reinterpret_cast<const T*>(a.a1) + a.a1_c0 + (q - a.J))
+                 + (n0 + trow[i]) * ld;
+        adv[i] = WG_T * ld;
+    }
+    auto issue = [&](int c) {
+        T* dstbuf = wlds + (c & 1) * (WG_T * RL);
+        const long t0 = n0 + (long)c * WG_T;
+        const bool ragged = t0 + WG_T > n1;                    // wave-uniform: rows past the range repeat its last row
+#pragma unroll
+        for (int i = 0; i < NPASS; ++i) {
+            const T* sp = src[i];
+            if (ragged && t0 + trow[i] >= n1) sp -= (t0 + trow[i] - (n1 - 1)) * (long)(adv[i] / WG_T);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                             (__attribute__((address_space(3))) void*)(dstbuf + (i * 256 + wv * 64) * 8),
+                                             16, 0, 2 /* nt: operands are read once */);
+            src[i] += adv[i];
+        }
+    };
+    const int li = lane & 15;
+    const int lane_off = (8 * kk + (li >> 2)) * RL + 16 * ((lane >> 4) & 1) + 4 * (li & 3);
+    const int bbase = a.J + 32 * kb;
+    auto tr = [&](const T* ptr) -> uint2 {
+        const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+        return *reinterpret_cast<const uint2*>(&v);
+    };
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.f;
+
+    if (nchunks > 0) issue(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();                 // chunk c has landed; buffer (c+1)&1 is free
+        if (c + 1 < nchunks) issue(c + 1);
+        const T* buf = wlds + (c & 1) * (WG_T * RL);
+        const long t0 = n0 + (long)c * WG_T;
+        const int nvalid = (n1 - t0 < WG_T) ? (int)(n1 - t0) : WG_T;
+        const bool ragged = nvalid < WG_T;
+#pragma unroll
+        for (int g = 0; g < NS; ++g) {
+            const T* base = buf + 16 * g * RL + lane_off;
+            uint2 bq[2], aq[NP][2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                bq[r] = tr(base + 4 * r * RL + bbase);
+#pragma unroll
+                for (int p = 0; p < NP; ++p) aq[p][r] = tr(base + 4 * r * RL + jcol[p]);
+            }
+            unsigned m[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (ragged) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int px = 16 * g + 8 * kk + 2 * d;
+                    m[d] = (px < nvalid ? 0x0000ffffu : 0u) | (px + 1 < nvalid ? 0xffff0000u : 0u);
+                }
+            }
+            const uint4 bw = make_uint4(bq[0].x, bq[0].y, bq[1].x, bq[1].y);
+            const bf16x8 bpk = *reinterpret_cast<const bf16x8*>(&bw);
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const uint4 aw = make_uint4(aq[p][0].x & m[0] & jm[p], aq[p][0].y & m[1] & jm[p], aq[p][1].x & m[2] & jm[p],
+                                            aq[p][1].y & m[3] & jm[p]);
+                const bf16x8 apk = *reinterpret_cast<const bf16x8*>(&aw);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apk, bpk, acc[p], 0, 0, 0);
+                if (kb == 0) bacc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(apk, ones, bacc[p], 0, 0, 0);   // wave-uniform
+            }
+        }
+    }
+    float* slab = a.slab + (long)blockIdx.x * a.stride;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int jb = jb0 + p * jbs;
+        if (jb < NJB) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = (q & 3) + 8 * (q >> 2) + 4 * kk;
+                slab[(long)(32 * jb + row) * a.K + 32 * kb + col] = acc[p][q];
+                if (kb == 0 && col == 0) slab[(long)a.J * a.K + 32 * jb + row] = bacc[p][q];
+            }
+        }
+    }
+}
+
 // out[j*sj + k*sk] = sum_g slab[g][j*K + k];  bias[j] = sum_g slab[g][tail_off + j] for j < tail_len.
 // With kan_O > 0 the rows are in lane order (half, e) of the fused feed+KAN kernel and are scattered to
 // the reference's channel numbering (rows that are padding are dropped).  blockIdx.y selects a batch
@@ -647,7 +775,26 @@ extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const flo
     long g = (N + 4 * T - 1) / (4 * T);
     if (g > WG_GRID) g = WG_GRID;
     if (lds_bytes > 40 * 1024 && g > WG_GRID / 2) g = WG_GRID / 2;     // 2 workgroups per CU fit
-    if (int rc = launch_wgrad_kernel(a, per_wave, T, lds_bytes, (unsigned)g, 1, stream)) return rc;
+    bool fast = false;
+    if (ksr_prec() == KSR_BF16S && !a2 && T == 64) {
+        const int rl4 = (J + K) / 8;
+#define KSR_WG_FAST(R4, NPV)                                                                                             \
+        if (rl4 == R4 && per_wave == NPV) {                                                                              \
+            static bool attr_set = false;                                                                                \
+            if (!attr_set) {                                                                                             \
+                hipError_t e = hipFuncSetAttribute((const void*)wgrad_fast_kernel<R4, NPV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+                if (e != hipSuccess) { ksr_set_error("wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e)); return KSR_ERR_HIP; } \
+                attr_set = true;                                                                                         \
+            }                                                                                                            \
+            hipLaunchKernelGGL((wgrad_fast_kernel<R4, NPV>), dim3((unsigned)g), dim3(256), lds_bytes, stream, a);        \
+            KSR_LAUNCH_CHECK("wgrad");                                                                                   \
+            fast = true;                                                                                                 \
+        }
+        KSR_WG_FAST(12, 1) else KSR_WG_FAST(16, 1) else KSR_WG_FAST(24, 2) else KSR_WG_FAST(28, 3)
+#undef KSR_WG_FAST
+    }
+    if (!fast)
+        if (int rc = launch_wgrad_kernel(a, per_wave, T, lds_bytes, (unsigned)g, 1, stream)) return rc;
     int kan_O = 0, kan_nbh = 0;
     if (kan_upscale > 0) {
         kan_O = kan_upscale * kan_upscale;
