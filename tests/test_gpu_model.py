@@ -649,3 +649,33 @@ def test_fused_in_projection_attention_equals_the_two_kernels(S, HW, p_drop, sav
         assert float((d > 0).float().mean()) <= 0.02
         assert rel_l2(qkv_b.float().cpu(), qkv_a.float().cpu()) <= 1e-3
     assert rel_l2(ctx_b.float().cpu(), ctx_a.float().cpu()) <= 4e-3
+
+
+@pytest.mark.parametrize("J,K,ld_dz,c0_dz,ld_a,c0_a", [(64, 64, 64, 0, 64, 0), (32, 64, 32, 0, 64, 0), (64, 32, 64, 0, 32, 0),
+                                                      (128, 64, 128, 0, 64, 0), (64, 64, 128, 64, 192, 128), (96, 64, 96, 0, 64, 0)])
+@pytest.mark.parametrize("N", [64 * 1024, 70001, 130, 37])
+def test_weight_gradient_kernels_bf16_storage_vs_fp64(J, K, ld_dz, c0_dz, ld_a, c0_a, N):
+    """ksr_wgrad in bf16 storage (the specialised kernel for the training step's shapes and, for J = 96, the general
+    one) against an fp64 product of the same bf16 tensors: dW = dz^T a, db = column sums of dz; channel slices of wider
+    tensors, pixel counts that leave ragged chunks and idle workgroups.  The products of bf16 values are exact in fp32;
+    only the summation order differs: rel-L2 <= 1e-5."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(J + K + N)
+    L = lib()
+    dz = torch.randn(N, ld_dz, device="cuda").bfloat16()
+    a = torch.randn(N, ld_a, device="cuda").bfloat16()
+    dW = torch.full((J, K), float("nan"), device="cuda")
+    db = torch.full((J,), float("nan"), device="cuda")
+    slab = torch.empty(int(L.ksr_wgrad_slab_floats(c_int(J), c_int(K))), device="cuda")
+    try:
+        engine.set_precision("bf16s")
+        for _ in range(2):          # twice: the second call must not depend on what the first left in the slab
+            check(L.ksr_wgrad(ptr(dz), c_int(ld_dz), c_int(c0_dz), c_int(J), ptr(a), c_int(ld_a), c_int(c0_a), c_int(K), None,
+                              c_int(0), c_int(0), c_int64(N), ptr(slab), ptr(dW), ptr(db), c_int(0), c_int(0), stream()), "wgrad")
+    finally:
+        engine.set_precision("fp32")
+    dzs, as_ = dz[:, c0_dz:c0_dz + J].double(), a[:, c0_a:c0_a + K].double()
+    assert rel_l2(dW.double().cpu(), (dzs.t() @ as_).cpu()) <= 1e-5
+    ref_b = dzs.sum(0).cpu()
+    assert float((db.double().cpu() - ref_b).norm()) <= 1e-5 * float(ref_b.norm()) + 1e-4
