@@ -179,15 +179,17 @@ class ConvSepKan(nn.Module):
     def _forward_attention(self, x, p, pre, g, p_drop, seed, needs_grad):
         """Encoder trunk -> channel attention head -> KAN + pixel shuffle + chroma."""
         from .ops import kan_head
-        if self.precision == "bf16s":
-            raise KsrError("the channel-attention head has no bf16-storage kernels: use precision 'fp32' or 'bf16'")
         head = self.layers[-1].encoder.encoder.feed
-        head.precision = self.precision
+        # bf16 storage: the encoder trunk runs in that mode; the head's kernels keep fp32 tensors (bf16 operands), so the
+        # 64-channel features are widened once at the boundary (and their gradient narrowed by autograd's cast)
+        head.precision = "bf16" if self.precision == "bf16s" else self.precision
         with torch.set_grad_enabled(needs_grad):
             if needs_grad:
                 from .autograd import trunk_train
                 feat = trunk_train(x, p, pre, g, p_drop, seed, self.precision)
             else:
                 feat = engine.encoder_forward(x, p, pre, g, None, p_drop, seed)
+            if feat.dtype is not torch.float32:
+                feat = feat.float()
             w = head.forward_nhwc(feat, (g.B, g.H, g.W))
             return kan_head(x, w, self.grid_size, self.spline_order, self.grid_range, self.upscale)

@@ -171,7 +171,7 @@ def test_model_with_attention_head(r, G, B, H, W):
         assert rel_l2(prm.grad.cpu(), ref) <= 2e-4 or float((prm.grad.cpu() - ref).norm()) <= 1e-7, (n, rel_l2(prm.grad.cpu(), ref))
 
 
-@pytest.mark.parametrize("loss,precision", [("l1", "fp32"), ("l1+ssim", "fp32"), ("l1+ssim", "bf16")])
+@pytest.mark.parametrize("loss,precision", [("l1", "fp32"), ("l1+ssim", "fp32"), ("l1+ssim", "bf16"), ("l1+ssim", "bf16s")])
 def test_attention_head_train_step_vs_oracle_adam(loss, precision):
     """TrainStep on ConvSepKan(..., attention=True) (BASELINE configs[3]: G = 16, channel-attention head; tape backward
     into the flat buffer, one exchange bucket, fused Adam): loss value, gradients of the first step and the parameters
@@ -220,3 +220,45 @@ def test_attention_head_train_step_vs_oracle_adam(loss, precision):
             assert rel_l2(prm.detach().cpu(), pr[n].detach()) <= 5e-3, n
     engine.set_precision("fp32")
     ts.close()
+
+
+def test_attention_head_model_bf16_storage_vs_oracle():
+    """ConvSepKan(..., attention=True) with precision "bf16s": the encoder trunk in bf16 storage, its features widened
+    once for the channel-attention head (bf16 operands, fp32 tensors).  16 x 32 x 32 pixels, eval mode, against the fp32
+    oracle: forward rel-L2 <= 2e-2; gradients of tensors with >= 64 elements cosine >= 0.99 and rel-L2 <= 0.15 (the
+    bound of the fp32-storage bf16 mode: the head's Gram products and softmax amplify operand rounding)."""
+    from kan_sr.module import ConvSepKan
+    from kan_sr import engine
+    torch.manual_seed(5)
+    r, G, B, H, W = 4, 16, 16, 32, 32
+    m = ConvSepKan([1], [r * r], [3], G, 3, 0.1, [-1, 1], r, attention=True).eval()
+    with torch.no_grad():
+        for n, prm in m.named_parameters():
+            if "norm" in n:
+                prm.add_(0.1 * torch.randn_like(prm))
+    params = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    x, gy = torch.rand(B, 3, H, W), torch.randn(B, 3, r * H, r * W)
+    p_ref = {n: v.clone().requires_grad_() for n, v in params.items()}
+    y_ref = orc.conv_sep_kan_forward(x, p_ref, out_channels=[r * r], grid_size=G, spline_order=3, grid_range=[-1, 1],
+                                     upscale=r, attention=True)
+    (y_ref * gy).sum().backward()
+    m = m.cuda()
+    m.precision = "bf16s"
+    try:
+        with torch.no_grad():
+            y0 = m(x.cuda())
+        assert rel_l2(y0[:, 0].cpu(), y_ref[:, 0].detach()) <= 2e-2
+        y = m(x.cuda())
+        y.backward(gy.cuda())
+    finally:
+        engine.set_precision("fp32")
+    assert rel_l2(y[:, 0].detach().cpu(), y_ref[:, 0].detach()) <= 2e-2
+    for n, prm in m.named_parameters():
+        if ".a_dw." in n:
+            continue
+        ref, got = p_ref[n].grad.flatten(), prm.grad.cpu().flatten()
+        assert bool(torch.isfinite(got).all()), n
+        if ref.numel() >= 64:
+            cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
+            assert cos >= 0.99, (n, cos)
+            assert rel_l2(got, ref) <= 0.15, (n, rel_l2(got, ref))

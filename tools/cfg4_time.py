@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the attention-head configuration (G=16, ConvSepKanAttention(64, 64, 336) in place of feed): forward +
-backward through autograd, 64 patches of 128x128, per entry point.  python tools/cfg4_time.py [fp32|bf16]"""
+backward through autograd, 64 patches of 128x128, per entry point.  python tools/cfg4_time.py [fp32|bf16|bf16s]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ from kan_sr import _lib  # noqa: E402
 from kan_sr.module import ConvSepKan  # noqa: E402
 
 torch.manual_seed(0)
-for prec in (sys.argv[1:] or ["fp32", "bf16"]):
+for prec in (sys.argv[1:] or ["fp32", "bf16", "bf16s"]):
     m = ConvSepKan([1], [16], [3], 16, 3, 0.1, [-1, 1], 4, attention=True).cuda().train()
     m.precision = prec
     x = torch.rand(64, 3, 128, 128, device="cuda")
