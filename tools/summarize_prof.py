@@ -62,7 +62,7 @@ with open(os.path.join(OUT, f"{TAG}_pmc_hbm.csv"), "w", newline="") as fh:
     wtr.writerows(rows)
 per_kernel = {r[0]: r[6] for r in rows}
 # ksr_wgrad launches one of several wgrad_kernel instances followed by one reduce_kernel: launch-weighted average
-wg = [r for r in rows if r[0].startswith("wgrad_kernel<")]
+wg = [r for r in rows if r[0].startswith(("wgrad_kernel<", "wgrad_fast_kernel<"))]
 if wg:
     per_kernel["entry:ksr_wgrad"] = int(sum(r[6] * r[1] for r in wg) / sum(r[1] for r in wg) + per_kernel.get("reduce_kernel", 0))
 # bench.py reads the default workload's file; other tags keep their own
