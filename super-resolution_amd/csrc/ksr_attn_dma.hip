@@ -45,36 +45,6 @@ __device__ __forceinline__ f32x16 zero16() {
     return z;
 }
 
-// every wave's LDS writes are complete and visible, every wave has arrived
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// as lds_barrier, and this wave's transfers (and stores) have completed before it arrives
-__device__ __forceinline__ void dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-// as dma_barrier, but the wave's YOUNGEST vector-memory instructions may still be in flight: vmcnt counts loads and
-// stores of a wave in issue order on this target (the compiler itself waits for a load past younger stores with
-// vmcnt(n > 0)), so "at most YOUNGER outstanding" means every transfer issued before them has landed.  Only usable
-// where the number of instructions issued after the transfers is exact (no store skipped by a branch).
-template <int YOUNGER>
-__device__ __forceinline__ void dma_barrier_but() {
-    static_assert(YOUNGER >= 0 && YOUNGER < 64, "vmcnt is a 6-bit field");
-    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(YOUNGER) : "memory");
-}
-
-// One LDS-DMA instruction: lane l moves 16 bytes from its own global address to lds_wave_base + 16 l.  Issued from inline
-// assembly (M0 saved and restored around it): the compiler then keeps no record of transfers in flight, where it would
-// otherwise make every read of an LDS array that no transfer ever targets (statistics, transposer tiles) wait for ALL of
-// them.  Every wait for a transfer in this file is therefore explicit (dma_barrier, dma_barrier_but).
-template <bool NT>
-__device__ __forceinline__ void dma16(const void* gsrc, void* lds_wave_base) {
-    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
-    unsigned keep_m0;
-    if constexpr (NT)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep_m0) : "s"(base), "v"(gsrc) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep_m0) : "s"(base), "v"(gsrc) : "memory");
-}
-
 // token row of slot s of pass `pass`, or -1
 struct PassMap {
     int Sp, lg, S, HW, PPT;
@@ -102,7 +72,7 @@ __device__ __forceinline__ void issue_pass(__bf16* __restrict__ st, const __bf16
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const __bf16* src = (t < 3) ? s3 + 64 * t : dctx + n * 64 + 32 * Xl + 8 * c;
-            dma16<true>(src, st + t * TEN + grp * 512);      // nt: every row is read once
+            ksr_dma16<true>(src, st + t * TEN + grp * 512);      // nt: every row is read once
         }
     }
 }
@@ -210,7 +180,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(AttnArgs a) {
     // the transfers at that barrier then finds no store of this wave in flight.
     long pend[2] = {-1, -1};
     auto body = [&](const __bf16* __restrict__ cur, __bf16* __restrict__ nxt, int pass, bool first) {
-        dma_barrier();                     // cur has landed (every wave waited for its own transfers); nxt is free
+        ksr_dma_barrier();                     // cur has landed (every wave waited for its own transfers); nxt is free
         if (pass + G < npass) issue_pass<3, FULL>(nxt, qkv, nullptr, pm, pass + G, wv, lane);
         if (!first) xp_to_rows<FULL>(xp, ctx, pend, 64, 32 * X, lane);
         const int p = pass * pm.PPT + pl;
@@ -307,7 +277,7 @@ __device__ __forceinline__ void issue_x(__bf16* __restrict__ st, const __bf16* _
         long n = pm.row<FULL>(pass, r);
         if (!FULL && n < 0) n = 0;
         const int c = cp ^ ((r >> 1) & 7);
-        dma16<false>(x + n * 64 + 8 * c, st + grp * 512);
+        ksr_dma16<false>(x + n * 64 + 8 * c, st + grp * 512);
     }
 }
 
@@ -361,9 +331,9 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
     auto body = [&](const __bf16* __restrict__ cur, __bf16* __restrict__ nxt, int pass, bool first, bool second) {
         // cur has landed; every wave is done with the previous pass's tile
         if (FULL && !first && !second) {
-            if (save_qkv) dma_barrier_but<8>(); else dma_barrier_but<2>();
+            if (save_qkv) ksr_dma_barrier_but<8>(); else ksr_dma_barrier_but<2>();
         } else {
-            dma_barrier();
+            ksr_dma_barrier();
         }
         if (pass + G < npass) issue_x<FULL>(nxt, a.x, pm, pass + G, wv, lane);
         if (!first) xp_to_rows<FULL>(xp, a.ctx, pend, 64, 32 * X, lane);
@@ -399,7 +369,7 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
                 }
             }
         }
-        lds_barrier();                     // the pass's q, k, v tile is complete
+        ksr_lds_barrier();                     // the pass's q, k, v tile is complete
         if (save_qkv) {
             // tile -> qkv rows: piece f of the tile in LDS order = (tensor, 8-row group, head, row & 7, chunk position)
 #pragma unroll
@@ -505,7 +475,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
     auto body = [&](const __bf16* __restrict__ cur, __bf16* __restrict__ nxt, int pass, bool first) {
         // cur has landed (its transfers were issued at the top of the previous pass; the 6 stores of that pass's results
         // are younger and may stay in flight); every wave is done with the previous pass: nxt (its stage) is free
-        if (FULL && !first) dma_barrier_but<6>(); else dma_barrier();
+        if (FULL && !first) ksr_dma_barrier_but<6>(); else ksr_dma_barrier();
         if (pass + G < npass) issue_pass<4, FULL>(nxt, qkv, dctx, pm, pass + G, wv, lane);
         const int p = pass * pm.PPT + pl;
         const bool live = FULL || ((b < S) && (p < HW));
@@ -580,7 +550,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
             tile_to_xp(xp, lane, dq, 1.f);
         }
         __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();                     // the statistics are visible
+        ksr_lds_barrier();                     // the statistics are visible
         xp_to_rows<FULL>(xp, dqkv, nrow, 192, 32 * X, lane);
         // ---------------- phase B: this lane is a key ----------------
         {

@@ -176,6 +176,36 @@ __device__ __forceinline__ bool ksr_attn_keep(unsigned base, int key_b, float ke
     return half < ksr_attn_keep_threshold(keep);
 }
 
+// One LDS-DMA instruction: lane l moves 16 bytes from its own global address to lds_wave_base + 16 l.  Issued from inline
+// assembly (M0 saved and restored around it): the compiler then keeps no record of transfers in flight, where it would
+// otherwise make every read of an LDS array that no transfer ever targets (statistics, transposer tiles) wait for ALL of
+// them.  Every wait for such a transfer is therefore explicit (ksr_dma_barrier, ksr_dma_barrier_but).
+template <bool NT>
+__device__ __forceinline__ void ksr_dma16(const void* gsrc, void* lds_wave_base) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    unsigned keep_m0;
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_m0) : "s"(base), "v"(gsrc) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep_m0) : "s"(base), "v"(gsrc) : "memory");
+}
+
+// every wave's LDS writes are complete and visible, every wave has arrived
+__device__ __forceinline__ void ksr_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// as ksr_lds_barrier, and this wave's transfers (and stores) have completed before it arrives
+__device__ __forceinline__ void ksr_dma_barrier() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// as ksr_dma_barrier, but the wave's YOUNGEST vector-memory instructions may still be in flight: vmcnt counts loads and
+// stores of a wave in issue order on this target (the compiler itself waits for a load past younger stores with
+// vmcnt(n > 0)), so "at most YOUNGER outstanding" means every transfer issued before them has landed.  Only usable
+// where the number of instructions issued after the transfers is exact (no store skipped by a branch).
+template <int YOUNGER>
+__device__ __forceinline__ void ksr_dma_barrier_but() {
+    static_assert(YOUNGER >= 0 && YOUNGER < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(YOUNGER) : "memory");
+}
+
 // Stores of tensors that are read again only much later (the backward's saved tensors): non-temporal, so that they do not
 // displace what the next kernels are about to read.  Measured on the in-projection + attention forward: 403 MB of saved
 // q, k, v cost 70 us as plain stores and 31 us non-temporal.

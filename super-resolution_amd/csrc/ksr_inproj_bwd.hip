@@ -4,13 +4,13 @@
 //     dW[j][k]  = sum_n dqkv[n][j] x[n][k],   db[j] = sum_n dqkv[n][j]
 // The data gradient and the weight gradient both consume dqkv [N,192], the widest tensor of the transformer backward;
 // as two kernels (ksr_in_proj_bwd, ksr_wgrad) it is read twice.  Here a workgroup walks its pixel range in chunks of 32
-// pixels whose rows [dqkv 192 | x 64 | resid 64] are copied global -> LDS by 16-byte LDS-DMA loads (double buffered,
+// pixels whose rows [dqkv 192 | x 64 | resid 64] are copied global -> LDS by 16-byte LDS-DMA loads (three stages,
 // non-temporal), and both products read their operands from that one staged copy:
 //   * the weight gradient contracts over pixels: operands are read with the transposing ds_read_b64_tr_b16 (8 pixels
 //     of one channel per lane); the 6 x 2 accumulator blocks are split over the four waves (3 each);
 //   * the data gradient contracts over the 192 channels: a lane's operand is 8 consecutive channels of its pixel, one
 //     16-byte LDS read (rows are padded by one 16-byte piece, so the 32 rows a wave reads fall into different banks);
-//     W^T sits in LDS in MFMA fragment order; waves 0 and 1 each produce 32 of the 64 output channels.
+//     W^T sits in registers in MFMA fragment order; waves 0 and 1 each produce 32 of the 64 output channels.
 // Partial weight gradients go to one slab row per workgroup and are summed in a fixed order (deterministic).
 #include "ksr_gemm.h"
 #include "ksr_wg_fuse.h"
@@ -34,49 +34,66 @@ struct InProjArgs {
     long N;
 };
 
-struct __attribute__((aligned(16))) InProjSmem {
-    __bf16 rows[2][IP_T * IP_RLP];                // double-buffered staged chunks
-    __bf16 wfrag[2 * 12 * 64 * 8];                // W^T in fragment order: [out block][k step][lane][8]
-};
+constexpr int IP_NVEC = IP_T * IP_RL4;            // 16-byte pieces per staged chunk (1312)
+constexpr int IP_NFULL = IP_NVEC / 256;           // transfer instructions every wave issues per chunk (5)
+constexpr int IP_STAGE = (IP_NFULL + 1) * 256 * 8;   // elements per stage: the sixth, partial instruction of wave 0 writes a whole KB
+constexpr int IP_STAGES = 3;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+// Three stages of 32 pixels, two chunks in flight per workgroup: with two (one in flight, 21 KB) the kernel ran at
+// chunk size x workgroups per CU / memory latency = 4.3 TB/s.  The transfers are issued from inline assembly and waited
+// for with counted vmcnt (ksr_dma_barrier_but): a wave may keep its youngest transfers and stores in flight.  Per chunk
+// every wave issues IP_NFULL transfer instructions, wave 0 one more (the last 32 pieces; its upper lanes fetch a valid
+// address into the stage's padding), waves 0 and 1 four 8-byte stores of the data gradient.
 template <bool SIGGRAD>
 __global__ void __launch_bounds__(256, 2) inproj_bwd_fused_kernel(InProjArgs a) {
-    __shared__ InProjSmem sm;
+    __shared__ __attribute__((aligned(16))) __bf16 stage[IP_STAGES * IP_STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int col = lane & 31, kk = lane >> 5;
 
-    // W^T fragments: element i of lane (row = col, half kk) in step s of out block ob = W[16 s + 8 kk + i][32 ob + col]
-    for (int idx = tid; idx < 2 * 12 * 64 * 8; idx += 256) {
-        const int i = idx & 7, ln = (idx >> 3) & 63, rest = idx >> 9;
-        const int s = rest % 12, ob = rest / 12;
-        sm.wfrag[idx] = (__bf16)a.w[(16 * s + 8 * (ln >> 5) + i) * 64 + 32 * ob + (ln & 31)];
+    // data gradient (waves 0, 1): W^T fragments of the wave's 32 output channels stay in registers (48):
+    // element i of step s = W[16 s + 8 kk + i][32 wv + col]
+    bf16x8 wreg[12];
+    if (wv < 2) {
+#pragma unroll
+        for (int s12 = 0; s12 < 12; ++s12)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) wreg[s12][i] = (__bf16)a.w[(16 * s12 + 8 * kk + i) * 64 + 32 * wv + col];
     }
 
     const long per = (((a.N + gridDim.x - 1) / gridDim.x) + IP_T - 1) / IP_T * IP_T;
     const long n0 = (long)blockIdx.x * per;
     const long n1 = (n0 + per < a.N) ? n0 + per : a.N;
     const int nchunks = n1 > n0 ? (int)((n1 - n0 + IP_T - 1) / IP_T) : 0;
-    constexpr int NVEC = IP_T * IP_RL4, NPASS = (NVEC + 255) / 256;
 
-    auto issue = [&](int c) {
-        __bf16* dstbuf = sm.rows[c & 1];
-        const long t0 = n0 + (long)c * IP_T;
+    // piece f = i * 256 + tid of a chunk: staged row f / 41, piece f % 41 of [dqkv 24 | x 8 | resid 8 | padding 1]
+    const __bf16* src[IP_NFULL + 1];
+    int trow[IP_NFULL + 1], ldr[IP_NFULL + 1];
 #pragma unroll
-        for (int i = 0; i < NPASS; ++i) {
-            const int f = i * 256 + tid;
-            if (f >= NVEC) break;                       // ragged last pass: the remaining lanes stage nothing
-            const int trow = f / IP_RL4, piece = f - trow * IP_RL4;
-            long tokn = t0 + trow;
-            if (tokn >= n1) tokn = n1 - 1;              // rows past the range repeat its last row (masked later)
-            const __bf16* src = a.dqkv + tokn * IP_J + 8 * (piece < 24 ? piece : 0);      // also the padding piece
-            if (piece >= 24 && piece < 32) src = a.xin + tokn * IP_K + 8 * (piece - 24);
-            if (piece >= 32 && piece < 40) src = a.resid + tokn * IP_K + 8 * (piece - 32);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                             (__attribute__((address_space(3))) void*)(dstbuf + (i * 256 + wv * 64) * 8),
-                                             16, 0, 2 /* nt: every row is read once */);
+    for (int i = 0; i <= IP_NFULL; ++i) {
+        int f = i * 256 + tid;
+        if (f >= IP_NVEC) f = IP_NVEC - 1;                // upper lanes of wave 0's sixth instruction
+        trow[i] = f / IP_RL4;
+        const int piece = f - trow[i] * IP_RL4;
+        const __bf16* base = a.dqkv + 8 * (piece < 24 ? piece : 0);      // also the padding piece
+        ldr[i] = IP_J;
+        if (piece >= 24 && piece < 32) { base = a.xin + 8 * (piece - 24); ldr[i] = IP_K; }
+        if (piece >= 32 && piece < 40) { base = a.resid + 8 * (piece - 32); ldr[i] = IP_K; }
+        src[i] = base + (n0 + trow[i]) * ldr[i];
+    }
+    auto issue = [&](int c) {
+        __bf16* dstbuf = stage + (c % IP_STAGES) * IP_STAGE;
+        const long t0 = n0 + (long)c * IP_T;
+        const bool ragged = t0 + IP_T > n1;               // wave-uniform: rows past the range repeat its last row (masked later)
+#pragma unroll
+        for (int i = 0; i <= IP_NFULL; ++i) {
+            if (i == IP_NFULL && wv != 0) break;          // wave-uniform
+            const __bf16* sp = src[i];
+            if (ragged && t0 + trow[i] >= n1) sp -= (t0 + trow[i] - (n1 - 1)) * (long)ldr[i];
+            ksr_dma16<true>(sp, dstbuf + (i * 256 + wv * 64) * 8);      // nt: every row is read once
+            src[i] += IP_T * ldr[i];
         }
     };
 
@@ -95,11 +112,22 @@ __global__ void __launch_bounds__(256, 2) inproj_bwd_fused_kernel(InProjArgs a) 
         return *reinterpret_cast<const uint2*>(&v);
     };
 
+    // Vector-memory instructions a wave issues after the transfers of chunk c and before it needs them: the stores of
+    // chunk c-2 (S), the transfers of chunk c+1 (D), the stores of chunk c-1 (S); fewer for the first two chunks; the
+    // last chunk of the range (no younger transfers, possibly skipped stores) waits for everything.
+    auto wait_chunk = [&](int c) {
+        if (c == nchunks - 1) { ksr_dma_barrier(); return; }
+        if (wv == 0) { if (c == 0) ksr_dma_barrier_but<6>(); else if (c == 1) ksr_dma_barrier_but<10>(); else ksr_dma_barrier_but<14>(); }
+        else if (wv == 1) { if (c == 0) ksr_dma_barrier_but<5>(); else if (c == 1) ksr_dma_barrier_but<9>(); else ksr_dma_barrier_but<13>(); }
+        else ksr_dma_barrier_but<5>();
+    };
+
     if (nchunks > 0) issue(0);
+    if (nchunks > 1) issue(1);
     for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();                 // chunk c has landed (and, for c = 0, the fragments are staged); buffer (c+1)&1 is free
-        if (c + 1 < nchunks) issue(c + 1);
-        const __bf16* buf = sm.rows[c & 1];
+        wait_chunk(c);                   // chunk c has landed for every wave; the stage of chunk c-1 (= of chunk c+2) is free
+        if (c + 2 < nchunks) issue(c + 2);
+        const __bf16* buf = stage + (c % IP_STAGES) * IP_STAGE;
         const long t0 = n0 + (long)c * IP_T;
         const int nvalid = (n1 - t0 < IP_T) ? (int)(n1 - t0) : IP_T;
 
@@ -143,11 +171,10 @@ __global__ void __launch_bounds__(256, 2) inproj_bwd_fused_kernel(InProjArgs a) 
             f32x16 d;
 #pragma unroll
             for (int q = 0; q < 16; ++q) d[q] = 0.f;
-            const bf16x8* wf = reinterpret_cast<const bf16x8*>(sm.wfrag) + (wv * 12) * 64 + lane;
             const __bf16* rowp = buf + col * IP_RLP + 8 * kk;
 #pragma unroll
             for (int s = 0; s < 12; ++s)
-                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s * 64], *reinterpret_cast<const bf16x8*>(rowp + 16 * s), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[s], *reinterpret_cast<const bf16x8*>(rowp + 16 * s), d, 0, 0, 0);
             if (col < nvalid) {
                 __bf16* dst = a.ds + (t0 + col) * IP_K;
 #pragma unroll
