@@ -170,10 +170,13 @@ int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
     return KSR_OK;
 }
 
-template <int NB>
+template <int NB, bool COAL>
 struct __attribute__((aligned(16))) FeedBwdSmem {
     float frag[2 * (NB * 16) * 64];
     float knots[KSR_MAX_KNOTS];
+    // bf16 storage: per-wave tile through which the two outputs leave in lane-linear 16-byte pieces (a lane's own 160
+    // and 64 contiguous bytes, stored directly, make every store instruction touch 64 separate segments)
+    __bf16 tile[COAL ? 4 * 32 * (NB * 16 + 8 > 72 ? NB * 16 + 8 : 72) : 8];
 };
 
 // Backward: dparam[e] per lane (lane order), dfeat = dparam * W_feed, both stored; the feed weight
@@ -183,7 +186,10 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
     using C = FeedCfg<R, KC>;
     constexpr int NB = C::NB, KH = NB * 16;
     using ST = typename KsrStore<PREC>::T;
-    __shared__ FeedBwdSmem<NB> sm;
+    constexpr bool COAL = sizeof(ST) == 2;
+    constexpr int TLD = KH + 8;                       // tile pitch for the parameter gradients (16 bytes of padding)
+    constexpr int TILE = 32 * (TLD > 72 ? TLD : 72);  // elements per wave (the feature gradients use a pitch of 72)
+    __shared__ FeedBwdSmem<NB, COAL> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
     ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.w, 64, nullptr, MapHL{32}, MapKan{C::O, KC}, tid, 256);
@@ -240,14 +246,52 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
                 dp[e] = 0.f;
             }
         }
-        if (live) ksr_storen<ST, KH>(a.gparam, (n * 2 + h) * KH, dp);
+        const long n0w = tile * 128 + wv * 32;            // the wave's 32 consecutive pixels
+        __bf16* tl = sm.tile + (COAL ? wv * TILE : 0);
+        if constexpr (COAL) {
+            // rows of gparam are [half 0: KH | half 1: KH] per pixel: one lane half at a time through the tile
+            static_assert(KH % 8 == 0, "16-byte pieces");
+            constexpr int PCS = KH / 8, TOTAL = 32 * PCS;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                ksr_wave_fence();
+                if (h == hh) {
+#pragma unroll
+                    for (int q = 0; q < PCS; ++q) *reinterpret_cast<uint4*>(tl + tok * TLD + 8 * q) = ksr_pack8(dp + 8 * q);
+                }
+                ksr_wave_fence();
+#pragma unroll
+                for (int i = 0; i < (TOTAL + 63) / 64; ++i) {
+                    const int idx = i * 64 + lane, row = idx / PCS, pc = idx - row * PCS;
+                    if (idx < TOTAL && n0w + row < N)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.gparam) + ((n0w + row) * 2 + hh) * KH + 8 * pc) =
+                            *reinterpret_cast<const uint4*>(tl + row * TLD + 8 * pc);
+                }
+            }
+        } else {
+            if (live) ksr_storen<ST, KH>(a.gparam, (n * 2 + h) * KH, dp);
+        }
         f32x16 acc[2];
         ksr_wave_gemm<PREC, KH, 2>(sm.frag, nullptr, dp, acc, lane);
-        if (live) {
-            float df[32];
+        float df[32];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { df[i] = acc[0][i]; df[16 + i] = acc[1][i]; }
-            ksr_storen<ST, 32>(a.gfeat, n * 64 + 32 * h, df);
+        for (int i = 0; i < 16; ++i) { df[i] = acc[0][i]; df[16 + i] = acc[1][i]; }
+        if constexpr (COAL) {
+            constexpr int FLD = 72;                       // 64 channels + 16 bytes of padding
+            static_assert(32 * FLD <= TILE, "the feature-gradient tile fits");
+            ksr_wave_fence();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(tl + tok * FLD + 32 * h + 8 * q) = ksr_pack8(df + 8 * q);
+            ksr_wave_fence();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = i * 64 + lane, row = idx >> 3, pc = idx & 7;
+                if (n0w + row < N)
+                    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.gfeat) + (n0w + row) * 64 + 8 * pc) =
+                        *reinterpret_cast<const uint4*>(tl + row * FLD + 8 * pc);
+            }
+        } else {
+            if (live) ksr_storen<ST, 32>(a.gfeat, n * 64 + 32 * h, df);
         }
     }
 }
