@@ -285,6 +285,210 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     }
 }
 
+// fn_1 backward of the first gated block without the matrix product.  The block's input is x1[n][k] = p2w[k] v[n] +
+// p2b[k] (one scalar per pixel), so everything its backward must deliver is a function of dt [N,128] alone:
+//     dpre[n]              = (v[n] > 0) * sum_c dt[n][c] * wt[c],   wt[c] = sum_k W[c][k] p2w[k]
+//     sum_n dx[n][k] * v[n] = sum_c W[c][k] * (sum_n dt[n][c] v[n]),  likewise sum_n dx[n][k]
+// (dx = dt * W is never formed).  dt's value half is read, its gate half is the transposed depthwise 3x3 of dgate times
+// the sign of t's gate half, rebuilt from v (t = relu(A v + B)).  Every lane keeps the four running column sums of its
+// own pixel's 32 channels over all tiles of the workgroup (128 registers); they cross lanes once, at the end.
+struct StemBwdArgs {
+    const void* dt; const void* dgate;          // [N,128] (channels 0..63 read), [N,64]
+    const float* dw_w;                          // [64][9] gate weights
+    const float* v; const float* ab;            // [N]; A|B [256]
+    const float* fn1_w; const float* p2w;       // [128][64]; [64]
+    float* dpre;                                // [N]
+    float* sums_slab;                           // [3][gridDim.x][2][64]
+    int B, H, W;
+};
+
+struct __attribute__((aligned(16))) StemBwdSmem {
+    float dww[9 * 64];
+    float affA[64], affB[64];
+    float wt[128];
+    float halo[HALO_FLOATS];
+};
+
+template <class ST>
+__global__ void __launch_bounds__(256, 2) fn1_stem_bwd_kernel(StemBwdArgs a) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    __shared__ StemBwdSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_dw<true>(sm.dww, a.dw_w, tid);
+    if (tid < 64) { sm.affA[tid] = a.ab[64 + tid]; sm.affB[tid] = a.ab[192 + tid]; }
+    if (tid >= 128) {
+        const int c = tid - 128;
+        float s = 0.f;
+        for (int k = 0; k < 64; ++k) s = fmaf(a.fn1_w[c * 64 + k], a.p2w[k], s);
+        sm.wt[c] = s;
+    }
+    __syncthreads();
+
+    const int HW = a.H * a.W;
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
+    const long ntiles = (long)a.B * tiles_y * tiles_x;
+    KsrHalo<ST> hr;
+    auto fetch_halo = [&](long t) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const int tb = (int)(t / ((long)tiles_x * tiles_y));
+        ksr_halo_fetch<ST>(a.dgate, 64, 0, tb, ty * 4, tx * 32, a.H, a.W, tid, hr);
+    };
+    if ((long)blockIdx.x < ntiles) fetch_halo(blockIdx.x);
+
+    // Column sums over tokens on the matrix cores (the scheme of ksr_wg_fuse.h): the wave's 32 x 64 tile of d goes to
+    // LDS as swizzled bf16 rows and comes back transposed as the A operand (channels x tokens); the B operand's columns
+    // 0, 1, 2 hold, per token, the upper and the lower bf16 half of v and 1.  accV / accG [block of 32 channels]: lane
+    // column (lane & 31) = 0, 1: sum d v (upper, lower part), 2: sum d, for 16 channels each.
+    f32x16 accV[2], accG[2];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { accV[0][q] = 0.f; accV[1][q] = 0.f; accG[0][q] = 0.f; accG[1][q] = 0.f; }
+    const int g5 = lane >> 5, db = (lane >> 4) & 1, qq = (lane & 15) >> 2, p4 = lane & 3;
+    auto tr = [&](const __bf16* tile, int row, int chunk) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(tile + ksr_wgf_off(row, chunk) + 4 * (p4 & 1)));
+    };
+    union Op { s16x4 hv[2]; bf16x8 v; };
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const int b = (int)(tile / ((long)tiles_x * tiles_y));
+        const int y0 = ty * 4, x0 = tx * 32;
+        const int y = y0 + wv, x = x0 + tok;
+        const bool live = (y < a.H) && (x < a.W);
+        const long n = live ? (long)b * HW + (long)y * a.W + x : 0;
+        const long n0w = (long)b * HW + (long)y * a.W + x0;
+        const int nvalid = (y < a.H) ? ((a.W - x0) < 32 ? a.W - x0 : 32) : 0;
+        __syncthreads();
+        ksr_halo_commit<ST>(sm.halo, tid, hr);
+        __syncthreads();
+        if (tile + gridDim.x < ntiles) fetch_halo(tile + gridDim.x);     // in flight during this tile
+        // this tile's value half and scalar: requested before the stencil, which covers their latency
+        KsrTile<ST> tv;
+        ksr_co_fetch<ST>(a.dt, n0w, nvalid, 128, 0, lane, tv);
+        const float vv = live ? a.v[n] : 0.f;
+
+        float g[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) g[i] = 0.f;
+        ksr_dwconv_lane(sm.halo, sm.dww, wv, tok, h, g);
+        __syncthreads();       // every wave is done with the halo tile: its first part now holds the waves' bf16 tiles
+        __bf16* tz = reinterpret_cast<__bf16*>(sm.halo + wv * KSR_XPOSE_FLOATS);
+        __bf16* ta = tz + 32 * 64;
+        // value half: the fetched pieces go to the swizzled tile as they are (bf16 storage) or rounded (fp32 storage)
+        if constexpr (sizeof(ST) == 2) {
+            const int r8 = lane >> 3, c8 = lane & 7;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(tz + ksr_wgf_off(8 * i + r8, c8)) = tv.v[i];
+        } else {
+            const int r4 = lane >> 4, c4 = lane & 15;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float x4[4] = {tv.v[i].x, tv.v[i].y, tv.v[i].z, tv.v[i].w};
+                bf16x8 pk;      // only the first four are stored
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pk[j] = (__bf16)x4[j];
+                *reinterpret_cast<uint2*>(tz + ksr_wgf_off(4 * i + r4, c4 >> 1) + 4 * (c4 & 1)) = *reinterpret_cast<const uint2*>(&pk);
+            }
+        }
+        if (h == 0) {
+            const float hi = __uint_as_float(__float_as_uint(vv) & 0xffff0000u);
+            const float x8[8] = {hi, vv - hi, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<uint4*>(ta + ksr_wgf_off(tok, 0)) = ksr_pack8(x8);
+        }
+        ksr_wave_fence();
+        Op Bv[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int r0 = 16 * s + 4 * g5 + qq;
+            const int chunk = 2 * db + (p4 >> 1);
+            Bv[s].hv[0] = tr(ta, r0, chunk); Bv[s].hv[1] = tr(ta, r0 + 8, chunk);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                Op A;
+                A.hv[0] = tr(tz, r0, 4 * blk + chunk); A.hv[1] = tr(tz, r0 + 8, 4 * blk + chunk);
+                accV[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, Bv[s].v, accV[blk], 0, 0, 0);
+            }
+        }
+        // this lane's 32 value-half channels, for the per-pixel product
+        float s = 0.f;
+        {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float x8[8];
+                ksr_unpack8(*reinterpret_cast<const uint4*>(tz + ksr_wgf_off(tok, 4 * h + q)), x8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s = fmaf(x8[j], sm.wt[32 * h + 8 * q + j], s);
+            }
+        }
+        // gate half: transposed depthwise conv of dgate, times the sign of t's gate half
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const float tg = fmaf(sm.affA[32 * h + i], vv, sm.affB[32 * h + i]);
+            g[i] = (live && tg > 0.f) ? g[i] : 0.f;          // t is 0 outside the image
+            s = fmaf(g[i], sm.wt[64 + 32 * h + i], s);
+        }
+        ksr_wave_fence();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint4*>(tz + ksr_wgf_off(tok, 4 * h + q)) = ksr_pack8(g + 8 * q);
+        ksr_wave_fence();
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int r0 = 16 * s2 + 4 * g5 + qq;
+            const int chunk = 2 * db + (p4 >> 1);
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                Op A;
+                A.hv[0] = tr(tz, r0, 4 * blk + chunk); A.hv[1] = tr(tz, r0 + 8, 4 * blk + chunk);
+                accG[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, Bv[s2].v, accG[blk], 0, 0, 0);
+            }
+        }
+        s = ksr_pair_sum(s);
+        if (live && h == 0) a.dpre[n] = vv > 0.f ? s : 0.f;
+    }
+
+    // the waves' sums meet in LDS: cols[wave][column 0..2][half l][channel c]
+    __syncthreads();
+    float* cols = sm.halo;                               // [4][3][128]
+    float* S = sm.halo + 4 * 3 * 128;                    // [256]: (half l, q, c) at 128 l + 64 q + c
+    float* part = S + 256;                               // [256]
+    {
+        const int col = lane & 31;
+        if (col < 3) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    const int c = 32 * blk + (q & 3) + 8 * (q >> 2) + 4 * g5;
+                    cols[(wv * 3 + col) * 128 + c] = accV[blk][q];
+                    cols[(wv * 3 + col) * 128 + 64 + c] = accG[blk][q];
+                }
+        }
+    }
+    __syncthreads();
+    {
+        const int l = tid >> 7, q = (tid >> 6) & 1, c = tid & 63;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* cw = cols + w * 3 * 128 + 64 * l + c;
+            t += q == 0 ? cw[0] + cw[128] : cw[256];
+        }
+        S[tid] = t;
+        a.sums_slab[((long)l * gridDim.x + blockIdx.x) * 128 + (tid & 127)] = t;
+    }
+    __syncthreads();
+    {   // this workgroup's share of sum_n dx[n][k] * v[n] (q = 0) and sum_n dx[n][k] (q = 1)
+        const int k = tid & 63, q = (tid >> 6) & 1, l = tid >> 7;
+        float p = 0.f;
+        for (int c = 0; c < 64; ++c) p = fmaf(a.fn1_w[(64 * l + c) * 64 + k], S[128 * l + 64 * q + c], p);
+        part[tid] = p;
+    }
+    __syncthreads();
+    if (tid < 128) a.sums_slab[((long)2 * gridDim.x + blockIdx.x) * 128 + tid] = part[tid] + part[tid + 128];
+}
+static_assert(4 * KSR_XPOSE_FLOATS + 512 <= HALO_FLOATS, "the final sums must fit in the halo tile");
+
 // out[l][q * stride[l] + c] = sum over workgroups of slab[l][g][q][c]  (l < 3, q < 2, c < 64), fixed order
 struct ColRedArgs { const float* slab; int G; float* out[3]; int stride[3]; };
 __global__ void __launch_bounds__(1024) colsum_reduce_kernel(ColRedArgs a) {
@@ -503,11 +707,22 @@ extern "C" int ksr_fn1_bwd_stem_v(float* dt, const float* dgate, const float* ga
     KSR_CHECK_ARG(dt && dgate && gate_w && v_saved && ab && fn1_w && pw2_w && dpre && sums_slab && dt_sums && dx_sums &&
                   dx_row_stride >= 64, "fn1_bwd_stem_v: bad argument");
     if (int rc = dims_ok(B, H, W, "fn1_bwd_stem_v")) return rc;
-    BwdArgs a{};
-    a.dz = dt; a.dz_ld = 128; a.halo_src = dgate; a.dw_w = gate_w; a.aff_v = v_saved; a.aff_ab = ab;
-    a.wt = fn1_w; a.B = B; a.H = H; a.W = W; a.v = v_saved; a.p2w = pw2_w; a.dpre = dpre; a.sums_slab = sums_slab;
-    if (int rc = launch_dgrad<128, BPRO_CONVT_G, BEPI_STEM, true>(a, stream)) return rc;
-    ColRedArgs r{sums_slab, (int)dgrad_grid(a, true), {dt_sums, dt_sums + 64, dx_sums}, {128, 128, dx_row_stride}};
+    const long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
+    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
+    if (ksr_prec() == KSR_BF16S) {
+        // bf16 storage: no matrix product, column sums on the matrix cores from bf16 tiles
+        StemBwdArgs a{dt, dgate, gate_w, v_saved, ab, fn1_w, pw2_w, dpre, sums_slab, B, H, W};
+        hipLaunchKernelGGL(fn1_stem_bwd_kernel<__bf16>, dim3(grid), dim3(256), 0, stream, a);
+        KSR_LAUNCH_CHECK("fn1_bwd_stem_v");
+    } else {
+        BwdArgs a{};
+        a.dz = dt; a.dz_ld = 128; a.halo_src = dgate; a.dw_w = gate_w; a.aff_v = v_saved; a.aff_ab = ab;
+        a.wt = fn1_w; a.B = B; a.H = H; a.W = W; a.v = v_saved; a.p2w = pw2_w; a.dpre = dpre; a.sums_slab = sums_slab;
+        const int rc = ksr_prec() == KSR_BF16 ? launch_dgrad_p<KSR_BF16, 128, BPRO_CONVT_G, BEPI_STEM, true>(a, stream)
+                                              : launch_dgrad_p<KSR_F32, 128, BPRO_CONVT_G, BEPI_STEM, true>(a, stream);
+        if (rc) return rc;
+    }
+    ColRedArgs r{sums_slab, (int)grid, {dt_sums, dt_sums + 64, dx_sums}, {128, 128, dx_row_stride}};
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3(3, 4), dim3(1024), 0, stream, r);
     KSR_LAUNCH_CHECK("fn1_bwd_stem_v(column sums)");
     return KSR_OK;

@@ -610,6 +610,56 @@ def test_backward_kernels_that_rebuild_t_from_v_equal_the_tensor_reading_ones(B,
         assert rel_l2(b, a) <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 9, 11), (1, 37, 70), (3, 8, 64), (5, 64, 96)])
+def test_stem_fn1_backward_bf16_storage_vs_fp64(B, H, W):
+    """ksr_fn1_bwd_stem_v in bf16 storage (no matrix product: dpre and the sums of dx follow from dt alone; column sums on
+    the matrix cores from bf16 tiles) against an fp64 evaluation on the same bf16 inputs.  dpre is exact fp32 arithmetic;
+    the sums see the gate half of dt rounded to bf16."""
+    import torch.nn.functional as F
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(B * 100 + H)
+    L = lib()
+    N = B * H * W
+    dev = "cuda"
+    v = torch.rand(N, device=dev) * (torch.rand(N, device=dev) > 0.2)
+    ab = torch.randn(256, device=dev) * 0.5
+    dt = torch.zeros(N, 128, device=dev, dtype=torch.bfloat16)
+    dt[:, :64] = torch.randn(N, 64, device=dev)
+    dg = torch.randn(N, 64, device=dev).bfloat16()
+    gw, w1, p2w = (torch.randn(*s, device=dev) * 0.1 for s in ((64, 9), (128, 64), (64,)))
+    sums = torch.empty(3 * 512 * 128, device=dev)
+    engine.set_precision("bf16s")
+    try:
+        res = []
+        for _ in range(2):
+            dpre, rc, r2 = torch.full((N,), 7.0, device=dev), torch.empty(2, 128, device=dev), torch.empty(2, 64, device=dev)
+            check(L.ksr_fn1_bwd_stem_v(ptr(dt), ptr(dg), ptr(gw), ptr(v), ptr(ab), ptr(w1), ptr(p2w), ptr(dpre), ptr(sums), ptr(rc),
+                                       ptr(r2), c_int(64), c_int(B), c_int(H), c_int(W), stream()), "fn1_bwd_stem_v")
+            res.append((dpre, rc, r2))
+    finally:
+        engine.set_precision("fp32")
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)                                     # fixed summation order
+    dpre, rc, r2 = res[0]
+    vd = v.double()
+    dgn = dg.double().view(B, H, W, 64).permute(0, 3, 1, 2)
+    dtg = F.conv_transpose2d(dgn, gw.double().view(64, 1, 3, 3), padding=1, groups=64).permute(0, 2, 3, 1).reshape(N, 64)
+    tg = vd[:, None] * ab[None, 64:128].double() + ab[None, 192:].double()
+    # the kernel forms t's gate half with one fp32 fma; pixels where that lands within round-off of 0 are left out of dpre
+    tg32 = torch.addcmul(ab[None, 192:], v[:, None], ab[None, 64:128])
+    dtf = torch.cat([dt[:, :64].double(), dtg * (tg > 0)], 1)
+    dx = dtf @ w1.double()
+    ref_dpre = (dx @ p2w.double()) * (vd > 0)
+    sure = ((tg32.abs() > 1e-6).all(1)).cpu()
+    assert sure.float().mean() > 0.99
+    assert rel_l2(dpre.cpu()[sure], ref_dpre.cpu()[sure]) <= 2e-5
+    ref_rc = torch.stack([(dtf * vd[:, None]).sum(0), dtf.sum(0)])
+    ref_r2 = torch.stack([(dx * vd[:, None]).sum(0), dx.sum(0)])
+    assert rel_l2(rc.cpu(), ref_rc.cpu()) <= 2e-3
+    assert rel_l2(r2.cpu(), ref_r2.cpu()) <= 2e-3
+
+
 @pytest.mark.parametrize("S,HW,p_drop,save", [(64, 1100, 0.1, True), (64, 130, 0.0, False), (32, 1301, 0.1, True), (12, 2101, 0.1, True),
                                               (48, 64, 0.0, True), (5, 40, 0.1, True), (8, 4100, 0.1, True), (2, 40, 0.1, True), (100, 9, 0.0, True)])
 def test_fused_in_projection_attention_equals_the_two_kernels(S, HW, p_drop, save):
