@@ -55,7 +55,11 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         # ffn1 + ffn2 + ffn3.pointwise1 from the Y plane: writes t [N,128], gate, x3, t3 [N,64] and v [N]
         "ksr_stem_gate_fwd": ("hbm", 2 * 2 * 64 * 64 + 2 * 9 * 64 * 3 + 400, 4 + 4 + (0 if fused else 512) + 3 * 256, pk),
         "ksr_gate_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64 + 64, 512 + 256 + 256, pk),            # ffn4's tail
-        "ksr_pointwise_fwd": ("hbm", 2 * 64 * 128 + 2 * 2 * 64 * 192, (256 + 512) + 2 * (256 + 768), pk),
+        # ffn4.fn_1 (64 -> 128); without bf16 storage also both layers' in-projections (64 -> 192)
+        "ksr_pointwise_fwd": (("hbm", 2 * 64 * 128, 256 + 512, pk) if fused else
+                              ("hbm", 2 * 64 * 128 + 2 * 2 * 64 * 192, (256 + 512) + 2 * (256 + 768), pk)),
+        # bf16 storage: in-projection inside the attention forward: x in, qkv (kept for the backward) and ctx out, both layers
+        "ksr_batch_qkv_attn_fwd": ("hbm", 2 * (2 * 64 * 192 + 256 * S), 2 * (256 + 768 + 256), pk),
         "ksr_dwrelu_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 256 + 256 + 256, pk),
         "ksr_batch_tx_layer_fwd": ("mfma", 2 * (2 * 64 * 192 + lin_post + 256 * S), 2 * 512, pk),
         # attention: the bf16-operand kernels are bound by memory and vector arithmetic (masks, exp, dropout hash), the
@@ -75,7 +79,7 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         "ksr_in_proj_bwd_wg": ("hbm", 2 * 2 * 2 * 192 * 64, 2 * (768 + 256 + 256 + 256), pk),
         # first gated block with t rebuilt from v: no [N,128] tensor is read
         "ksr_gate_pw_bwd_v": ("hbm", 2 * 2 * 64 * 64, 256 + 256 + 4 + 256 + 256, pk),
-        "ksr_fn1_bwd_stem_v": ("hbm", 2 * 128 * 64 + 2 * 9 * 64, 256 + 256 + 4 + 4, pk),
+        "ksr_fn1_bwd_stem_v": ("hbm", 2 * 9 * 64 + 6 * 128, 256 + 256 + 4 + 4, pk),        # no matrix product (dpre and the sums follow from dt)
         "ksr_dwconv_wgrad_v": ("hbm", 2 * 10 * 64, 256 + 4, pk),
         "ksr_gate_pw_bwd": ("hbm", 2 * 2 * 64 * 64, 2 * 1280, pk),
         "ksr_gate_pw_bwd_wg": ("hbm", 2 * 2 * 64 * 64, 1280, pk),                  # ffn4: + the fn_2 weight gradient, same bytes
@@ -91,10 +95,12 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         # reads the maps, pred, tgt, and updates gy
         "ksr_ssim_fwd": ("hbm", 0, 16 * (3 * 8 + 12), pk),
         "ksr_ssim_y_grad": ("hbm", 0, 16 * (12 + 8 + 8), pk),
+        # both terms' luma gradient in one pass: maps, pred, tgt in, gy out
+        "ksr_ssim_y_grad_l1": ("hbm", 0, 16 * (12 + 8 + 4), pk),
         "ksr_l1_y_loss": ("hbm", 0, 16 * 12, pk),
     }
     # activation bytes scale with the storage type; the image-side tensors of these entry points stay fp32
-    fixed = {"ksr_ssim_fwd": 16 * 36, "ksr_ssim_y_grad": 16 * 28, "ksr_l1_y_loss": 16 * 12, "ksr_stem_fwd": 8, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_feed_kan_bwd": 64 + 4 + 128, "ksr_bilinear_up": 8 + 8 * 16,
+    fixed = {"ksr_ssim_fwd": 16 * 36, "ksr_ssim_y_grad": 16 * 28, "ksr_ssim_y_grad_l1": 16 * 24, "ksr_l1_y_loss": 16 * 12, "ksr_stem_fwd": 8, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_feed_kan_bwd": 64 + 4 + 128, "ksr_bilinear_up": 8 + 8 * 16,
              "ksr_gate_pw_fwd": 256 if act_bytes != 4 else 0, "ksr_batch_tx_layer_post_fwd": 128 if act_bytes != 4 else 0,
              "ksr_stem_gate_fwd": 8, "ksr_gate_pw_bwd_v": 4, "ksr_fn1_bwd_stem_v": 8, "ksr_dwconv_wgrad_v": 4}
     out = {}
@@ -114,7 +120,8 @@ ENTRY_KERNEL = {
     "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<2, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<2, 4, 8, 3>",
     "ksr_gate_pw_fwd": "conv_fwd_kernel<2, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<2, 64, 0, 3, false, false>",
     "ksr_gate_pw_bwd_wg": "dgrad_kernel<2, 64, 0, 3, true, false>", "ksr_gate_pw_bwd_v": "dgrad_kernel<2, 64, 0, 3, true, true>",
-    "ksr_stem_gate_fwd": "stem_gate_fwd_kernel<2>", "ksr_ssim_fwd": "ssim_fwd_kernel",
+    "ksr_stem_gate_fwd": "stem_gate_fwd_kernel<2>", "ksr_ssim_fwd": "ssim_fwd_cols_kernel",
+    "ksr_batch_qkv_attn_fwd": "qkv_attn_fwd_dma_kernel<2, true, true>",
     "ksr_wgrad": "entry:ksr_wgrad",      # launch-weighted average over the wgrad_kernel instances + the slab reduction
 }
 

@@ -315,6 +315,14 @@ int ksr_ssim_fwd(const float* pred, int64_t pred_batch_stride, const float* tgt,
 int ksr_ssim_y_grad(const float* maps, const float* pred, int64_t pred_batch_stride, const float* tgt,
                     int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W, float scale,
                     ksr_stream_t stream);
+/* Both terms of the reference's loss gradient (src/ml/pipelines/default.py:79-81) in one pass over the luma planes:
+ * grad[b, y, x] = l1_grad_scale * sign(pred - tgt) / (B*H*W) + scale * d(SSIM sum)/d pred (written, not accumulated)
+ * and l1_out[0] = mean |pred[:, 0] - tgt[:, 0]|: ksr_l1_y_loss followed by ksr_ssim_y_grad without the second read of
+ * the planes.  l1_slab: ksr_ssim_l1_slab_floats(B, H, W) floats of workspace. */
+int64_t ksr_ssim_l1_slab_floats(int B, int H, int W);
+int ksr_ssim_y_grad_l1(const float* maps, const float* pred, int64_t pred_batch_stride, const float* tgt,
+                       int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W, float scale,
+                       float l1_grad_scale, float* l1_slab, float* l1_out, ksr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Colour pre/post-processing: the steps either side of the model in the reference's data path

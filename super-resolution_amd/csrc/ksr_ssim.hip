@@ -198,11 +198,18 @@ struct SsimGradArgs {
     float* grad; long grad_bs;           // accumulated into
     int B, H, W;
     float scale;
+    float l1_inv;                        // L1: gradient magnitude of the L1 term, gscale / (B H W)
+    float* l1_slab;                      // L1: [gridDim.x] partial sums of |pred - tgt|
 };
 
 // grad[x] += scale * clampmask(p[x]) * sum over windows u covering x of g(x - u) (A_u + 2 p_x B_u + t_x C_u)
+// L1: the luma L1 term rides along (the kernel reads both planes anyway): grad[x] = l1_inv * sign(p - t) + the above
+// (written, not accumulated) and the workgroup's sum of |p - t| goes to l1_slab.
+template <bool L1>
 __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin w) {
     __shared__ float ms[3][SS_IN][SS_IN + 1];
+    __shared__ float l1red[4];
+    float l1acc = 0.f;
     __shared__ float hs[3][SS_IN][SS_T + 1];
     const int Hi = a.H - 2 * SS_R, Wi = a.W - 2 * SS_R;
     const int tiles_x = (a.W + SS_T - 1) / SS_T;
@@ -290,12 +297,26 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin 
             const int y = py0 + r0 + o;
             if (y >= a.H || x >= a.W) continue;
             const long off = (long)y * a.W + x;
-            const float p = a.pred[(long)b * a.pred_bs + off], tg = clamp01(a.tgt[(long)b * a.tgt_bs + off]);
+            const float p = a.pred[(long)b * a.pred_bs + off], traw = a.tgt[(long)b * a.tgt_bs + off], tg = clamp01(traw);
             const float inside = (p >= 0.f && p <= 1.f) ? 1.f : 0.f;
-            a.grad[(long)b * a.grad_bs + off] += a.scale * inside * (sa[o][0] + 2.f * clamp01(p) * sa[o][1] + tg * sc[o]);
+            const float gs = a.scale * inside * (sa[o][0] + 2.f * clamp01(p) * sa[o][1] + tg * sc[o]);
+            if constexpr (L1) {
+                const float d = p - traw;
+                l1acc += fabsf(d);
+                a.grad[(long)b * a.grad_bs + off] = (d > 0.f ? a.l1_inv : (d < 0.f ? -a.l1_inv : 0.f)) + gs;
+            } else {
+                a.grad[(long)b * a.grad_bs + off] += gs;
+            }
         }
     }
     }   // tiles
+    if constexpr (L1) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) l1acc += __shfl_xor(l1acc, off, 64);
+        if (lane == 0) l1red[wv] = l1acc;
+        __syncthreads();
+        if (threadIdx.x == 0) a.l1_slab[blockIdx.x] = (l1red[0] + l1red[1]) + (l1red[2] + l1red[3]);
+    }
 }
 
 int fill_window(SsimWin& w) {
@@ -349,10 +370,38 @@ extern "C" int ksr_ssim_y_grad(const float* maps, const float* pred, int64_t pre
     KSR_CHECK_ARG(H > 2 * SS_R && W > 2 * SS_R, "ssim_y_grad: the image must be larger than the 11 x 11 window");
     SsimWin w;
     fill_window(w);
-    SsimGradArgs a{maps, pred, (long)pred_batch_stride, tgt, (long)tgt_batch_stride, grad, (long)grad_batch_stride, B, H, W, scale};
+    SsimGradArgs a{maps, pred, (long)pred_batch_stride, tgt, (long)tgt_batch_stride, grad, (long)grad_batch_stride, B, H, W, scale,
+                   0.f, nullptr};
     const unsigned tiles = (unsigned)(((H + SS_T - 1) / SS_T) * ((W + SS_T - 1) / SS_T));
     KSR_CHECK_ARG((long)tiles * B < (1L << 31), "ssim_y_grad: too many tiles for one launch");
-    hipLaunchKernelGGL(ssim_grad_kernel, dim3(tiles * B), dim3(256), 0, stream, a, w);
+    hipLaunchKernelGGL(ssim_grad_kernel<false>, dim3(tiles * B), dim3(256), 0, stream, a, w);
     KSR_LAUNCH_CHECK("ssim_y_grad");
+    return KSR_OK;
+}
+
+extern "C" int64_t ksr_ssim_l1_slab_floats(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return (int64_t)((H + SS_T - 1) / SS_T) * ((W + SS_T - 1) / SS_T) * B;
+}
+
+// ksr_l1_y_loss and ksr_ssim_y_grad in one pass over the luma planes: grad[b, y, x] = l1_grad_scale * sign(pred - tgt) /
+// (B H W) + scale * dSSIM_sum/dpred (written, not accumulated), l1_out[0] = mean |pred - tgt|.
+// l1_slab: ksr_ssim_l1_slab_floats(B, H, W) floats of workspace.
+extern "C" int ksr_ssim_y_grad_l1(const float* maps, const float* pred, int64_t pred_batch_stride, const float* tgt,
+                                  int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W,
+                                  float scale, float l1_grad_scale, float* l1_slab, float* l1_out, hipStream_t stream) {
+    KSR_CHECK_ARG(maps && pred && tgt && grad && l1_slab && l1_out && B > 0, "ssim_y_grad_l1: bad argument");
+    KSR_CHECK_ARG(H > 2 * SS_R && W > 2 * SS_R, "ssim_y_grad_l1: the image must be larger than the 11 x 11 window");
+    SsimWin w;
+    fill_window(w);
+    const double numel = (double)B * H * W;
+    SsimGradArgs a{maps, pred, (long)pred_batch_stride, tgt, (long)tgt_batch_stride, grad, (long)grad_batch_stride, B, H, W, scale,
+                   (float)(l1_grad_scale / numel), l1_slab};
+    const unsigned tiles = (unsigned)(((H + SS_T - 1) / SS_T) * ((W + SS_T - 1) / SS_T));
+    KSR_CHECK_ARG((long)tiles * B < (1L << 31), "ssim_y_grad_l1: too many tiles for one launch");
+    hipLaunchKernelGGL(ssim_grad_kernel<true>, dim3(tiles * B), dim3(256), 0, stream, a, w);
+    KSR_LAUNCH_CHECK("ssim_y_grad_l1");
+    hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, l1_slab, (long)tiles * B, 1.0 / numel, l1_out);
+    KSR_LAUNCH_CHECK("ssim_y_grad_l1(finish)");
     return KSR_OK;
 }

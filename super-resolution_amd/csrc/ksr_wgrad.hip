@@ -621,35 +621,68 @@ struct StemgArgs {
     int B, H, W;
 };
 
+// Every one of the 12 sums is sum_m dpre[m] * f(m) with f a function of the 3x3 window of Y around m: the two sums over
+// du are re-indexed (n = m + tap): sum_n du[n] Y[n] = sum_m dpre[m] sum_tap wd[tap] Y(m + tap), m + tap inside the image.
+// A thread owns 4 neighbouring pixels of a row (VEC4: W % 4 == 0, 16-byte loads) or one pixel.
+template <bool VEC4>
 __global__ void __launch_bounds__(256) stemgrad_kernel(StemgArgs a) {
     __shared__ float red[12][4];
+    constexpr int PX = VEC4 ? 4 : 1;
     const long HW = (long)a.H * a.W;
     const long N = (long)a.B * HW;
     const float w1 = a.p1w[0], b1 = a.p1b[0];
+    float wd[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wd[t] = a.dww[t];
     float acc[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) acc[i] = 0.f;
-    for (long n = (long)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += (long)gridDim.x * blockDim.x) {
+    for (long n = ((long)blockIdx.x * blockDim.x + threadIdx.x) * PX; n < N; n += (long)gridDim.x * blockDim.x * PX) {
         const int b = (int)(n / HW);
         const int hw = (int)(n % HW);
         const int y = hw / a.W, x = hw % a.W;
         const float* Y = a.x_img + (long)b * a.img_bstride;
-        const float* dp = a.dpre + (long)b * HW;
-        const float d = dp[hw];
-        float du = 0.f;
+        float d[PX];
+        if constexpr (VEC4) {
+            const float4 t = *reinterpret_cast<const float4*>(a.dpre + n);
+            d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+        } else {
+            d[0] = a.dpre[n];
+        }
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int yy = y + dy;
+            const bool rowin = yy >= 0 && yy < a.H;
+            const float* Yr = Y + (long)(rowin ? yy : y) * a.W;
+            float win[PX + 2];      // Y(yy, x - 1 .. x + PX), 0 outside the image
+            bool in[PX + 2];
+            in[0] = rowin && x > 0;
+            win[0] = in[0] ? Yr[x - 1] : 0.f;
+            if constexpr (VEC4) {
+                const float4 t = *reinterpret_cast<const float4*>(Yr + x);
+                win[1] = rowin ? t.x : 0.f; win[2] = rowin ? t.y : 0.f; win[3] = rowin ? t.z : 0.f; win[4] = rowin ? t.w : 0.f;
+                in[1] = in[2] = in[3] = in[4] = rowin;
+            } else {
+                in[1] = rowin;
+                win[1] = rowin ? Yr[x] : 0.f;
+            }
+            in[PX + 1] = rowin && x + PX < a.W;
+            win[PX + 1] = in[PX + 1] ? Yr[x + PX] : 0.f;
 #pragma unroll
             for (int dx = -1; dx <= 1; ++dx) {
                 const int tap = (dy + 1) * 3 + (dx + 1);
-                const int yy = y + dy, xx = x + dx;
-                if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) acc[2 + tap] += d * (w1 * Y[(long)yy * a.W + xx] + b1);
-                const int ys = y - dy, xs = x - dx;
-                if (ys >= 0 && ys < a.H && xs >= 0 && xs < a.W) du += a.dww[tap] * dp[(long)ys * a.W + xs];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    const float yt = win[p + 1 + dx];
+                    const float one = in[p + 1 + dx] ? 1.f : 0.f;
+                    acc[2 + tap] += d[p] * fmaf(w1, yt, b1 * one);
+                    acc[0] += d[p] * (wd[tap] * yt);
+                    acc[1] += d[p] * (wd[tap] * one);
+                }
             }
-        acc[11] += d;
-        acc[0] += du * Y[hw];
-        acc[1] += du;
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) acc[11] += d[p];
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -890,9 +923,11 @@ extern "C" int ksr_stem_scalar_wgrad(const float* x_img, int64_t img_batch_strid
                   "stem_scalar_wgrad: bad argument");
     StemgArgs s{x_img, (long)img_batch_stride, dpre, pw1_w, pw1_b, dw_w, slab, B, H, W};
     const long N = (long)B * H * W;
-    long g = (N + 255) / 256;
+    const bool vec4 = W % 4 == 0 && img_batch_stride % 4 == 0 && ((uintptr_t)x_img & 15) == 0 && ((uintptr_t)dpre & 15) == 0;
+    long g = (N / (vec4 ? 4 : 1) + 255) / 256;
     if (g > 256) g = 256;
-    hipLaunchKernelGGL(stemgrad_kernel, dim3((unsigned)g), dim3(256), 0, stream, s);
+    if (vec4) hipLaunchKernelGGL(stemgrad_kernel<true>, dim3((unsigned)g), dim3(256), 0, stream, s);
+    else hipLaunchKernelGGL(stemgrad_kernel<false>, dim3((unsigned)g), dim3(256), 0, stream, s);
     KSR_LAUNCH_CHECK("stem_scalar_wgrad");
     return launch_reduce(slab, (int)g, 1, 12, 12, out12, 12, 1, nullptr, 0, 0, 0, stream);
 }

@@ -36,7 +36,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad", "_finalize", "_mix", "_merge", "_dgrad", "_batch", "_wg", "_v")):
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad", "_finalize", "_mix", "_merge", "_dgrad", "_batch", "_wg", "_v", "_l1")):
             return fn
 
         def timed(*args):
@@ -73,6 +73,7 @@ def _declare(L: ctypes.CDLL) -> None:
     L.ksr_last_error.restype = c_char_p
     L.ksr_gram_slab_floats.restype = c_int64
     L.ksr_ssim_slab_floats.restype = c_int64
+    L.ksr_ssim_l1_slab_floats.restype = c_int64
     L.ksr_unet_conv_partials.restype = c_int64
     L.ksr_unet_wgrad_slab_floats.restype = c_int64
     L.ksr_unet_bn_bwd_partials.restype = c_int64
@@ -97,7 +98,7 @@ EXPORTS = [
     "ksr_pointwise_bwd", "ksr_chan_dw_fwd", "ksr_chan_dw_bwd", "ksr_gram_slab_floats", "ksr_gram_batched",
     "ksr_chan_soft_fwd", "ksr_chan_soft_bwd", "ksr_sum_entries", "ksr_chan_apply",
     "ksr_rgb_to_ycbcr", "ksr_ycbcr_to_rgb", "ksr_bilinear_up_to_rgb",
-    "ksr_ssim_slab_floats", "ksr_ssim_fwd", "ksr_ssim_y_grad",
+    "ksr_ssim_slab_floats", "ksr_ssim_fwd", "ksr_ssim_y_grad", "ksr_ssim_l1_slab_floats", "ksr_ssim_y_grad_l1",
     "ksr_unet_conv_partials", "ksr_unet_conv_fwd", "ksr_unet_bn_finalize", "ksr_unet_bn_relu_fwd", "ksr_unet_convt_fwd",
     "ksr_unet_att_mix",
     "ksr_unet_wgrad_slab_floats", "ksr_unet_wgrad", "ksr_unet_bn_bwd_partials", "ksr_unet_bn_relu_bwd", "ksr_unet_grad_merge",

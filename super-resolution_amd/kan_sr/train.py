@@ -302,12 +302,7 @@ class TrainStep:
         # loss + dL/dY'
         plane = g.H * g.r * g.W * g.r
         gy = torch.empty(g.B, plane, device=x.device, dtype=torch.float32)
-        check(L.ksr_l1_y_loss(ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
-                              c_int64(plane), c_int(g.B), c_int64(plane), c_float(1.0), ptr(self.slab), ptr(self._l1),
-                              stream()), "ksr_l1_y_loss")
-        self.loss = self._l1
-        if self.loss_kind == "l1+ssim":
-            self._add_ssim_term(out, tgt, gy, g, plane)
+        self._loss_and_luma_gradient(out, tgt, gy, plane, (g.B, g.H * g.r, g.W * g.r), plane)
         main = torch.cuda.current_stream()
         overlap = overlap_comm and self.side is not None
 
@@ -372,24 +367,26 @@ class TrainStep:
             self._gfull = torch.empty_like(out)
         gfull = self._gfull
         outd = out.detach()
-        check(L.ksr_l1_y_loss(ptr(outd), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gfull),
-                              c_int64(3 * plane), c_int(B), c_int64(plane), c_float(1.0), ptr(self.slab), ptr(self._l1),
-                              stream()), "ksr_l1_y_loss")
-        self.loss = self._l1
-        if self.loss_kind == "l1+ssim":
-            self._add_ssim_term(outd, tgt, gfull, None, plane, dims=(B, Hh, Wh), gy_stride=3 * plane)
+        self._loss_and_luma_gradient(outd, tgt, gfull, plane, (B, Hh, Wh), 3 * plane)
         if getattr(m.layers[-1].encoder.encoder, "grad_sink", None) is None:
             self.flat_g.zero_()                   # autograd accumulates into the views
         out.backward(gfull)
         self.out = outd
 
-    def _add_ssim_term(self, out, tgt, gy, g, plane, dims=None, gy_stride=None):
-        """loss += 0.15 (1 - SSIM(out, tgt)); gy += the luma gradient of that term (gy rows gy_stride elements apart)."""
+    def _loss_and_luma_gradient(self, out, tgt, gy, plane, dims, gy_stride):
+        """self.loss = L1(Y) [+ 0.15 (1 - SSIM(out, tgt))] (src/ml/pipelines/default.py:79-81); gy [B, plane] (rows gy_stride
+        elements apart) = its gradient with respect to the luma plane of `out`."""
         L = lib()
-        B, Hh, Wh = dims if dims is not None else (g.B, g.H * g.r, g.W * g.r)
-        gy_stride = plane if gy_stride is None else gy_stride
+        B, Hh, Wh = dims
+        if self.loss_kind != "l1+ssim":
+            check(L.ksr_l1_y_loss(ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
+                                  c_int64(gy_stride), c_int(B), c_int64(plane), c_float(1.0), ptr(self.slab), ptr(self._l1),
+                                  stream()), "ksr_l1_y_loss")
+            self.loss = self._l1
+            return
         C = 3
-        nslab = int(L.ksr_ssim_slab_floats(c_int(C), c_int(B), c_int(Hh), c_int(Wh)))
+        nslab = max(int(L.ksr_ssim_slab_floats(c_int(C), c_int(B), c_int(Hh), c_int(Wh))),
+                    int(L.ksr_ssim_l1_slab_floats(c_int(B), c_int(Hh), c_int(Wh))))
         if getattr(self, "_ssim_ws", None) is None or self._ssim_ws[0].numel() < nslab or self._ssim_ws[1].numel() < 3 * B * (Hh - 10) * (Wh - 10):
             self._ssim_ws = (torch.empty(nslab, device=out.device), torch.empty(3 * B * (Hh - 10) * (Wh - 10), device=out.device),
                              torch.zeros(1, device=out.device))
@@ -397,8 +394,10 @@ class TrainStep:
         check(L.ksr_ssim_fwd(ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), c_int(C), c_int(B),
                              c_int(Hh), c_int(Wh), ptr(maps), ptr(slab), ptr(val), stream()), "ksr_ssim_fwd")
         scale = -0.15 / (B * C * (Hh - 10) * (Wh - 10))
-        check(L.ksr_ssim_y_grad(ptr(maps), ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
-                                c_int64(gy_stride), c_int(B), c_int(Hh), c_int(Wh), c_float(scale), stream()), "ksr_ssim_y_grad")
+        # both terms' gradient in one pass over the luma planes (the SSIM forward's finish kernel has consumed slab)
+        check(L.ksr_ssim_y_grad_l1(ptr(maps), ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
+                                   c_int64(gy_stride), c_int(B), c_int(Hh), c_int(Wh), c_float(scale), c_float(1.0), ptr(slab),
+                                   ptr(self._l1), stream()), "ksr_ssim_y_grad_l1")
         self.ssim = val
         self.loss = self._l1 + (1.0 - val) * 0.15           # one-element tensors
 

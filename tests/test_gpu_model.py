@@ -610,6 +610,28 @@ def test_backward_kernels_that_rebuild_t_from_v_equal_the_tensor_reading_ones(B,
         assert rel_l2(b, a) <= 1e-5
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 9, 11), (1, 37, 70), (3, 8, 64), (2, 1, 4), (1, 5, 1), (4, 128, 128)])
+def test_stem_scalar_parameter_gradients_vs_autograd(B, H, W):
+    """ksr_stem_scalar_wgrad (ffn1.pointwise1 1 -> 1 and ffn1.depthwise 3x3 on one channel, given dpre) against fp64
+    autograd of pre = bd + conv3x3(w1 Y + b1); widths that are and are not multiples of 4 (two kernel instances)."""
+    import torch.nn.functional as F
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(7 * B + H)
+    dev = "cuda"
+    x = torch.rand(B, 3, H, W, device=dev)
+    dpre = torch.randn(B * H * W, device=dev)
+    w1, b1, wd = torch.randn(1, device=dev), torch.randn(1, device=dev), torch.randn(9, device=dev)
+    slab, out12 = torch.empty(256 * 12, device=dev), torch.empty(12, device=dev)
+    check(lib().ksr_stem_scalar_wgrad(ptr(x), c_int64(3 * H * W), ptr(dpre), ptr(w1), ptr(b1), ptr(wd), ptr(slab), ptr(out12),
+                                      c_int(B), c_int(H), c_int(W), stream()), "ksr_stem_scalar_wgrad")
+    w1d, b1d, wdd, bdd = (t.double().clone().requires_grad_(True) for t in (w1, b1, wd, torch.zeros(1, device=dev)))
+    u = x[:, :1].double() * w1d + b1d
+    pre = F.conv2d(u, wdd.view(1, 1, 3, 3), bdd, padding=1)
+    pre.backward(dpre.double().view(B, 1, H, W))
+    ref = torch.cat([w1d.grad, b1d.grad, wdd.grad, bdd.grad])
+    assert (out12.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item() + 1e-5
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 9, 11), (1, 37, 70), (3, 8, 64), (5, 64, 96)])
 def test_stem_fn1_backward_bf16_storage_vs_fp64(B, H, W):
     """ksr_fn1_bwd_stem_v in bf16 storage (no matrix product: dpre and the sums of dx follow from dt alone; column sums on
