@@ -45,9 +45,10 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
     # bf16 storage: the fn_2 (ffn2, ffn4) and ffn3.pointwise2 weight gradients are accumulated inside their data-gradient
     # kernels (ksr_gate_pw_bwd_wg / _v, ksr_pw2_bwd_wg), the in-projection's in ksr_in_proj_bwd_wg: they leave ksr_wgrad
     fused = act_bytes == 2
-    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64 + 64 * 64) + 128 * 64 + 64 * 64 + (0 if fused else 3 * 64 * 64 + 2 * 192 * 64)
-    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64) + (64 + 64)) + (128 + 64) + (64 + 64)
-                    + (0 if fused else 2 * 64 * 3 + (64 + 64) + 2 * (192 + 64)))
+    # ... and out_proj's in ksr_batch_tx_layer_bwd_out_wg
+    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64) + 128 * 64 + 64 * 64 + (0 if fused else 2 * 64 * 64 + 3 * 64 * 64 + 2 * 192 * 64)
+    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64)) + (128 + 64) + (64 + 64)
+                    + (0 if fused else 2 * (64 + 64) + 2 * 64 * 3 + (64 + 64) + 2 * (192 + 64)))
     lin_post = 2 * (64 * 64 + 64 * 32 + 32 * 64)
     models = {
         # forward
@@ -65,12 +66,16 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         # attention: the bf16-operand kernels are bound by memory and vector arithmetic (masks, exp, dropout hash), the
         # matrix pipe is < 10 % busy: priced against HBM; the exact fp32 kernels against the fp32 MFMA peak
         "ksr_batch_attn_fwd": ("hbm" if bf16 else "mfma", 2 * 256 * S, 2 * (768 + 256), f32),
-        "ksr_batch_tx_layer_post_fwd": ("hbm", 2 * lin_post, 1664 + 1920, pk),
+        "ksr_batch_tx_layer_post_fwd": ("hbm", 2 * lin_post, 1664 + 1920 - (512 if fused else 0), pk),   # bf16 storage: LayerNorm 1's output is not kept
         "ksr_feed_kan_fwd": ("mfma" if not bf16 else "hbm", 2 * 64 * P + 400, 256 + 4 + 4 * 16, pk),
         "ksr_bilinear_up": ("hbm", 0, 8 + 8 * 16, pk),
         # backward
         "ksr_feed_kan_bwd": ("hbm", 2 * 64 * P + 800, 64 + 4 + 128 + 256 + 4 * P, pk),
-        "ksr_batch_tx_layer_bwd_token": ("hbm", 2 * lin_post, 2304 + 2304, pk),     # LayerNorm gain / shift sums are fused in
+        # LayerNorm gain / shift sums are fused in; bf16 storage: stops at du1 (dy, xhat2, hmid, xhat1, the last layer's
+        # xhatf in; dm, dpre, du1 out), the out-projection's backward and weight gradient follow in a kernel of their own
+        "ksr_batch_tx_layer_bwd_token": (("hbm", 2 * (lin_post - 64 * 64), 2048 + 1280, pk) if fused else
+                                         ("hbm", 2 * lin_post, 2048 + 2304, pk)),
+        "ksr_batch_tx_layer_bwd_out_wg": ("hbm", 2 * 2 * 2 * 64 * 64, 2 * 768, pk),
         # bf16 storage: the forward's output is not read (rowsum(dO * O) comes from the recomputed probabilities)
         "ksr_batch_attn_bwd": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + (0 if fused else 64) + 64 + 192), f32),
         "ksr_batch_tx_layer_bwd_attn": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
@@ -116,7 +121,7 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
 ENTRY_KERNEL = {
     "ksr_batch_attn_bwd": "attn_bwd_dma_kernel<2, true, true>", "ksr_batch_attn_fwd": "attn_fwd_dma_kernel<2, true, true>",
     "ksr_batch_tx_layer_bwd_token": "tx_bwd_token_kernel<2>", "ksr_batch_tx_layer_post_fwd": "tx_layer_fwd_kernel<2, true, 1>",
-    "ksr_in_proj_bwd_wg": "inproj_bwd_fused_kernel<false>",
+    "ksr_in_proj_bwd_wg": "inproj_bwd_fused_kernel<false>", "ksr_batch_tx_layer_bwd_out_wg": "tx_bwd_out_wg_kernel",
     "ksr_feed_kan_bwd": "feed_kan_bwd_kernel<2, 4, 8, 3>", "ksr_feed_kan_fwd": "feed_kan_fwd_kernel<2, 4, 8, 3>",
     "ksr_gate_pw_fwd": "conv_fwd_kernel<2, 3, 64, 2>", "ksr_gate_pw_bwd": "dgrad_kernel<2, 64, 0, 3, false, false>",
     "ksr_gate_pw_bwd_wg": "dgrad_kernel<2, 64, 0, 3, true, false>", "ksr_gate_pw_bwd_v": "dgrad_kernel<2, 64, 0, 3, true, true>",

@@ -296,6 +296,20 @@ int ksr_stem_scalar_wgrad(const float* x_img, int64_t img_batch_stride, const fl
  * ksr_pointwise_fwd without activation). */
 int ksr_pointwise_bwd(const float* dz, int n_out, const float* w, float* dx, int B, int H, int W, ksr_stream_t stream);
 
+/* bf16 storage mode: the out-projection's backward continued from du1 (the gradient that ksr_batch_tx_layer_bwd_token
+ * leaves when its dctx output is NULL): dctx [N,64] = mask(du1) * W_out, with the attention branch's dropout mask
+ * (gazetr.py:55-56 at p = 0.1) regenerated from seed, and dW [64][64] / db [64] of self_attn.out_proj from mask(du1)
+ * and the saved ctx in the same pass.  wg_slab: ksr_tx_bwd_wg_slab_floats() floats of workspace. */
+int64_t ksr_tx_bwd_wg_slab_floats(void);
+int ksr_batch_tx_layer_bwd_out_wg(const float* du1, const float* ctx, const float* out_w, float* dctx, int64_t N,
+                                  float p_drop, uint64_t seed, float* wg_slab, float* dW, float* db, ksr_stream_t stream);
+
+/* Weight gradient of a linear map fed by a LayerNorm output s = xhat * gain + shift (linear1 after norm1,
+ * gazetr.py:56-58) when the product was taken with xhat instead of s, which then need not be kept for the backward:
+ * dW[j][k] <- dW[j][k] * gain[k] + db[j] * shift[k], in place. */
+int ksr_wgrad_affine_input(float* dW, const float* db, const float* gain, const float* shift, int J, int K,
+                           ksr_stream_t stream);
+
 /* out[j][k] = r[j]*u[k] + c[j]*w[k] (weight gradient of ffn2.fn_1, whose input is u*v+w with one scalar v
  * per pixel); c_copy (optional) receives c, the bias gradient. */
 int ksr_outer2(float* out, const float* r, const float* u, const float* c, const float* w, int J, int K,

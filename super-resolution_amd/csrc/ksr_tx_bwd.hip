@@ -6,6 +6,7 @@
 //   tx_bwd_attn_kernel  : softmax-attention backward over the S images of a pixel: d(q|k|v).
 // The QKV projection's data gradient (+ residual) is ksr_in_proj_bwd (ksr_bwd.hip).
 #include "ksr_gemm.h"
+#include "ksr_wg_fuse.h"
 
 namespace {
 
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
         if (ln_sums) ksr_colsum32(xb, lane, ds1, xh, cs[2][0], cs[2][1]);
         ln_bwd(ds1, sm.ln[2], h, xh, rs_1, du1);
         ksr_store32_co<ST>(xb, a.du1, n0w, nvalid, 64, 0, lane, du1);
+        if (a.dctx == nullptr) continue;      // the out-projection's backward runs in a kernel of its own (ksr_batch_tx_layer_bwd_out_wg)
         float da[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i)
@@ -196,6 +198,78 @@ __global__ void __launch_bounds__(1024) ln_reduce_kernel(LnRedArgs a) {
 #pragma unroll
     for (int r = 0; r < 32; ++r) s += part[r][o];
     a.out[l][(e >> 6) * a.row_stride + (e & 63)] = s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16 storage: the out-projection's backward as a kernel of its own that also accumulates out_proj's weight gradient
+// (the scheme of ksr_wg_fuse.h: both operands of dW = da^T ctx are in its registers): the token kernel then stops at du1,
+// and da (du1 under the attention branch's dropout mask), which only fed that product and this matrix product, is never
+// written.  Tried and dropped: linear1's and linear2's weight gradients inside the token kernel (64 more accumulator
+// registers beside its 246: 200-330 spilled registers in every arrangement of the prefetches).
+struct TxBwdOutArgs {
+    const void* du1; const void* ctx;     // [N,64]
+    const float* out_w;                   // [64][64]
+    void* dctx;
+    float* wg_slab;                       // [gridDim.x][KSR_WGF_ROW]
+    long N;
+    float p_drop;
+    unsigned long long seed;
+    const unsigned long long* seed_dev;
+};
+
+struct __attribute__((aligned(16))) TxBwdOutSmem {
+    float f_outt[2 * 32 * 64 / 2];
+    float xpose[4 * KSR_XPOSE_FLOATS];
+};
+
+__global__ void __launch_bounds__(256, 2) tx_bwd_out_wg_kernel(TxBwdOutArgs a) {
+    KSR_MIX_SEED(a);
+    using ST = __bf16;
+    constexpr int PREC = KSR_BF16S;
+    __shared__ TxBwdOutSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<PREC, 32, 2, true>(sm.f_outt, nullptr, a.out_w, 64, nullptr, MapHL{32}, MapHL{32}, tid, 256);
+    __syncthreads();
+    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+    const bool drop = a.p_drop > 0.f;
+    const long ntiles = (a.N + 127) / 128;
+    KsrWgFused wgf;
+    ksr_wgf_init(wgf);
+    KsrTile<ST> t_du, t_cx;
+    auto fetch = [&](long t) {
+        const long r0 = t * 128 + wv * 32;
+        const int nv = (a.N - r0) < 32 ? (int)(a.N - r0 > 0 ? a.N - r0 : 0) : 32;
+        ksr_co_fetch<ST, true>(a.du1, r0, nv, 64, 0, lane, t_du);
+        ksr_co_fetch<ST, true>(a.ctx, r0, nv, 64, 0, lane, t_cx);
+    };
+    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n0 = tile * 128 + wv * 32 + tok;
+        const long n = n0 < a.N ? n0 : 0;
+        const long n0w = tile * 128 + wv * 32;
+        const int nvalid = (a.N - n0w) < 32 ? (int)(a.N - n0w > 0 ? a.N - n0w : 0) : 32;
+        float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+        float da[32], cx[32];
+        ksr_co_finish<ST>(xb, lane, t_du, da);
+        ksr_co_finish<ST>(xb, lane, t_cx, cx);
+        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);     // in flight during this tile
+        if (drop) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                da[i] = ksr_keep(a.seed, 1u, (unsigned long long)n * 64 + 32 * h, i, keep) ? da[i] * inv_keep : 0.f;
+        }
+        {
+            f32x16 acc[2];
+            ksr_wave_gemm<PREC, 32, 2>(sm.f_outt, nullptr, da, acc, lane);
+            float dc[32];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { dc[i] = acc[0][i]; dc[16 + i] = acc[1][i]; }
+            ksr_store32_co<ST, false>(xb, a.dctx, n0w, nvalid, 64, 0, lane, dc);
+        }
+        ksr_wgf_accumulate(xb, lane, da, cx, wgf);     // rows past the end of the tensor hold zeros in da
+    }
+    ksr_wgf_finish(sm.xpose, a.wg_slab + (long)blockIdx.x * KSR_WGF_ROW, tid, wgf);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -348,7 +422,8 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_attn_kernel(TxBwdAttnArgs a) {
 
 // params[6]: norm_final.weight (or NULL), norm2.weight, norm1.weight, linear2.weight, linear1.weight,
 // out_proj.weight.  saved[7]: xhat_final, rstd_final, xhat2, rstd2, hmid, xhat1, rstd1.
-// outs[7]: ds2 (only with the final norm), dm, dpre [N,32], ds1, du1, da (only when p_drop > 0), dctx.
+// outs[7]: ds2 (only with the final norm), dm, dpre [N,32], ds1, du1, da (only when p_drop > 0), dctx (NULL: the kernel
+// stops at du1 and writes neither da nor dctx; ksr_batch_tx_layer_bwd_out_wg continues from du1).
 // ln_slab (optional): 3 * 768 * 128 floats of workspace; with it the kernel also reduces the LayerNorm gain / shift
 // gradients, ln_grads[l] (l = final norm, norm2, norm1; NULL to skip) receiving the gain gradient at [c] and the shift
 // gradient at [ln_row_stride + c], and the outputs ds2 / ds1 (which only those reductions consume) may be NULL.
@@ -365,12 +440,12 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     a.ds2 = outs[0]; a.dm = outs[1]; a.dpre = outs[2]; a.ds1 = outs[3]; a.du1 = outs[4]; a.da = outs[5]; a.dctx = outs[6];
     for (int i = 1; i < 6; ++i) KSR_CHECK_ARG(params[i] != nullptr, "batch_tx_layer_bwd_token: params[%d] is null", i);
     for (int i = 2; i < 7; ++i) KSR_CHECK_ARG(saved[i] != nullptr, "batch_tx_layer_bwd_token: saved[%d] is null", i);
-    KSR_CHECK_ARG(a.dm && a.dpre && a.du1 && a.dctx, "batch_tx_layer_bwd_token: null output");
+    KSR_CHECK_ARG(a.dm && a.dpre && a.du1, "batch_tx_layer_bwd_token: null output");
     KSR_CHECK_ARG(!a.nf_w || (a.xhatf && a.rstdf), "batch_tx_layer_bwd_token: final norm needs xhat/rstd");
     KSR_CHECK_ARG(ln_slab || (a.ds1 && (!a.nf_w || a.ds2)), "batch_tx_layer_bwd_token: ds1 / ds2 are required without ln_slab");
     KSR_CHECK_ARG(!ln_slab || (ln_grads && ln_row_stride >= 64), "batch_tx_layer_bwd_token: ln_slab needs ln_grads and a row stride >= 64");
     a.ln_slab = ln_slab;
-    KSR_CHECK_ARG(!(p_drop > 0.f) || a.da, "batch_tx_layer_bwd_token: dropout needs the da output");
+    KSR_CHECK_ARG(!(p_drop > 0.f) || a.da || !a.dctx, "batch_tx_layer_bwd_token: dropout needs the da output");
     a.N = (long)N; a.p_drop = p_drop; a.seed = seed; a.seed_dev = ksr_seed_dev();
     const long ntiles = (N + 127) / 128;
 #define KSR_CALL(P) hipLaunchKernelGGL(tx_bwd_token_kernel<P>, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a)
@@ -396,4 +471,22 @@ extern "C" int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, c
     else hipLaunchKernelGGL(tx_bwd_attn_kernel<float>, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_attn");
     return KSR_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+extern "C" int64_t ksr_tx_bwd_wg_slab_floats(void) { return (int64_t)KSR_WGF_MAX_GRID * KSR_WGF_ROW; }
+
+// dctx [N,64] = mask(du1) * W_out (the attention branch's dropout mask regenerated from seed), dW [64][64] / db [64] of
+// out_proj from mask(du1) and ctx.  wg_slab: ksr_tx_bwd_wg_slab_floats() floats.
+extern "C" int ksr_batch_tx_layer_bwd_out_wg(const float* du1, const float* ctx, const float* out_w, float* dctx, int64_t N,
+                                             float p_drop, uint64_t seed, float* wg_slab, float* dW, float* db,
+                                             hipStream_t stream) {
+    KSR_CHECK_ARG(du1 && ctx && out_w && dctx && wg_slab && dW && db && N > 0, "batch_tx_layer_bwd_out_wg: bad argument");
+    KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "batch_tx_layer_bwd_out_wg: bf16 storage mode only");
+    TxBwdOutArgs a{du1, ctx, out_w, dctx, wg_slab, (long)N, p_drop, seed, ksr_seed_dev()};
+    const long ntiles = (N + 127) / 128;
+    const unsigned grid = (unsigned)(ntiles < KSR_WGF_MAX_GRID ? ntiles : KSR_WGF_MAX_GRID);
+    hipLaunchKernelGGL(tx_bwd_out_wg_kernel, dim3(grid), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("batch_tx_layer_bwd_out_wg");
+    return ksr_slab_reduce(wg_slab, (int)grid, 64, 64, dW, db, stream);
 }

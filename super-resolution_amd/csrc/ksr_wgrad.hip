@@ -697,6 +697,15 @@ __global__ void __launch_bounds__(256) stemgrad_kernel(StemgArgs a) {
         red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
 }
 
+// dW[j][k] = dW[j][k] * gain[k] + db[j] * shift[k]
+__global__ void __launch_bounds__(256) affine_fold_kernel(float* dW, const float* db, const float* gain, const float* shift,
+                                                          int J, int K) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= J * K) return;
+    const int j = idx / K, k = idx - j * K;
+    dW[idx] = fmaf(dW[idx], gain[k], db[j] * shift[k]);
+}
+
 // out[j][k] = r[j]*u[k] + c[j]*w[k]
 __global__ void __launch_bounds__(256) outer2_kernel(float* out, const float* r, const float* u, const float* c,
                                                      const float* w, int J, int K, float* c_copy) {
@@ -786,6 +795,11 @@ extern "C" int ksr_wgrad_slab_floats(int J, int K) { return WG_GRID * (J * K + J
 // Fixed-order sum of G partial rows [J*K | J] (written by a kernel that accumulated the products itself) to dW, db.
 int ksr_slab_reduce(const float* slab, int G, int J, int K, float* dW, float* db, hipStream_t stream) {
     return launch_reduce(slab, G, J, K, (long)J * K + J, dW, K, 1, db, 0, 0, 0, stream);
+}
+
+// The same for partial rows that hold [J*K | J] at the start of `stride` floats each (several gradients per row).
+int ksr_slab_reduce_strided(const float* slab, int G, int J, int K, long stride, float* dW, float* db, hipStream_t stream) {
+    return launch_reduce(slab, G, J, K, stride, dW, K, 1, db, 0, 0, 0, stream);
 }
 
 // dW [J][K] (row-major, or scattered through the KAN channel map when kan_upscale > 0) and db [J].
@@ -940,5 +954,15 @@ extern "C" int ksr_outer2(float* out, const float* r, const float* u, const floa
     KSR_CHECK_ARG(out && r && u && c && w && J > 0 && K > 0, "outer2: bad argument");
     hipLaunchKernelGGL(outer2_kernel, dim3((J * K + 255) / 256), dim3(256), 0, stream, out, r, u, c, w, J, K, c_copy);
     KSR_LAUNCH_CHECK("outer2");
+    return KSR_OK;
+}
+
+// Weight gradient of a linear map whose input is a LayerNorm output s = xhat * gain + shift, from the product taken with
+// xhat instead of s (so that s need not be kept): dW[j][k] <- dW[j][k] * gain[k] + db[j] * shift[k], in place.
+extern "C" int ksr_wgrad_affine_input(float* dW, const float* db, const float* gain, const float* shift, int J, int K,
+                                      hipStream_t stream) {
+    KSR_CHECK_ARG(dW && db && gain && shift && J > 0 && K > 0, "wgrad_affine_input: bad argument");
+    hipLaunchKernelGGL(affine_fold_kernel, dim3((J * K + 255) / 256), dim3(256), 0, stream, dW, db, gain, shift, J, K);
+    KSR_LAUNCH_CHECK("wgrad_affine_input");
     return KSR_OK;
 }

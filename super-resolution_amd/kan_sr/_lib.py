@@ -36,7 +36,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad", "_finalize", "_mix", "_merge", "_dgrad", "_batch", "_wg", "_v", "_l1")):
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad", "_finalize", "_mix", "_merge", "_dgrad", "_batch", "_wg", "_v", "_l1", "_input")):
             return fn
 
         def timed(*args):
@@ -80,6 +80,7 @@ def _declare(L: ctypes.CDLL) -> None:
     L.ksr_kan_lin_slab_floats.restype = c_int64
     L.ksr_fused_wgrad_slab_floats.restype = c_int64
     L.ksr_in_proj_bwd_wg_slab_floats.restype = c_int64
+    L.ksr_tx_bwd_wg_slab_floats.restype = c_int64
 
 
 # every symbol include/ksr.h declares (tests/test_host_logic.py compares the two lists)
@@ -90,7 +91,7 @@ EXPORTS = [
     "ksr_batch_tx_layer_fwd", "ksr_batch_attn_fwd", "ksr_batch_qkv_attn_fwd", "ksr_batch_tx_layer_post_fwd",
     "ksr_feed_kan_supported", "ksr_feed_kan_fwd",
     "ksr_feed_kan_lane_len", "ksr_feed_kan_bwd", "ksr_batch_tx_layer_bwd_token", "ksr_batch_tx_layer_bwd_attn",
-    "ksr_batch_attn_bwd",
+    "ksr_batch_attn_bwd", "ksr_tx_bwd_wg_slab_floats", "ksr_batch_tx_layer_bwd_out_wg", "ksr_wgrad_affine_input",
     "ksr_gate_pw_bwd_v", "ksr_fn1_bwd_stem_v", "ksr_dwconv_wgrad_v", "ksr_in_proj_bwd", "ksr_in_proj_bwd_wg", "ksr_in_proj_bwd_wg_slab_floats", "ksr_gate_pw_bwd", "ksr_gate_pw_bwd_wg", "ksr_pw2_bwd_wg", "ksr_fused_wgrad_slab_floats", "ksr_fn1_bwd", "ksr_pw2_bwd", "ksr_pw1_bwd",
     "ksr_wgrad_slab_floats", "ksr_wgrad", "ksr_colreduce", "ksr_dwconv_wgrad", "ksr_stem_scalar_wgrad", "ksr_outer2",
     "ksr_l1_y_loss", "ksr_l1_y_loss_static", "ksr_adam_step", "ksr_adam_step_dev", "ksr_set_dropout_seed_source", "ksr_comm_unique_id", "ksr_comm_init", "ksr_allreduce_sum", "ksr_comm_nranks",

@@ -108,7 +108,8 @@ class _Ws:
         on the caller's stream, in order, and each call's reduction has consumed the rows before the next call's kernel
         starts; it must stay apart from slab(), which the reductions on the second stream use concurrently."""
         if self._fused_slab is None:
-            n = max(int(lib().ksr_fused_wgrad_slab_floats()), int(lib().ksr_in_proj_bwd_wg_slab_floats()))
+            n = max(int(lib().ksr_fused_wgrad_slab_floats()), int(lib().ksr_in_proj_bwd_wg_slab_floats()),
+                    int(lib().ksr_tx_bwd_wg_slab_floats()))
             self._fused_slab = torch.empty(n, device=self.dev, dtype=torch.float32)
         return self._fused_slab
 
@@ -167,14 +168,16 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
               p[q + "self_attn.out_proj.weight"]]
     saved = [sv["xhatf"], sv["rstdf"], sv["xhat2"], sv["rstd2"], sv["hmid"], sv["xhat1"], sv["rstd1"]]
     dm, dpre, du1, dctx = ws.act(N, 64), ws.act(N, 32), ws.act(N, 64), ws.act(N, 64)
-    da = ws.act(N, 64) if p_drop > 0 else None
+    fused = ws.fused_wgrad()
+    # bf16 storage: the token kernel stops at du1; the out-projection's backward (with out_proj's weight gradient) follows
+    da = ws.act(N, 64) if (p_drop > 0 and not fused) else None
     lseed = (seed * 4 + li) & 0xFFFFFFFFFFFFFFFF
     # LayerNorm gains / shifts are summed inside the token kernel (ds2 / ds1 would only feed those sums)
     gn2 = ws.grad_pair(q + "norm2.weight", q + "norm2.bias", 64)
     gn1 = ws.grad_pair(q + "norm1.weight", q + "norm1.bias", 64)
     gnf = ws.grad_pair(pre + "encoder.norm.weight", pre + "encoder.norm.bias", 64) if last else None
     check(L.ksr_batch_tx_layer_bwd_token(ptr(dy), _ptr_array(params), _ptr_array(saved),
-                                         _ptr_array([None, dm, dpre, None, du1, da, dctx]), c_int64(N),
+                                         _ptr_array([None, dm, dpre, None, du1, da, None if fused else dctx]), c_int64(N),
                                          c_float(p_drop), c_uint64(lseed), ptr(ws.ln_slab()), _ptr_array([gnf, gn2, gn1]),
                                          c_int(64), stream()), "ksr_batch_tx_layer_bwd_token")
     if da is None:
@@ -188,10 +191,22 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     _wgrad(ws, dm, 64, 0, 64, sv["hmid"], 32, 0, 32, N, gw, gb)
     grads[q + "linear2.weight"], grads[q + "linear2.bias"] = gw, gb
     gw, gb = ws.grad(q + "linear1.weight", 32, 64), ws.grad(q + "linear1.bias", 32)
-    _wgrad(ws, dpre, 32, 0, 32, sv["s1"], 64, 0, 64, N, gw, gb)
+    if sv.get("s1") is not None:
+        _wgrad(ws, dpre, 32, 0, 32, sv["s1"], 64, 0, 64, N, gw, gb)
+    else:
+        # the forward did not keep LayerNorm 1's output s1 = xhat1 * gain + shift: product with xhat1, then the affine map
+        _wgrad(ws, dpre, 32, 0, 32, sv["xhat1"], 64, 0, 64, N, gw, gb)
+        with ws.side(gw, gb):
+            check(L.ksr_wgrad_affine_input(ptr(gw), ptr(gb), ptr(p[q + "norm1.weight"]), ptr(p[q + "norm1.bias"]), c_int(32),
+                                           c_int(64), stream()), "ksr_wgrad_affine_input")
     grads[q + "linear1.weight"], grads[q + "linear1.bias"] = gw, gb
     gw, gb = ws.grad(q + "self_attn.out_proj.weight", 64, 64), ws.grad(q + "self_attn.out_proj.bias", 64)
-    _wgrad(ws, da, 64, 0, 64, sv["ctx"], 64, 0, 64, N, gw, gb)
+    if fused:
+        check(L.ksr_batch_tx_layer_bwd_out_wg(ptr(du1), ptr(sv["ctx"]), ptr(p[q + "self_attn.out_proj.weight"]), ptr(dctx),
+                                              c_int64(N), c_float(p_drop), c_uint64(lseed), ptr(ws.fused_slab()), ptr(gw), ptr(gb),
+                                              stream()), "ksr_batch_tx_layer_bwd_out_wg")
+    else:
+        _wgrad(ws, da, 64, 0, 64, sv["ctx"], 64, 0, 64, N, gw, gb)
     grads[q + "self_attn.out_proj.weight"], grads[q + "self_attn.out_proj.bias"] = gw, gb
     # attention
     dqkv = ws.act(N, 192)

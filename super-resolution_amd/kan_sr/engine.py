@@ -146,7 +146,9 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
         out = new(N, 64)
         sv = None
         if keep:
-            sv = dict(qkv=new(N, 192), ctx=new(N, 64), xhat1=new(N, 64), rstd1=new32(N), s1=new(N, 64),
+            # bf16 storage: LayerNorm 1's output s1 is not kept (linear1's weight gradient takes xhat1 and the affine map)
+            sv = dict(qkv=new(N, 192), ctx=new(N, 64), xhat1=new(N, 64), rstd1=new32(N),
+                      s1=new(N, 64) if adt == torch.float32 else None,
                       hmid=new(N, 32), xhat2=new(N, 64), rstd2=new32(N),
                       xhatf=new(N, 64) if last else None, rstdf=new32(N) if last else None)
             sv["in"] = s
