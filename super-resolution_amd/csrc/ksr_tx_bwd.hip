@@ -204,8 +204,11 @@ __global__ void __launch_bounds__(1024) ln_reduce_kernel(LnRedArgs a) {
 // bf16 storage: the out-projection's backward as a kernel of its own that also accumulates out_proj's weight gradient
 // (the scheme of ksr_wg_fuse.h: both operands of dW = da^T ctx are in its registers): the token kernel then stops at du1,
 // and da (du1 under the attention branch's dropout mask), which only fed that product and this matrix product, is never
-// written.  Tried and dropped: linear1's and linear2's weight gradients inside the token kernel (64 more accumulator
-// registers beside its 246: 200-330 spilled registers in every arrangement of the prefetches).
+// written.  Tried and dropped: linear1's and linear2's weight gradients inside the token kernel.  64 more accumulator
+// registers beside its 246 spill 200-330 registers in every arrangement of the prefetches; with the output blocks split over
+// the four waves (operand tiles of all 128 tokens in LDS, 16 accumulators per wave, two barriers per tile) and only
+// linear2's product it still spills 99 (0.53 ms per launch against 0.23 + 0.05 for the separate kernels), and built for one
+// wave per SIMD (no spills) it takes 0.33 ms.
 struct TxBwdOutArgs {
     const void* du1; const void* ctx;     // [N,64]
     const float* out_w;                   // [64][64]

@@ -167,8 +167,8 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     params = [nf_w, p[q + "norm2.weight"], p[q + "norm1.weight"], p[q + "linear2.weight"], p[q + "linear1.weight"],
               p[q + "self_attn.out_proj.weight"]]
     saved = [sv["xhatf"], sv["rstdf"], sv["xhat2"], sv["rstd2"], sv["hmid"], sv["xhat1"], sv["rstd1"]]
-    dm, dpre, du1, dctx = ws.act(N, 64), ws.act(N, 32), ws.act(N, 64), ws.act(N, 64)
     fused = ws.fused_wgrad()
+    dm, dpre, du1, dctx = ws.act(N, 64), ws.act(N, 32), ws.act(N, 64), ws.act(N, 64)
     # bf16 storage: the token kernel stops at du1; the out-projection's backward (with out_proj's weight gradient) follows
     da = ws.act(N, 64) if (p_drop > 0 and not fused) else None
     lseed = (seed * 4 + li) & 0xFFFFFFFFFFFFFFFF
@@ -180,6 +180,9 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
                                          _ptr_array([None, dm, dpre, None, du1, da, None if fused else dctx]), c_int64(N),
                                          c_float(p_drop), c_uint64(lseed), ptr(ws.ln_slab()), _ptr_array([gnf, gn2, gn1]),
                                          c_int(64), stream()), "ksr_batch_tx_layer_bwd_token")
+    gw, gb = ws.grad(q + "linear2.weight", 64, 32), ws.grad(q + "linear2.bias", 64)
+    _wgrad(ws, dm, 64, 0, 64, sv["hmid"], 32, 0, 32, N, gw, gb)
+    grads[q + "linear2.weight"], grads[q + "linear2.bias"] = gw, gb
     if da is None:
         da = du1
     if last:
@@ -187,9 +190,6 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     grads[q + "norm2.weight"], grads[q + "norm2.bias"] = gn2[0], gn2[1]
     grads[q + "norm1.weight"], grads[q + "norm1.bias"] = gn1[0], gn1[1]
     # linear2 / linear1 / out_proj weights
-    gw, gb = ws.grad(q + "linear2.weight", 64, 32), ws.grad(q + "linear2.bias", 64)
-    _wgrad(ws, dm, 64, 0, 64, sv["hmid"], 32, 0, 32, N, gw, gb)
-    grads[q + "linear2.weight"], grads[q + "linear2.bias"] = gw, gb
     gw, gb = ws.grad(q + "linear1.weight", 32, 64), ws.grad(q + "linear1.bias", 32)
     if sv.get("s1") is not None:
         _wgrad(ws, dpre, 32, 0, 32, sv["s1"], 64, 0, 64, N, gw, gb)
