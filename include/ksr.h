@@ -339,6 +339,24 @@ int ksr_ssim_y_grad_l1(const float* maps, const float* pred, int64_t pred_batch_
                        float l1_grad_scale, float* l1_slab, float* l1_out, ksr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Gradient with respect to the INPUT IMAGE (what the reference's autograd returns when x requires a gradient; its
+ * training step never asks for it).  Three contributions, each an entry point:
+ *  - Cb / Cr planes: the adjoint of F.interpolate(..., mode='bilinear') (conv_sep_kan.py:33-34): ksr_bilinear_up_bwd,
+ *    arguments as ksr_bilinear_up with gout in the place of out and gin (written) in the place of in;
+ *  - luma, through the KAN evaluation's own dependence on the pixel value (kan_layer.py:68-84,106-118, bspline.py:4-28,
+ *    the order-0 indicator held constant as autograd does): ksr_feed_kan_dx, gx written;
+ *  - luma, through the encoder (ffn1's front, unet_blocks.py:236-238): ksr_stem_dx adds w1 * convT(dpre) to gx, where
+ *    dpre [N] is the output of ksr_fn1_bwd(stem = 1) / ksr_fn1_bwd_stem_v. */
+int ksr_bilinear_up_bwd(const float* gout, float* gin, int B, int n_channels, int H, int W, int r, int64_t in_batch_stride,
+                        int in_channel0, int64_t out_batch_stride, int out_channel0, ksr_stream_t stream);
+int ksr_feed_kan_dx(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
+                    const float* feed_b, const float* gout, int64_t gout_batch_stride, float* gx, int64_t gx_batch_stride,
+                    int B, int H, int W, int upscale, int n_coef, const float* knots, int n_knots, int spline_order,
+                    ksr_stream_t stream);
+int ksr_stem_dx(const float* dpre, const float* pw1_w, const float* dw_w, float* gx, int64_t gx_batch_stride, int B, int H,
+                int W, ksr_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Colour pre/post-processing: the steps either side of the model in the reference's data path
  * (src/ml/utils/colors/ycbcr.py; dataset transform src/ml/datasets/huawei/datamodule.py:113-134 and
  * GenerateCallback src/ml/callbacks/generate.py:43,65,80).  NCHW fp32 images; m9 / o3 are HOST arrays.

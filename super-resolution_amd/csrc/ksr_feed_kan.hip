@@ -170,6 +170,85 @@ int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
     return KSR_OK;
 }
 
+// Gradient of the KAN evaluation with respect to the pixel's own luma value (the reference's autograd gives it when the
+// input image requires a gradient; conv_sep_kan_cells.py:136-156 through kan_layer.py:68-84,106-118 and bspline.py:4-28):
+//   dx[n] = sum_o go[n,o] * (rw[o] silu'(x) + uw[o] sum_g B'_g(x) coef[o,g]),
+// with the order-0 indicator held constant in B'.  The per-pixel parameters are recomputed (feed product) as in the forward.
+template <int PREC, int R, int KC, int KORD>
+__global__ void __launch_bounds__(256, 2) feed_kan_dx_kernel(FeedArgs a, KsrKnots kn, float* __restrict__ gx, long gx_bstride) {
+    using C = FeedCfg<R, KC>;
+    constexpr int NB = C::NB;
+    using ST = typename KsrStore<PREC>::T;
+    __shared__ FeedSmem<NB, false> sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.w, 64, a.bias, MapKan{C::O, KC}, MapHL{32}, tid, 256);
+    if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
+    __syncthreads();
+    const int HW = a.H * a.W;
+    const long N = (long)a.B * HW;
+    const long ntiles = (N + 127) / 128;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n = tile * 128 + wv * 32 + tok;
+        const bool live = n < N;
+        const long nn = live ? n : 0;
+        const int b = (int)(nn / HW), hw = (int)(nn % HW);
+        const int y = hw / a.W, x = hw % a.W;
+        float f[32];
+        if (live) ksr_loadn<ST, 32>(a.feat, n * 64 + 32 * h, f);
+        else {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) f[i] = 0.f;
+        }
+        f32x16 acc[NB];
+        ksr_wave_gemm<PREC, 32, NB>(sm.frag, sm.biasfrag, f, acc, lane);
+        const float xv = live ? a.x_img[(long)b * a.img_bstride + hw] : 0.f;
+        float Nl[KORD + 1], dNl[KORD + 1], dNv[KSR_MAX_ORDER + 1], dbv[KC];
+        const int m = ksr_bspline_local<KORD, true>(xv, sm.knots, kn.M, Nl, dNl);
+#pragma unroll
+        for (int q = 0; q <= KSR_MAX_ORDER; ++q) dNv[q] = 0.f;
+#pragma unroll
+        for (int q = 0; q <= KORD; ++q) dNv[q] = dNl[q];
+        dense_basis<KC>(m, dNv, KORD, dbv);
+        const float sg = ksr_sigmoid(xv), dsl = sg * (1.f + xv * (1.f - sg));
+        float go[C::OH];
+        {
+            const float* gp = a.gout + (long)b * a.out_bstride + ((long)(y * R + h * (R / 2))) * (a.W * R) + (long)x * R;
+#pragma unroll
+            for (int rr = 0; rr < R / 2; ++rr)
+#pragma unroll
+                for (int j = 0; j < R; ++j) go[rr * R + j] = live ? gp[(long)rr * a.W * R + j] : 0.f;
+        }
+        float d = 0.f;
+#pragma unroll
+        for (int ol = 0; ol < C::OH; ++ol) {
+            float dS = 0.f;
+#pragma unroll
+            for (int g = 0; g < KC; ++g) {
+                const int e = ol * C::PER + g;
+                dS += dbv[g] * acc[e / 16][e % 16];
+            }
+            const int eu = ol * C::PER + KC, er = eu + 1;
+            const float uw = acc[eu / 16][eu % 16], rw = acc[er / 16][er % 16];
+            d += go[ol] * (rw * dsl + uw * dS);
+        }
+        d = ksr_pair_sum(d);
+        if (live && h == 0) gx[(long)b * gx_bstride + hw] = d;
+    }
+}
+
+template <int R, int KC, int KORD>
+int launch_feed_dx(const FeedArgs& a, const KsrKnots& kn, float* gx, long gx_bstride, hipStream_t s) {
+    const long N = (long)a.B * a.H * a.W;
+    const long ntiles = (N + 127) / 128;
+    const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);
+#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_dx_kernel<P, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn, gx, gx_bstride)
+    KSR_DISPATCH_PREC(KSR_CALL);
+#undef KSR_CALL
+    KSR_LAUNCH_CHECK("feed_kan_dx");
+    return KSR_OK;
+}
+
 template <int NB, bool COAL>
 struct __attribute__((aligned(16))) FeedBwdSmem {
     float frag[2 * (NB * 16) * 64];
@@ -369,6 +448,28 @@ extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, co
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
 #define KSR_X(R, KC, KO) if (upscale == R && n_coef == KC && spline_order == KO) return launch_feed_bwd<R, KC, KO>(a, kn, stream);
+    KSR_FEED_CONFIGS(KSR_X)
+#undef KSR_X
+    return KSR_ERR_UNSUPPORTED;
+}
+
+// gx[b, y, x] (images gx_batch_stride elements apart) = d(out)/d(luma) contracted with gout, through the KAN evaluation's
+// direct dependence on the pixel's luma value (the path through the encoder is ksr_stem_dx).  Written, not accumulated.
+extern "C" int ksr_feed_kan_dx(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
+                               const float* feed_b, const float* gout, int64_t gout_batch_stride, float* gx,
+                               int64_t gx_batch_stride, int B, int H, int W, int upscale, int n_coef, const float* knots,
+                               int n_knots, int spline_order, hipStream_t stream) {
+    KSR_CHECK_ARG(feat && x_img && feed_w && feed_b && gout && gx && knots, "feed_kan_dx: null pointer");
+    KSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "feed_kan_dx: non-positive dimension");
+    KSR_CHECK_ARG(n_knots == n_coef + spline_order + 1 && n_knots <= KSR_MAX_KNOTS, "feed_kan_dx: bad knot count %d", n_knots);
+    KSR_UNSUPPORTED(!ksr_feed_kan_supported(upscale, n_coef, spline_order), "feed_kan_dx: configuration has no fused kernel");
+    FeedArgs a{};
+    a.feat = feat; a.x_img = x_img; a.img_bstride = img_batch_stride; a.w = feed_w; a.bias = feed_b;
+    a.gout = gout; a.out_bstride = gout_batch_stride; a.B = B; a.H = H; a.W = W;
+    KsrKnots kn;
+    for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
+    kn.M = n_knots; kn.k = spline_order;
+#define KSR_X(R, KC, KO) if (upscale == R && n_coef == KC && spline_order == KO) return launch_feed_dx<R, KC, KO>(a, kn, gx, (long)gx_batch_stride, stream);
     KSR_FEED_CONFIGS(KSR_X)
 #undef KSR_X
     return KSR_ERR_UNSUPPORTED;

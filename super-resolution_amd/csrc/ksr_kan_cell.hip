@@ -643,6 +643,66 @@ __global__ void __launch_bounds__(256) bilinear_up_kernel(BilArgs a) {
     *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// Adjoint of bilinear_up_kernel: a.in = gradient of the upsampled planes, a.out = gradient of the source planes
+// (in / out keep the forward's roles in BilArgs: `out` strides describe the r x larger tensor).  Gather form: every
+// source pixel visits the upsampled pixels whose footprint can contain it and re-derives their weights.
+__global__ void __launch_bounds__(256) bilinear_up_bwd_kernel(const float* __restrict__ gout, float* __restrict__ gin, BilArgs a) {
+    const int OW = a.W * a.r, OH = a.H * a.r;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)a.B * a.nc * a.H * a.W;
+    if (idx >= total) return;
+    const int x = (int)(idx % a.W);
+    const int y = (int)((idx / a.W) % a.H);
+    const int c = (int)((idx / ((long)a.W * a.H)) % a.nc);
+    const int b = (int)(idx / ((long)a.W * a.H * a.nc));
+    const float sc = 1.0f / (float)a.r;
+    const float* g = gout + (long)b * a.out_bstride + (long)(a.oc0 + c) * a.out_cstride;
+    const int oy_lo = max(0, a.r * (y - 1)), oy_hi = min(OH - 1, a.r * (y + 2) - 1);
+    const int ox_lo = max(0, a.r * (x - 1)), ox_hi = min(OW - 1, a.r * (x + 2) - 1);
+    float s = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        float sy = sc * ((float)oy + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+            float sx = sc * ((float)ox + 0.5f) - 0.5f;
+            sx = sx < 0.f ? 0.f : sx;
+            const int x0 = (int)sx;
+            const int x1 = x0 + (x0 < a.W - 1 ? 1 : 0);
+            const float lx1 = sx - (float)x0, lx0 = 1.f - lx1;
+            const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
+            s += wy * wx * g[(long)oy * OW + ox];
+        }
+    }
+    gin[(long)b * a.in_bstride + (long)(a.ic0 + c) * a.in_cstride + (long)y * a.W + x] = s;
+}
+
+// Gradient of the first FFN's front (u = w1 Y + b1, pre = bd + dw3x3(u)) with respect to the luma plane:
+// gx[n] += w1 * sum_tap wd[tap] * dpre(n - tap)   (taps that leave the image contribute nothing)
+__global__ void __launch_bounds__(256) stem_dx_kernel(const float* __restrict__ dpre, const float* __restrict__ p1w,
+                                                      const float* __restrict__ dww, float* __restrict__ gx, long gx_bstride,
+                                                      int B, int H, int W) {
+    const long HW = (long)H * W;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= (long)B * HW) return;
+    const int b = (int)(n / HW), hw = (int)(n % HW);
+    const int y = hw / W, x = hw % W;
+    const float* dp = dpre + (long)b * HW;
+    float du = 0.f;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int ys = y - dy, xs = x - dx;
+            if (ys >= 0 && ys < H && xs >= 0 && xs < W) du += dww[(dy + 1) * 3 + (dx + 1)] * dp[(long)ys * W + xs];
+        }
+    gx[(long)b * gx_bstride + hw] += p1w[0] * du;
+}
+
 __global__ void __launch_bounds__(256) bilinear_up_scalar_kernel(BilArgs a) {
     const int OW = a.W * a.r, OH = a.H * a.r;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -820,5 +880,34 @@ extern "C" int ksr_bilinear_up(const float* in, float* out, int B, int n_channel
         hipLaunchKernelGGL(bilinear_up_scalar_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     }
     KSR_LAUNCH_CHECK("bilinear_up");
+    return KSR_OK;
+}
+
+// Adjoint of ksr_bilinear_up: gin planes in_channel0.. of [B, C, H, W] (written) from gout planes out_channel0.. of the
+// r x larger tensor.  Strides in elements.
+extern "C" int ksr_bilinear_up_bwd(const float* gout, float* gin, int B, int n_channels, int H, int W, int r,
+                                   int64_t in_batch_stride, int in_channel0, int64_t out_batch_stride, int out_channel0,
+                                   hipStream_t stream) {
+    KSR_CHECK_ARG(gout && gin && B > 0 && n_channels > 0 && H > 0 && W > 0 && r > 0, "bilinear_up_bwd: bad argument");
+    BilArgs a{};
+    a.B = B; a.nc = n_channels; a.H = H; a.W = W; a.r = r;
+    a.in_bstride = in_batch_stride; a.in_cstride = (long)H * W;
+    a.out_bstride = out_batch_stride; a.out_cstride = (long)H * r * W * r;
+    a.ic0 = in_channel0; a.oc0 = out_channel0;
+    const long total = (long)B * n_channels * H * W;
+    hipLaunchKernelGGL(bilinear_up_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, gout, gin, a);
+    KSR_LAUNCH_CHECK("bilinear_up_bwd");
+    return KSR_OK;
+}
+
+// gx[b, y, x] (images gx_batch_stride elements apart) += the gradient that reaches the luma plane through the first FFN's
+// front, given dpre [N] (gradient of the depthwise conv's output before the ReLU, as the fn_1 backward kernels leave it).
+extern "C" int ksr_stem_dx(const float* dpre, const float* pw1_w, const float* dw_w, float* gx, int64_t gx_batch_stride,
+                           int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dpre && pw1_w && dw_w && gx && B > 0 && H > 0 && W > 0, "stem_dx: bad argument");
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(stem_dx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dpre, pw1_w, dw_w, gx,
+                       (long)gx_batch_stride, B, H, W);
+    KSR_LAUNCH_CHECK("stem_dx");
     return KSR_OK;
 }

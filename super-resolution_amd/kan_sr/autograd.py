@@ -55,6 +55,7 @@ class _Ws:
         self._ln_slab = None
         self._sums_slab = None
         self._fused_slab = None
+        self.dpre = None
         self.arena = arena
         # small problems are bound by the host's launch rate, where the extra stream bookkeeping only costs
         self.wstream = _side_stream(dev) if (SIDE_STREAM_FOR_WGRAD and allow_side_stream and dev.type == "cuda"
@@ -338,16 +339,21 @@ def _stem_parameter_gradients(ws: _Ws, q, p, pre, g: Geometry, grads, v, dpre, r
     grads[f + "pointwise1.bias"] = out12[1:2]
     grads[f + "depthwise.weight"] = out12[2:11].reshape(1, 1, 3, 3)
     grads[f + "depthwise.bias"] = out12[11:12]
+    ws.dpre = dpre            # the input-image gradient (if asked for) continues from here
     return None
 
 
 def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str,
                  g: Geometry, sv: dict, save_us: torch.Tensor, p_drop: float, seed: int, arena=None,
-                 on_tail_done=None, allow_side_stream: bool = True) -> Dict[str, torch.Tensor]:
+                 on_tail_done=None, allow_side_stream: bool = True, want_input_grad: bool = False,
+                 gout_chroma=None) -> Dict[str, torch.Tensor]:
     """gout: gradient of the Y plane of the output (images gout_batch_stride elements apart).
     arena: optional name -> view map; gradients are then written in place.  on_tail_done() is called
     once the gradients of feed + both transformer layers + the final norm have been enqueued (the
-    first all-reduce bucket), while the conv-trunk backward is still to come."""
+    first all-reduce bucket), while the conv-trunk backward is still to come.
+    want_input_grad: also return the gradient with respect to the input image under the key "__input__"
+    (gout_chroma: the whole [B,3,rH,rW] output gradient, whose planes 1, 2 reach the input through the bilinear
+    upsampling; None = those planes carry no gradient)."""
     L = lib()
     N = g.N
     ws = _Ws(x.device, arena, g.N, allow_side_stream)      # one stream while a HIP graph is being recorded
@@ -366,7 +372,30 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
     grads[pre + "feed.weight"], grads[pre + "feed.bias"] = gw, gb
     trunk_backward(ws, gfeat, x, p, pre, g, sv, p_drop, seed, grads, on_tail_done)
     ws.join()
+    if want_input_grad:
+        grads["__input__"] = _input_gradient(ws, gout, gout_batch_stride, gout_chroma, x, p, pre, g, sv)
     return grads
+
+
+def _input_gradient(ws: _Ws, gout, gout_batch_stride, gout_full, x, p, pre, g: Geometry, sv):
+    """Gradient with respect to the input image [B,3,H,W] (conv_sep_kan.py:29-42 under autograd): chroma planes through
+    the bilinear upsampling, luma through the KAN evaluation's own use of the pixel value and through the encoder."""
+    L = lib()
+    gx = torch.empty_like(x)
+    plane = g.H * g.W
+    if gout_full is not None:
+        check(L.ksr_bilinear_up_bwd(ptr(gout_full), ptr(gx), c_int(g.B), c_int(2), c_int(g.H), c_int(g.W), c_int(g.r),
+                                    c_int64(3 * plane), c_int(1), c_int64(3 * plane * g.r * g.r), c_int(1), stream()),
+              "ksr_bilinear_up_bwd")
+    else:
+        gx[:, 1:].zero_()
+    check(L.ksr_feed_kan_dx(ptr(sv["feat"]), ptr(x), c_int64(3 * plane), ptr(p[pre + "feed.weight"]), ptr(p[pre + "feed.bias"]),
+                            ptr(gout), c_int64(gout_batch_stride), ptr(gx), c_int64(3 * plane), *_dims(g), c_int(g.r),
+                            c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k), stream()), "ksr_feed_kan_dx")
+    f = pre + "ffn1."
+    check(L.ksr_stem_dx(ptr(ws.dpre), ptr(p[f + "pointwise1.weight"]), ptr(p[f + "depthwise.weight"]), ptr(gx),
+                        c_int64(3 * plane), *_dims(g), stream()), "ksr_stem_dx")
+    return gx
 
 
 def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Geometry,
@@ -425,18 +454,16 @@ class _ConvSepKanFn(torch.autograd.Function):
     def backward(ctx, gout):
         pre, g, p_drop, seed, names, precision = ctx.cfg
         engine.set_precision(precision)
-        if ctx.needs_input_grad[0]:
-            raise KsrError("gradient with respect to the input image is not implemented (the training step "
-                           "of the reference never needs it)")
         gout = gout.contiguous()
+        want_gx = ctx.needs_input_grad[0]
         grads = backward_all(gout, gout.shape[1] * gout.shape[2] * gout.shape[3], ctx.x, ctx.p, pre, g, ctx.sv,
-                             ctx.save_us, p_drop, seed)
+                             ctx.save_us, p_drop, seed, want_input_grad=want_gx, gout_chroma=gout if want_gx else None)
         ctx.sv = ctx.save_us = None
         out = []
         for n, t in zip(names, ctx.p.values()):
             gr = grads.get(n)
             out.append(None if gr is None else gr.reshape(t.shape))
-        return (None, None, None, None, None, None, None, *out)
+        return (grads.get("__input__"), None, None, None, None, None, None, *out)
 
 
 def conv_sep_kan_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_drop: float, seed: int,

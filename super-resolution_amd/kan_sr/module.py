@@ -165,7 +165,7 @@ class ConvSepKan(nn.Module):
         p = self._params()
         pre = f"layers.{len(self.layers) - 1}.encoder.encoder."
         engine.set_precision(self.precision)
-        needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in p.values())
+        needs_grad = torch.is_grad_enabled() and (x.requires_grad or any(t.requires_grad for t in p.values()))
         p_drop = self.layers[-1].encoder.encoder.encoder.layers[0].p_drop if self.training else 0.0
         seed = engine.new_seed() if p_drop > 0 else 0
         if self.attention:

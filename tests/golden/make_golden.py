@@ -325,6 +325,32 @@ def gold_unet():
     save("unet", **out)
 
 
+# ---------------------------------------------------------------- whole model: gradient with respect to the input image
+def gold_model_input_grad():
+    """The model fixtures' setup (same seeds, hence the same weights, x and gy as model_r*_G*_k*.npz) with x requiring a
+    gradient: what autograd returns for the image (all three planes)."""
+    out = {}
+    for (r, G, k) in [(2, 5, 3), (4, 5, 3), (4, 16, 3)]:
+        torch.manual_seed(600 + 10 * r + G)
+        gen = torch.Generator().manual_seed(600 + 10 * r + G)
+        m = ConvSepKan([1], [r * r], [3], G, k, 0.1, [-1, 1], r).eval()
+        perturb_norms(m, gen)
+        x = torch.rand(2, 3, 16, 16, generator=gen).requires_grad_()
+        y = m(x)
+        gy = torch.randn(y.shape, generator=gen)
+        (y * gy).sum().backward()
+        ref = np.load(os.path.join(HERE, f"model_r{r}_G{G}_k{k}.npz"))
+        assert np.array_equal(ref["x"], x.detach().numpy()) and np.array_equal(ref["gy"], gy.numpy())
+        out[f"r{r}_G{G}.gx"] = x.grad
+        m64 = ConvSepKan([1], [r * r], [3], G, k, 0.1, [-1, 1], r).double().eval()
+        m64.load_state_dict({n: v.double() for n, v in m.state_dict().items()})
+        m64.layers[0].kan_cell.kan_layer.activation_fn.grid = generate_control_points(-1.0, 1.0, 1, r * r, k, G).double()
+        x64 = x.detach().double().requires_grad_()
+        (m64(x64) * gy.double()).sum().backward()
+        out[f"r{r}_G{G}.gx64"] = x64.grad
+    save("model_input_grad", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
@@ -341,3 +367,4 @@ if __name__ == "__main__":
     gold_chan_attention()
     gold_color()
     gold_unet()
+    gold_model_input_grad()

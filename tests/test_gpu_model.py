@@ -110,6 +110,50 @@ def test_full_model_forward_golden(r, G, k):
     assert_fwd(y, t(g["y"]), atol=2e-5)
 
 
+@pytest.mark.parametrize("r,G,k", [(2, 5, 3), (4, 5, 3), (4, 16, 3)])
+def test_full_model_input_gradient_golden(r, G, k):
+    """x.requires_grad: the gradient with respect to the input image against the reference's autograd (chroma planes
+    through the bilinear upsampling's adjoint; luma through the KAN evaluation's own use of the pixel value, with the
+    order-0 indicator constant, and through the encoder's first convolution), parameter gradients unchanged."""
+    g, m = _load_model_golden(r, G, k)
+    gi = load_golden("model_input_grad")
+    x = t(g["x"]).cuda().requires_grad_()
+    y = m(x)
+    assert_fwd(y, t(g["y"]), atol=2e-5)
+    (y * t(g["gy"]).cuda()).sum().backward()
+    ref, ref64 = t(gi[f"r{r}_G{G}.gx"]), t(gi[f"r{r}_G{G}.gx64"])
+    assert x.grad is not None and x.grad.shape == x.shape
+    for c in range(3):
+        assert rel_l2(x.grad[:, c].cpu(), ref[:, c]) <= 1e-4, c
+    e_me, e_ref = float((x.grad.cpu().double() - ref64).norm()), float((ref.double() - ref64).norm())
+    assert e_me <= 2 * e_ref + 1e-6 * float(ref64.norm())
+    for n, prm in m.named_parameters():
+        assert rel_l2(prm.grad.cpu(), t(g["g." + n])) <= 1e-4, n
+    # only the image requires a gradient
+    m.zero_grad()
+    for prm in m.parameters():
+        prm.requires_grad_(False)
+    x2 = t(g["x"]).cuda().requires_grad_()
+    (m(x2) * t(g["gy"]).cuda()).sum().backward()
+    assert torch.equal(x2.grad, x.grad)
+
+
+def test_input_gradient_odd_sizes_vs_oracle():
+    """Image sizes that are not multiples of the tile sizes, B = 3 (the transformer mixes the images), upscale 2."""
+    from kan_sr.module import ConvSepKan
+    torch.manual_seed(5)
+    m = ConvSepKan([1], [4], [3], 5, 3, 0.1, [-1, 1], 2).eval()
+    p = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    x = (torch.rand(3, 3, 9, 13) * 1.4 - 0.2).requires_grad_()
+    y = orc.conv_sep_kan_forward(x, p, out_channels=[4], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=2)
+    gy = torch.randn(y.shape)
+    (y * gy).sum().backward()
+    xg = x.detach().cuda().requires_grad_()
+    (m.cuda()(xg) * gy.cuda()).sum().backward()
+    for c in range(3):
+        assert rel_l2(xg.grad[:, c].cpu(), x.grad[:, c]) <= 1e-4, c
+
+
 def test_cfg1_shape_golden():
     from kan_sr.module import ConvSepKan
     g = load_golden("cfg1_smoke")

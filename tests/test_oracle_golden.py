@@ -127,6 +127,22 @@ def test_full_model(r, G, k):
         assert e_me <= 2 * e_ref + 1e-6 * float(ref64.norm()) + 1e-9, n
 
 
+@pytest.mark.parametrize("r,G,k", [(2, 5, 3), (4, 5, 3), (4, 16, 3)])
+def test_full_model_input_gradient(r, G, k):
+    """Gradient with respect to the input image (the reference's autograd with x.requires_grad: chroma through the
+    bilinear upsampling, luma through the KAN evaluation and through the encoder)."""
+    g, gi = load_golden(f"model_r{r}_G{G}_k{k}"), load_golden("model_input_grad")
+    p = {n[2:]: t(v) for n, v in g.items() if n.startswith("p.")}
+    x = t(g["x"]).requires_grad_()
+    y = orc.conv_sep_kan_forward(x, p, out_channels=[r * r], grid_size=G, spline_order=k, grid_range=[-1, 1], upscale=r)
+    (y * t(g["gy"])).sum().backward()
+    ref, ref64 = t(gi[f"r{r}_G{G}.gx"]), t(gi[f"r{r}_G{G}.gx64"])
+    for c in range(3):
+        assert rel_l2(x.grad[:, c], ref[:, c]) <= GRAD_REL, c
+    e_me, e_ref = float((x.grad.double() - ref64).norm()), float((ref.double() - ref64).norm())
+    assert e_me <= 2 * e_ref + 1e-6 * float(ref64.norm()) + 1e-9
+
+
 def test_full_model_fp64_matches_reference_fp64():
     g = load_golden("model_r4_G5_k3")
     p = {n[2:]: t(v).double() for n, v in g.items() if n.startswith("p.")}
