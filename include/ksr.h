@@ -338,6 +338,26 @@ int ksr_ssim_y_grad_l1(const float* maps, const float* pred, int64_t pred_batch_
                        int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W, float scale,
                        float l1_grad_scale, float* l1_slab, float* l1_out, ksr_stream_t stream);
 
+/* The fused feed + KAN kernels with ONE WEIGHT MATRIX PER IMAGE (feed_w_per_image [B][P][64], P = r^2 (n_coef + 2); the
+ * bias [P] is shared) and the pixel's 64 features at channels feat_c0 .. feat_c0 + 63 of rows of feat_ld elements.  This
+ * is the channel-attention head of BASELINE configs[3] feeding the KAN cell: ConvSepKanAttention's last step,
+ * a_proj(softmax(q^ k^T) v) (conv_sep_kan_attention.py:62-69), is linear in v with the per-image matrix
+ * M_b = W_a softmax_b, so the [N, P] tensor of per-pixel parameters (ConvSepKanCell's `w`, conv_sep_kan_cells.py:136-156)
+ * is never formed.  Otherwise as ksr_feed_kan_fwd / ksr_feed_kan_bwd; the backward writes the feature gradient to
+ * channels gfeat_c0 .. of rows of gfeat_ld elements.  ksr_gram_batched_kan turns gparam (lane order, J =
+ * 2 * ksr_feed_kan_lane_len) into the per-image dM_b [B][P][K] and the column sums tail [B][J] (first P entries of each
+ * row, channel order): ksr_gram_batched with the rows scattered back to the reference's channel numbering. */
+int ksr_feed_kan_fwd_img(const float* feat, int feat_ld, int feat_c0, const float* x_img, int64_t img_batch_stride,
+                         const float* feed_w_per_image, const float* feed_b, float* out, int64_t out_batch_stride,
+                         float* save_us, int B, int H, int W, int upscale, int n_coef, const float* knots, int n_knots,
+                         int spline_order, ksr_stream_t stream);
+int ksr_feed_kan_bwd_img(const float* gout, int64_t gout_batch_stride, const float* x_img, int64_t img_batch_stride,
+                         const float* feed_w_per_image, const float* save_us, float* gfeat, int gfeat_ld, int gfeat_c0,
+                         float* gparam, int B, int H, int W, int upscale, int n_coef, const float* knots, int n_knots,
+                         int spline_order, ksr_stream_t stream);
+int ksr_gram_batched_kan(const float* gparam, int J, const float* a1, int a1_ld, int a1_c0, int K, int64_t tokens_per_entry,
+                         int nb, float* slab, float* out, float* tail, int kan_upscale, int kan_n_coef, ksr_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Gradient with respect to the INPUT IMAGE (what the reference's autograd returns when x requires a gradient; its
  * training step never asks for it).  Three contributions, each an entry point:

@@ -25,7 +25,21 @@ struct FeedArgs {
     float* gfeat;          // [N, 64]
     float* gparam;         // [N, 2, NB*16] gradient of the feed output in lane order (half, e)
     int B, H, W;
+    // Per-image weights (the channel-attention head, whose 1x1 map differs from image to image): w / bias advance by
+    // w_bstride / bias_bstride elements per image, blockIdx.y is the image and the tiles cover its HW pixels.
+    // 0 / 0 with a one-dimensional grid: one weight matrix, tiles over all N pixels.
+    long w_bstride, bias_bstride;
+    int feat_ld, feat_c0;      // row length and first channel of feat (64, 0 for a dense [N,64] tensor)
+    int gfeat_ld, gfeat_c0;    // the same for gfeat
 };
+
+// Pixels a workgroup's tiles run over: all N, or the HW pixels of image blockIdx.y (per-image weights)
+struct FeedRange { long first, count; };
+__device__ __forceinline__ FeedRange feed_range(const FeedArgs& a) {
+    const long HW = (long)a.H * a.W;
+    if (a.w_bstride == 0 && gridDim.y == 1) return FeedRange{0, (long)a.B * HW};
+    return FeedRange{(long)blockIdx.y * HW, HW};
+}
 
 template <int KC>
 __device__ __forceinline__ void dense_basis(int m, const float (&Nv)[KSR_MAX_ORDER + 1], int K, float (&bv)[KC]) {
@@ -75,25 +89,28 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
     __shared__ FeedSmem<NB, COAL> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
-    ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.w, 64, a.bias, MapKan{C::O, KC}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.w + (long)blockIdx.y * a.w_bstride, 64,
+                                           a.bias + (long)blockIdx.y * a.bias_bstride, MapKan{C::O, KC}, MapHL{32}, tid, 256);
     if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
     __syncthreads();
 
     const int HW = a.H * a.W;
-    const long N = (long)a.B * HW;
+    const FeedRange rg = feed_range(a);
+    const long N = rg.count;                         // pixels of this workgroup's range, which starts at rg.first
     const long ntiles = (N + 127) / 128;
     float* xb = sm.xpose + (COAL ? wv * KSR_XPOSE_FLOATS : 0);
     KsrTile<ST> ahead;
     auto fetch_tile = [&](long t) {
         const long r0 = t * 128 + wv * 32;
         const int nv = (N - r0) < 32 ? (int)(N - r0 > 0 ? N - r0 : 0) : 32;
-        ksr_co_fetch<ST, true>(a.feat, r0, nv, 64, 0, lane, ahead);
+        ksr_co_fetch<ST, true>(a.feat, rg.first + r0, nv, a.feat_ld, a.feat_c0, lane, ahead);
     };
     if (COAL && (long)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long n = tile * 128 + wv * 32 + tok;
-        const bool live = n < N;
-        const long nn = live ? n : 0;
+        const long nl = tile * 128 + wv * 32 + tok;
+        const bool live = nl < N;
+        const long n = rg.first + nl;
+        const long nn = live ? n : rg.first;
         const int b = (int)(nn / HW), hw = (int)(nn % HW);
         const int y = hw / a.W, x = hw % a.W;
 
@@ -102,7 +119,7 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
             ksr_co_finish<ST>(xb, lane, ahead, f);
             if (tile + gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
         } else {
-            if (live) ksr_loadn<ST, 32>(a.feat, n * 64 + 32 * h, f);
+            if (live) ksr_loadn<ST, 32>(a.feat, n * a.feat_ld + a.feat_c0 + 32 * h, f);
             else {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) f[i] = 0.f;
@@ -158,12 +175,22 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
     }
 }
 
+// Grid of the feed kernels: tiles over all pixels, or (tiles of one image, image) with per-image weights
+dim3 feed_grid(const FeedArgs& a, long cap) {
+    if (a.w_bstride == 0) {
+        const long ntiles = ((long)a.B * a.H * a.W + 127) / 128;
+        return dim3((unsigned)(ntiles < cap ? ntiles : cap));
+    }
+    const long ntiles = ((long)a.H * a.W + 127) / 128;
+    long per = (cap + a.B - 1) / a.B;
+    if (per < 1) per = 1;
+    return dim3((unsigned)(ntiles < per ? ntiles : per), (unsigned)a.B);
+}
+
 template <int R, int KC, int KORD>
 int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
-    const long N = (long)a.B * a.H * a.W;
-    const long ntiles = (N + 127) / 128;
-    const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);
-#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_fwd_kernel<P, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn)
+    const dim3 grid = feed_grid(a, 768);
+#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_fwd_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("feed_kan_fwd");
@@ -195,7 +222,7 @@ __global__ void __launch_bounds__(256, 2) feed_kan_dx_kernel(FeedArgs a, KsrKnot
         const int b = (int)(nn / HW), hw = (int)(nn % HW);
         const int y = hw / a.W, x = hw % a.W;
         float f[32];
-        if (live) ksr_loadn<ST, 32>(a.feat, n * 64 + 32 * h, f);
+        if (live) ksr_loadn<ST, 32>(a.feat, n * a.feat_ld + a.feat_c0 + 32 * h, f);
         else {
 #pragma unroll
             for (int i = 0; i < 32; ++i) f[i] = 0.f;
@@ -271,17 +298,19 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
     __shared__ FeedBwdSmem<NB, COAL> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
-    ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.w, 64, nullptr, MapHL{32}, MapKan{C::O, KC}, tid, 256);
+    ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.w + (long)blockIdx.y * a.w_bstride, 64, nullptr, MapHL{32},
+                                         MapKan{C::O, KC}, tid, 256);
     if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
     __syncthreads();
 
     const int HW = a.H * a.W;
-    const long N = (long)a.B * HW;
-    const long ntiles = (N + 127) / 128;
+    const FeedRange rg = feed_range(a);
+    const long N = rg.first + rg.count;              // one past the last pixel of this workgroup's range
+    const long ntiles = (rg.count + 127) / 128;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long n0 = tile * 128 + wv * 32 + tok;
+        const long n0 = rg.first + tile * 128 + wv * 32 + tok;
         const bool live = n0 < N;
-        const long n = live ? n0 : 0;
+        const long n = live ? n0 : rg.first;
         const int b = (int)(n / HW), hw = (int)(n % HW);
         const int y = hw / a.W, x = hw % a.W;
 
@@ -325,7 +354,7 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
                 dp[e] = 0.f;
             }
         }
-        const long n0w = tile * 128 + wv * 32;            // the wave's 32 consecutive pixels
+        const long n0w = rg.first + tile * 128 + wv * 32;            // the wave's 32 consecutive pixels
         __bf16* tl = sm.tile + (COAL ? wv * TILE : 0);
         if constexpr (COAL) {
             // rows of gparam are [half 0: KH | half 1: KH] per pixel: one lane half at a time through the tile
@@ -366,21 +395,19 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
             for (int i = 0; i < 4; ++i) {
                 const int idx = i * 64 + lane, row = idx >> 3, pc = idx & 7;
                 if (n0w + row < N)
-                    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.gfeat) + (n0w + row) * 64 + 8 * pc) =
+                    *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.gfeat) + (n0w + row) * a.gfeat_ld + a.gfeat_c0 + 8 * pc) =
                         *reinterpret_cast<const uint4*>(tl + row * FLD + 8 * pc);
             }
         } else {
-            if (live) ksr_storen<ST, 32>(a.gfeat, n * 64 + 32 * h, df);
+            if (live) ksr_storen<ST, 32>(a.gfeat, n * a.gfeat_ld + a.gfeat_c0 + 32 * h, df);
         }
     }
 }
 
 template <int R, int KC, int KORD>
 int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
-    const long N = (long)a.B * a.H * a.W;
-    const long ntiles = (N + 127) / 128;
-    const unsigned grid = (unsigned)(ntiles < 512 ? ntiles : 512);
-#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_bwd_kernel<P, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn)
+    const dim3 grid = feed_grid(a, 512);
+#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_bwd_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("feed_kan_bwd");
@@ -403,11 +430,16 @@ extern "C" int ksr_feed_kan_supported(int upscale, int n_coef, int spline_order)
     return 0;
 }
 
-extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
-                                const float* feed_b, float* out, int64_t out_batch_stride, float* save_us, int B,
-                                int H, int W, int upscale, int n_coef, const float* knots, int n_knots,
-                                int spline_order, hipStream_t stream) {
+static int ksr_feed_kan_P(int upscale, int n_coef) { return upscale * upscale * (n_coef + 2); }
+
+static int feed_kan_fwd_impl(const float* feat, int feat_ld, int feat_c0, const float* x_img, int64_t img_batch_stride,
+                             const float* feed_w, int per_image_weights, const float* feed_b, float* out,
+                             int64_t out_batch_stride, float* save_us, int B, int H, int W, int upscale, int n_coef,
+                             const float* knots, int n_knots, int spline_order, hipStream_t stream) {
     KSR_CHECK_ARG(feat && x_img && feed_w && feed_b && out && knots, "feed_kan_fwd: null pointer");
+    KSR_CHECK_ARG(feat_ld >= 64 && feat_c0 >= 0 && feat_c0 + 64 <= feat_ld && feat_ld % 8 == 0 && feat_c0 % 8 == 0,
+                  "feed_kan_fwd: bad feature row layout (ld %d, first channel %d)", feat_ld, feat_c0);
+    KSR_CHECK_ARG(!per_image_weights || B <= 65535, "feed_kan_fwd: per-image weights take at most 65535 images");
     KSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "feed_kan_fwd: non-positive dimension");
     KSR_CHECK_ARG(n_knots == n_coef + spline_order + 1 && n_knots <= KSR_MAX_KNOTS, "feed_kan_fwd: bad knot count %d", n_knots);
     KSR_UNSUPPORTED(!ksr_feed_kan_supported(upscale, n_coef, spline_order),
@@ -417,6 +449,8 @@ extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t i
     FeedArgs a{};
     a.feat = feat; a.x_img = x_img; a.img_bstride = img_batch_stride; a.w = feed_w; a.bias = feed_b;
     a.out = out; a.out_bstride = out_batch_stride; a.save_us = save_us; a.B = B; a.H = H; a.W = W;
+    a.feat_ld = feat_ld; a.feat_c0 = feat_c0; a.w_bstride = per_image_weights ? (long)ksr_feed_kan_P(upscale, n_coef) * 64 : 0;
+    a.bias_bstride = 0;
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
@@ -426,17 +460,40 @@ extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t i
     return KSR_ERR_UNSUPPORTED;
 }
 
+extern "C" int ksr_feed_kan_fwd(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
+                                const float* feed_b, float* out, int64_t out_batch_stride, float* save_us, int B,
+                                int H, int W, int upscale, int n_coef, const float* knots, int n_knots,
+                                int spline_order, hipStream_t stream) {
+    return feed_kan_fwd_impl(feat, 64, 0, x_img, img_batch_stride, feed_w, 0, feed_b, out, out_batch_stride, save_us, B, H, W,
+                             upscale, n_coef, knots, n_knots, spline_order, stream);
+}
+
+// The same with one weight matrix PER IMAGE (feed_w [B][P][64]; the bias is shared) and the 64 features of a pixel at
+// channels feat_c0 .. feat_c0 + 63 of rows of feat_ld elements: the channel-attention head, whose last 1x1 map is the
+// per-image matrix M_b = W_a softmax(q^ k^T) applied to v (conv_sep_kan_attention.py:62-69), evaluated without the
+// [N, P] parameter tensor.
+extern "C" int ksr_feed_kan_fwd_img(const float* feat, int feat_ld, int feat_c0, const float* x_img, int64_t img_batch_stride,
+                                    const float* feed_w_per_image, const float* feed_b, float* out, int64_t out_batch_stride,
+                                    float* save_us, int B, int H, int W, int upscale, int n_coef, const float* knots,
+                                    int n_knots, int spline_order, hipStream_t stream) {
+    return feed_kan_fwd_impl(feat, feat_ld, feat_c0, x_img, img_batch_stride, feed_w_per_image, 1, feed_b, out, out_batch_stride,
+                             save_us, B, H, W, upscale, n_coef, knots, n_knots, spline_order, stream);
+}
+
 // Per-half padded length of the lane-ordered parameter gradient: gparam is [N, 2, this].
 extern "C" int ksr_feed_kan_lane_len(int upscale, int n_coef) {
     const int nh = (upscale * upscale / 2) * (n_coef + 2);
     return (nh + 15) / 16 * 16;
 }
 
-extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, const float* x_img,
-                                int64_t img_batch_stride, const float* feed_w, const float* save_us, float* gfeat,
-                                float* gparam, int B, int H, int W, int upscale, int n_coef, const float* knots,
-                                int n_knots, int spline_order, hipStream_t stream) {
+static int feed_kan_bwd_impl(const float* gout, int64_t gout_batch_stride, const float* x_img, int64_t img_batch_stride,
+                             const float* feed_w, int per_image_weights, const float* save_us, float* gfeat, int gfeat_ld,
+                             int gfeat_c0, float* gparam, int B, int H, int W, int upscale, int n_coef, const float* knots,
+                             int n_knots, int spline_order, hipStream_t stream) {
     KSR_CHECK_ARG(gout && x_img && feed_w && save_us && gfeat && gparam && knots, "feed_kan_bwd: null pointer");
+    KSR_CHECK_ARG(gfeat_ld >= 64 && gfeat_c0 >= 0 && gfeat_c0 + 64 <= gfeat_ld && gfeat_ld % 8 == 0 && gfeat_c0 % 8 == 0,
+                  "feed_kan_bwd: bad feature-gradient row layout (ld %d, first channel %d)", gfeat_ld, gfeat_c0);
+    KSR_CHECK_ARG(!per_image_weights || B <= 65535, "feed_kan_bwd: per-image weights take at most 65535 images");
     KSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "feed_kan_bwd: non-positive dimension");
     KSR_CHECK_ARG(n_knots == n_coef + spline_order + 1 && n_knots <= KSR_MAX_KNOTS, "feed_kan_bwd: bad knot count %d", n_knots);
     KSR_UNSUPPORTED(!ksr_feed_kan_supported(upscale, n_coef, spline_order), "feed_kan_bwd: configuration has no fused kernel");
@@ -444,6 +501,8 @@ extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, co
     FeedArgs a{};
     a.gout = gout; a.out_bstride = gout_batch_stride; a.x_img = x_img; a.img_bstride = img_batch_stride;
     a.w = feed_w; a.save_us = const_cast<float*>(save_us); a.gfeat = gfeat; a.gparam = gparam; a.B = B; a.H = H; a.W = W;
+    a.gfeat_ld = gfeat_ld; a.gfeat_c0 = gfeat_c0; a.feat_ld = 64;
+    a.w_bstride = per_image_weights ? (long)ksr_feed_kan_P(upscale, n_coef) * 64 : 0;
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
@@ -451,6 +510,24 @@ extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, co
     KSR_FEED_CONFIGS(KSR_X)
 #undef KSR_X
     return KSR_ERR_UNSUPPORTED;
+}
+
+extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, const float* x_img,
+                                int64_t img_batch_stride, const float* feed_w, const float* save_us, float* gfeat,
+                                float* gparam, int B, int H, int W, int upscale, int n_coef, const float* knots,
+                                int n_knots, int spline_order, hipStream_t stream) {
+    return feed_kan_bwd_impl(gout, gout_batch_stride, x_img, img_batch_stride, feed_w, 0, save_us, gfeat, 64, 0, gparam, B, H, W,
+                             upscale, n_coef, knots, n_knots, spline_order, stream);
+}
+
+// Backward of ksr_feed_kan_fwd_img: per-image weights; the feature gradient goes to channels gfeat_c0 .. + 63 of rows of
+// gfeat_ld elements (e.g. the v third of a [N,192] gradient tensor).
+extern "C" int ksr_feed_kan_bwd_img(const float* gout, int64_t gout_batch_stride, const float* x_img, int64_t img_batch_stride,
+                                    const float* feed_w_per_image, const float* save_us, float* gfeat, int gfeat_ld, int gfeat_c0,
+                                    float* gparam, int B, int H, int W, int upscale, int n_coef, const float* knots,
+                                    int n_knots, int spline_order, hipStream_t stream) {
+    return feed_kan_bwd_impl(gout, gout_batch_stride, x_img, img_batch_stride, feed_w_per_image, 1, save_us, gfeat, gfeat_ld,
+                             gfeat_c0, gparam, B, H, W, upscale, n_coef, knots, n_knots, spline_order, stream);
 }
 
 // gx[b, y, x] (images gx_batch_stride elements apart) = d(out)/d(luma) contracted with gout, through the KAN evaluation's
@@ -466,6 +543,7 @@ extern "C" int ksr_feed_kan_dx(const float* feat, const float* x_img, int64_t im
     FeedArgs a{};
     a.feat = feat; a.x_img = x_img; a.img_bstride = img_batch_stride; a.w = feed_w; a.bias = feed_b;
     a.gout = gout; a.out_bstride = gout_batch_stride; a.B = B; a.H = H; a.W = W;
+    a.feat_ld = 64; a.feat_c0 = 0;
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;

@@ -884,6 +884,34 @@ extern "C" int ksr_gram_batched(const float* dz, int dz_ld, int dz_c0, int J, co
     return launch_reduce(slab, (int)g, J, K, stride, out, K, 1, tail, 0, 0, 0, stream, Jp * K, tail_len, nb, (long)J * K);
 }
 
+// ksr_gram_batched for the fused feed+KAN kernel with per-image weights: dz = gparam [N, J] holds the gradient of the
+// per-pixel KAN parameters in that kernel's lane order (J = 2 * ksr_feed_kan_lane_len); the rows of the products are
+// scattered to the reference's channel numbering, padding rows dropped:
+//   out[e][p][k] = sum_n gparam[n][lane(p)] * a[n][k],  tail[e][p] = sum_n gparam[n][lane(p)]   (p < P = r^2 (n_coef + 2))
+extern "C" int ksr_gram_batched_kan(const float* gparam, int J, const float* a1, int a1_ld, int a1_c0, int K,
+                                    int64_t tokens_per_entry, int nb, float* slab, float* out, float* tail, int kan_upscale,
+                                    int kan_n_coef, hipStream_t stream) {
+    KSR_CHECK_ARG(gparam && a1 && slab && out && tail, "gram_batched_kan: null pointer");
+    KSR_CHECK_ARG(J > 0 && J % 32 == 0 && (K == 32 || K == 64), "gram_batched_kan: J must be a multiple of 32 and K 32 or 64");
+    KSR_CHECK_ARG(tokens_per_entry > 0 && nb > 0 && nb <= 65535, "gram_batched_kan: bad batch");
+    KSR_CHECK_ARG(kan_upscale > 0 && kan_n_coef > 0 && kan_upscale * kan_upscale / 2 * (kan_n_coef + 2) <= J / 2,
+                  "gram_batched_kan: J does not hold the parameters of upscale %d, n_coef %d", kan_upscale, kan_n_coef);
+    const int al = wgrad_align();
+    KSR_CHECK_ARG(a1_ld % al == 0 && a1_c0 % al == 0, "gram_batched_kan: leading dimension and channel offset must be multiples of %d", al);
+    const int NKB = K / 32, per_wave = (J / 32 + (4 / NKB) - 1) / (4 / NKB);
+    KSR_UNSUPPORTED(per_wave > WG_MAXP, "gram_batched_kan: J=%d too large", J);
+    const long stride = (long)J * K + 2 * J + K;
+    WgArgs a{gparam, J, 0, J, a1, a1_ld, a1_c0, K, nullptr, 0, 0, slab, (long)tokens_per_entry, J, 0, stride};
+    int T; size_t lds_bytes;
+    wgrad_shape(J + K, per_wave, &T, &lds_bytes);
+    KSR_UNSUPPORTED(lds_bytes > 160 * 1024, "gram_batched_kan: J=%d needs %zu bytes of LDS", J, lds_bytes);
+    const long g = gram_grid(J, K, nb, (long)tokens_per_entry);
+    if (int rc = launch_wgrad_kernel(a, per_wave, T, lds_bytes, (unsigned)g, (unsigned)nb, stream)) return rc;
+    const int P = kan_upscale * kan_upscale * (kan_n_coef + 2);
+    return launch_reduce(slab, (int)g, J, K, stride, out, K, 1, tail, kan_upscale * kan_upscale, kan_n_coef, J / 2, stream, J * K, J,
+                         nb, (long)P * K);
+}
+
 // out[0][c] = sum_n a[n][c]*b, out[1][c] = sum_n a[n][c] for 64 channels c; rows out_row_stride apart.
 // slab: 1024*128 floats.
 extern "C" int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b, int b_is_per_pixel_scalar, int64_t N,

@@ -8,12 +8,13 @@ out in {40, 64, 160, 336} have kernels; anything else raises KsrError.
 from __future__ import annotations
 
 from ctypes import c_int, c_int64
+from typing import Sequence
 
 import torch
 import torch.nn as nn
 
 from . import engine
-from ._lib import KsrError, check, lib, ptr, stream
+from ._lib import KsrError, check, host_floats, lib, ptr, stream
 
 SUPPORTED_OUT = (40, 64, 160, 336)
 
@@ -130,6 +131,70 @@ class _AttnCoreFn(torch.autograd.Function):
         return dqkv, g_wa, g_ba, None, None
 
 
+class _AttnKanFn(torch.autograd.Function):
+    """_AttnCoreFn followed by the KAN evaluation, pixel shuffle and chroma upsampling (conv_sep_kan.py:29-42 with the
+    attention head producing the per-pixel parameters), without the [N, P] parameter tensor: the head's last step is a 1x1
+    map with one matrix per image, M_b = W_a softmax(q^ k^T), which the fused feed+KAN kernel takes as per-image weights."""
+
+    @staticmethod
+    def forward(ctx, qkv, wa, ba, x, dims, precision, n_coef, knots, spline_order, r):
+        B, H, W = dims
+        HW = H * W
+        engine.set_precision(precision)
+        L = lib()
+        dev = qkv.device
+        P = wa.shape[0]
+        G, tail = _gram(qkv, 0, 64, qkv, 64, HW, B, True)
+        A, S, nrm, M = _new(dev, B, 64, 64), _new(dev, B, 64, 64), _new(dev, B, 128), _new(dev, B, P, 64)
+        check(L.ksr_chan_soft_fwd(ptr(G), ptr(tail), ptr(wa), ptr(A), ptr(S), ptr(nrm), ptr(M), c_int(P), c_int(B),
+                                  stream()), "ksr_chan_soft_fwd")
+        out = _new(dev, B, 3, H * r, W * r)
+        from .ops import bilinear_up_into
+        bilinear_up_into(x, out, r, 1, 2, 1)
+        save_us = _new(dev, B * HW, r * r, 2)
+        kn = host_floats(knots)
+        check(L.ksr_feed_kan_fwd_img(ptr(qkv), c_int(192), c_int(128), ptr(x), c_int64(3 * HW), ptr(M), ptr(ba), ptr(out),
+                                     c_int64(3 * HW * r * r), ptr(save_us), c_int(B), c_int(H), c_int(W), c_int(r), c_int(n_coef),
+                                     kn, c_int(len(knots)), c_int(spline_order), stream()), "ksr_feed_kan_fwd_img")
+        ctx.save_for_backward(qkv, wa, A, S, nrm, M, save_us, x)
+        ctx.cfg = (dims, precision, n_coef, knots, spline_order, r)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        qkv, wa, A, S, nrm, M, save_us, x = ctx.saved_tensors
+        (B, H, W), precision, n_coef, knots, spline_order, r = ctx.cfg
+        HW = H * W
+        if ctx.needs_input_grad[3]:
+            raise KsrError("gradient with respect to the input image is not implemented for the attention head")
+        engine.set_precision(precision)
+        L = lib()
+        dev = qkv.device
+        P = wa.shape[0]
+        gout = gout.contiguous()
+        J = 2 * int(L.ksr_feed_kan_lane_len(c_int(r), c_int(n_coef)))
+        gparam = _new(dev, B * HW, J)
+        dqkv = _new(dev, B * HW, 192)
+        kn = host_floats(knots)
+        # gradient of the per-pixel parameters (lane order) and, through M_b, of v: written into the v third of dqkv
+        check(L.ksr_feed_kan_bwd_img(ptr(gout), c_int64(3 * HW * r * r), ptr(x), c_int64(3 * HW), ptr(M), ptr(save_us), ptr(dqkv),
+                                     c_int(192), c_int(128), ptr(gparam), c_int(B), c_int(H), c_int(W), c_int(r), c_int(n_coef),
+                                     kn, c_int(len(knots)), c_int(spline_order), stream()), "ksr_feed_kan_bwd_img")
+        # per-image dM_b = dparam^T v and the column sums of dparam (bias gradient), rows back in channel order
+        slab = _new(dev, max(1, int(L.ksr_gram_slab_floats(c_int(J), c_int(64), c_int(B), c_int64(HW)))))
+        Gd, colsum = _new(dev, B, P, 64), _new(dev, B, J)
+        check(L.ksr_gram_batched_kan(ptr(gparam), c_int(J), ptr(qkv), c_int(192), c_int(128), c_int(64), c_int64(HW), c_int(B),
+                                     ptr(slab), ptr(Gd), ptr(colsum), c_int(r), c_int(n_coef), stream()), "ksr_gram_batched_kan")
+        g_ba = _new(dev, P)
+        check(L.ksr_sum_entries(ptr(colsum), c_int(B), c_int64(J), c_int(P), ptr(g_ba), stream()), "ksr_sum_entries")
+        Mqk, part, g_wa = _new(dev, B, 128, 128), _new(dev, B, P, 64), _new(dev, P, 64)
+        check(L.ksr_chan_soft_bwd(ptr(Gd), ptr(A), ptr(S), ptr(nrm), ptr(wa), ptr(Mqk), ptr(part), ptr(g_wa), c_int(P),
+                                  c_int(B), stream()), "ksr_chan_soft_bwd")
+        check(L.ksr_chan_apply(ptr(qkv), c_int(192), c_int(0), c_int(128), ptr(Mqk), c_int(0), ptr(None), ptr(dqkv),
+                               c_int(192), c_int(0), c_int(128), c_int(B), c_int(HW), stream()), "ksr_chan_apply")
+        return dqkv, g_wa, g_ba, None, None, None, None, None, None, None
+
+
 def _to_nhwc(t):
     B, C, H, W = t.shape
     return t.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
@@ -168,6 +233,26 @@ class ConvSepKanAttention(nn.Module):
             qkv = torch.cat(parts, dim=1)
         return _AttnCoreFn.apply(qkv, self.a_proj.weight.reshape(self.out_channels, 64), self.a_proj.bias, dims,
                                  self.precision)
+
+    def _qkv(self, x, dims):
+        w = torch.cat([getattr(self, n + "_proj").weight.reshape(64, 64) for n in "qkv"])
+        b = torch.cat([getattr(self, n + "_proj").bias for n in "qkv"])
+        dw_w = torch.cat([getattr(self, n + "_dw").weight.reshape(64, 9) for n in "qkv"])
+        dw_b = torch.cat([getattr(self, n + "_dw").bias for n in "qkv"])
+        return _QkvFn.apply(x.contiguous(), w, b, dw_w, dw_b, dims, self.precision)
+
+    def forward_kan(self, feat, dims, x_img, n_coef: int, knots: Sequence[float], spline_order: int, r: int):
+        """Head + KAN evaluation + pixel shuffle + chroma in one tape node chain: feat [N,64] (NHWC pixels of x_img
+        [B,3,H,W]) -> [B,3,rH,rW].  The [N, out] tensor of per-pixel KAN parameters is never formed (see _AttnKanFn).
+        Needs a fused feed+KAN kernel for (r, n_coef, spline_order): ksr_feed_kan_supported."""
+        if self.in_channels != 64 or self.mid_channels != 64 or self.out_channels != r * r * (n_coef + 2):
+            raise KsrError(f"ConvSepKanAttention({self.in_channels}, {self.mid_channels}, {self.out_channels}) does not produce "
+                           f"the parameters of a KAN cell with upscale {r} and {n_coef} coefficients")
+        if not feat.is_cuda or feat.dtype != torch.float32:
+            raise KsrError("ConvSepKanAttention needs fp32 GPU tensors (the HIP path is the only path)")
+        qkv = self._qkv(feat, dims)
+        return _AttnKanFn.apply(qkv, self.a_proj.weight.reshape(self.out_channels, 64), self.a_proj.bias, x_img.contiguous(),
+                                dims, self.precision, n_coef, tuple(knots), spline_order, r)
 
     def forward(self, x, q=None, k=None, v=None):
         B, C, H, W = x.shape

@@ -102,6 +102,11 @@ class ConvSepKanLayer(_Container):          # conv_sep_kan/conv_sep_kan_layer.py
         self.encoder = ConvSepKanEncoder(in_channels, self.kan_cell.size, attention, backbone)
 
 
+# cfg-4 wiring: evaluate the attention head's per-image 1x1 map inside the fused feed+KAN kernel (False: materialise the
+# [N, P] parameter tensor and run the stand-alone KAN cell, the first version of this path)
+FUSED_ATTENTION_HEAD = True
+
+
 class ConvSepKan(nn.Module):
     """Same constructor arguments as the reference; `kernel_sizes` and `residual_std` are accepted and
     unused there too.  forward(x[B,3,H,W]) -> [B,3,rH,rW] (Y', Cb, Cr).
@@ -191,5 +196,8 @@ class ConvSepKan(nn.Module):
                 feat = engine.encoder_forward(x, p, pre, g, None, p_drop, seed)
             if feat.dtype is not torch.float32:
                 feat = feat.float()
+            if FUSED_ATTENTION_HEAD:
+                # the head's last 1x1 map (one matrix per image) runs inside the fused feed+KAN kernel: no [N, P] tensor
+                return head.forward_kan(feat, (g.B, g.H, g.W), x, g.n_coef, g.knots, g.k, g.r)
             w = head.forward_nhwc(feat, (g.B, g.H, g.W))
             return kan_head(x, w, self.grid_size, self.spline_order, self.grid_range, self.upscale)

@@ -140,11 +140,16 @@ def test_bf16_mode():
     engine.set_precision("fp32")
 
 
-@pytest.mark.parametrize("r,G,B,H,W", [(4, 16, 2, 12, 20), (4, 5, 3, 16, 16), (2, 5, 1, 9, 33)])
-def test_model_with_attention_head(r, G, B, H, W):
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("r,G,B,H,W", [(4, 16, 2, 12, 20), (4, 5, 3, 16, 16), (2, 5, 1, 9, 33), (4, 16, 5, 16, 24)])
+def test_model_with_attention_head(r, G, B, H, W, fused, monkeypatch):
     """ConvSepKan(..., attention=True): encoder trunk -> ConvSepKanAttention(64, 64, P) -> KAN -> shuffle, against
-    the oracle built from the same reference-pinned pieces (the wiring itself is not in the reference)."""
+    the oracle built from the same reference-pinned pieces (the wiring itself is not in the reference).  fused: the
+    head's per-image 1x1 map inside the fused feed+KAN kernel (no [N, P] tensor); otherwise the tensor is materialised
+    and the stand-alone KAN cell evaluates it."""
+    from kan_sr import module as kmod
     from kan_sr.module import ConvSepKan
+    monkeypatch.setattr(kmod, "FUSED_ATTENTION_HEAD", fused)
     torch.manual_seed(40 + G)
     m = ConvSepKan([1], [r * r], [3], G, 3, 0.1, [-1, 1], r, attention=True).eval()
     with torch.no_grad():
