@@ -193,11 +193,13 @@ struct SoftBwdArgs {
     int P;
 };
 
-__global__ void __launch_bounds__(256) chan_soft_bwd_kernel(SoftBwdArgs a) {
+// One workgroup of 1024 threads per image (the batch is the only grid dimension: with 256 threads a batch of 64 images
+// left three quarters of the GPU's SIMDs without a wave).
+__global__ void __launch_bounds__(1024) chan_soft_bwd_kernel(SoftBwdArgs a) {
     __shared__ float As[64][65], Ss[64][65], dS[64][65];
     __shared__ float nq[64], nk[64], pq[64], pk[64], r[64], rp[64];
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int idx = tid; idx < 4096; idx += 256) {
+    for (int idx = tid; idx < 4096; idx += 1024) {
         As[idx >> 6][idx & 63] = a.A[(long)b * 4096 + idx];
         Ss[idx >> 6][idx & 63] = a.S[(long)b * 4096 + idx];
     }
@@ -208,14 +210,14 @@ __global__ void __launch_bounds__(256) chan_soft_bwd_kernel(SoftBwdArgs a) {
     }
     const float* Gd = a.Gd + (long)b * a.P * 64;
     // dA = W_a^T Gd
-    for (int idx = tid; idx < 4096; idx += 256) {
+    for (int idx = tid; idx < 4096; idx += 1024) {
         const int c = idx >> 6, cc = idx & 63;
         float acc = 0.f;
         for (int p = 0; p < a.P; ++p) acc += a.Wa[p * 64 + c] * Gd[p * 64 + cc];
         dS[c][cc] = acc;
     }
     __syncthreads();
-    {   // softmax derivative, row sums of dS * S
+    if (tid < 256) {   // softmax derivative, row sums of dS * S
         const int c = tid >> 2, part = tid & 3;
         float dot = 0.f;
 #pragma unroll
@@ -243,7 +245,7 @@ __global__ void __launch_bounds__(256) chan_soft_bwd_kernel(SoftBwdArgs a) {
     __syncthreads();
     // [dq | dk] = Mqk [q | k]
     float* Mqk = a.Mqk + (long)b * 16384;
-    for (int idx = tid; idx < 16384; idx += 256) {
+    for (int idx = tid; idx < 16384; idx += 1024) {
         const int o = idx >> 7, i = idx & 127;
         float v;
         if (o < 64) {
@@ -257,7 +259,7 @@ __global__ void __launch_bounds__(256) chan_soft_bwd_kernel(SoftBwdArgs a) {
         Mqk[idx] = v;
     }
     // dW_a contribution of this image: Gd A^T
-    for (int idx = tid; idx < a.P * 64; idx += 256) {
+    for (int idx = tid; idx < a.P * 64; idx += 1024) {
         const int p = idx >> 6, c = idx & 63;
         const float* g = Gd + p * 64;
         float acc = 0.f;
@@ -329,7 +331,7 @@ extern "C" int ksr_chan_soft_bwd(const float* Gd, const float* A, const float* S
                                  hipStream_t stream) {
     KSR_CHECK_ARG(Gd && A && S && nrm && a_proj_w && Mqk && dWa_part && dWa && n_out > 0 && B > 0, "chan_soft_bwd: bad argument");
     SoftBwdArgs a{Gd, A, S, nrm, a_proj_w, Mqk, dWa_part, n_out};
-    hipLaunchKernelGGL(chan_soft_bwd_kernel, dim3(B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(chan_soft_bwd_kernel, dim3(B), dim3(1024), 0, stream, a);
     KSR_LAUNCH_CHECK("chan_soft_bwd");
     const int n = n_out * 64;
     hipLaunchKernelGGL(sum_entries_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dWa_part, B, (long)n, n, dWa);
