@@ -262,8 +262,14 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; KSR_BENCH_SHARE_GPU=1 (rehearsals of the multi-rank path on a box with fewer GPUs) wraps the ranks
+    # around the visible devices instead of failing
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and os.environ.get("KSR_BENCH_SHARE_GPU") != "1":
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU of its own ({ndev} visible)")
+    local_dev = local_rank % max(ndev, 1)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     dist = None
     if world > 1:
         import torch.distributed as dist_
