@@ -45,10 +45,10 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
     # bf16 storage: the fn_2 (ffn2, ffn4) and ffn3.pointwise2 weight gradients are accumulated inside their data-gradient
     # kernels (ksr_gate_pw_bwd_wg / _v, ksr_pw2_bwd_wg), the in-projection's in ksr_in_proj_bwd_wg: they leave ksr_wgrad
     fused = act_bytes == 2
-    # ... and out_proj's in ksr_batch_tx_layer_bwd_out_wg
-    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64) + 128 * 64 + 64 * 64 + (0 if fused else 2 * 64 * 64 + 3 * 64 * 64 + 2 * 192 * 64)
-    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64)) + (128 + 64) + (64 + 64)
-                    + (0 if fused else 2 * (64 + 64) + 2 * 64 * 3 + (64 + 64) + 2 * (192 + 64)))
+    # ... out_proj's in ksr_batch_tx_layer_bwd_out_wg, ffn3.pointwise1's in ksr_pw1_bwd_wg
+    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64) + 128 * 64 + (0 if fused else 64 * 64 + 2 * 64 * 64 + 3 * 64 * 64 + 2 * 192 * 64)
+    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64)) + (128 + 64)
+                    + (0 if fused else (64 + 64) + 2 * (64 + 64) + 2 * 64 * 3 + (64 + 64) + 2 * (192 + 64)))
     lin_post = 2 * (64 * 64 + 64 * 32 + 32 * 64)
     models = {
         # forward
@@ -93,6 +93,7 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
                         ("hbm", 2 * (2 * 128 * 64 + 2 * 9 * 64), 2 * 1280 - 512, pk)),   # the stem call writes neither dx nor dt[:, 64:]
         "ksr_pw2_bwd": ("hbm", 2 * 64 * 64, 768, pk),
         "ksr_pw1_bwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 1024, pk),
+        "ksr_pw1_bwd_wg": ("hbm", 2 * 2 * 64 * 64 + 2 * 9 * 64, 768, pk),        # + pointwise1's weight gradient; dt3 not written
         "ksr_wgrad": ("hbm", 2 * wg_jk, wg_bytes, pk),
         "ksr_colreduce": ("hbm", 0, 3 * 260, pk),        # ffn1.pointwise2 only (three per-pixel-scalar reductions)
         "ksr_dwconv_wgrad": ("hbm", (2 if fused else 3) * 2 * 10 * 64, (2 if fused else 3) * 512, pk),

@@ -250,6 +250,11 @@ int ksr_gate_pw_bwd_wg(const float* dz, const float* fn2_w, const float* gate_sa
                        ksr_stream_t stream);
 int ksr_pw2_bwd_wg(const float* dy, const float* pw2_w, const float* operand_saved, float* ds, float* slab, float* dW,
                    float* db, int B, int H, int W, ksr_stream_t stream);
+/* ksr_pw1_bwd with ffn3.pointwise1's weight / bias gradient (dt^T y_saved) accumulated in the same pass (bf16 storage mode;
+ * the four 32 x 32 blocks of the product are split over the workgroup's four waves): dt, which only fed that product, is
+ * not written.  slab: ksr_fused_wgrad_slab_floats() floats. */
+int ksr_pw1_bwd_wg(const float* ds, const float* dw_w, const float* pw1_w, const float* y_saved, float* dz_prev, float* slab,
+                   float* dW, float* db, int B, int H, int W, ksr_stream_t stream);
 
 /* First gated block (ffn2, whose input is ffn1): variants of ksr_gate_pw_bwd(_wg), ksr_fn1_bwd (stem form with column sums)
  * and ksr_dwconv_wgrad that rebuild the saved tensor t [N,128] = relu(fn_1(ffn1(Y))) from the per-pixel scalar v_saved [N]

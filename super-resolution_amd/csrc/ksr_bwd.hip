@@ -49,8 +49,15 @@ static_assert(4 * KSR_XPOSE_FLOATS <= HALO_FLOATS, "transposers must fit in the 
 // AFF: the saved 128-channel tensor of the first gated block is not read but rebuilt from one scalar per pixel,
 // t[n][c] = relu(A[c] v[n] + B[c]) (see stem_gate_fwd_kernel): the value half in the GATE epilogue, the sign of the
 // gate half as the CONVT_G mask.
-template <int PREC, int KIN, int BPRO, int BEPI, bool WGF = false, bool AFF = false>
+// WGS: the same weight / bias gradient for the stencil instance <64, CONVT, SIGGRAD> (ffn3.pointwise1: dz = the
+// conv-transposed gradient, input = the sigmoid output the epilogue reads), whose registers cannot take the 64 accumulators
+// of the whole product: every wave writes its 32 pixels' operands as swizzled bf16 tiles into its slice of the (by then
+// free) halo area, and after a barrier wave w accumulates the 32 x 32 block (w >> 1, w & 1) over all 128 pixels of the tile
+// (16 accumulators, 8 matrix instructions).  dz_store is not written then.
+template <int PREC, int KIN, int BPRO, int BEPI, bool WGF = false, bool AFF = false, bool WGS = false>
 __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
+    static_assert(!WGS || (KIN == 64 && PREC == KSR_BF16S && BPRO == BPRO_CONVT && BEPI == BEPI_SIGGRAD && !WGF),
+                  "weight gradient split over the waves: the <64, CONVT, SIGGRAD> instance in bf16 storage mode");
     static_assert(!AFF || BEPI == BEPI_GATE || BPRO == BPRO_CONVT_G, "AFF replaces e2 (GATE) or mask_src (CONVT_G)");
     static_assert(!WGF || (KIN == 64 && PREC == KSR_BF16S && BPRO == BPRO_PLAIN && (BEPI == BEPI_GATE || BEPI == BEPI_RELUMASK)),
                   "fused weight gradient: 64 -> 64 convs, bf16 storage mode, no stencil prologue (register budget)");
@@ -108,6 +115,10 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     const bool col_sums = BEPI == BEPI_STEM && a.sums_slab != nullptr;
     KsrWgFused wgf;
     if constexpr (WGF) ksr_wgf_init(wgf);
+    f32x16 wgs_acc;          // WGS: block (wv >> 1, wv & 1) of dW over every pixel of the workgroup's tiles
+    float wgs_bias = 0.f;    // WGS, waves 0 and 2: sum of dz[.][32 (wv >> 1) + (lane & 31)] over the pixels of waves 2 (lane >> 5), + 1
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wgs_acc[q] = 0.f;
 
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         bool live;
@@ -226,12 +237,17 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
                 ksr_wgf_accumulate(xb, lane, d0, e, wgf);
             }
         }
+        uint4 wgs_e[4];          // WGS: the conv's input (the sigmoid output) as bf16, for the tile written below
         if (BEPI == BEPI_SIGGRAD || BEPI == BEPI_RESID_SIGGRAD) {
             float e[32];
             if constexpr (PRE_E1) ksr_co_finish<ST>(xb, lane, pf_e1, e);
             else ksr_load32_co<ST>(xb, a.e1, n0w, nvalid, a.e1_ld, a.e1_c0, lane, e);
 #pragma unroll
             for (int i = 0; i < 32; ++i) dA[i] = dA[i] * e[i] * (1.f - e[i]);
+            if constexpr (WGS) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wgs_e[q] = ksr_pack8(e + 8 * q);
+            }
         }
         if (BEPI == BEPI_GATE) {
             float gte[32], val[32], o2[32];
@@ -266,6 +282,65 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
         }
         if (a.out1) ksr_store32_co<ST, !AHEAD>(xb, a.out1, n0w, nvalid, a.out1_ld, a.out1_c0, lane, dA);
         if (AHEAD && tile + gridDim.x < ntiles) fetch_epi(tile + gridDim.x);
+        if constexpr (WGS) {
+            typedef short s16x4 __attribute__((ext_vector_type(4)));
+            union Op { s16x4 hv[2]; bf16x8 v; };
+            __bf16* tz = reinterpret_cast<__bf16*>(xb);
+            __bf16* ta = tz + 32 * 64;
+            ksr_wave_fence();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float d8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d8[j] = live ? dz[8 * q + j] : 0.f;      // pixels outside the image have no gradient
+                *reinterpret_cast<uint4*>(tz + ksr_wgf_off(tok, 4 * h + q)) = ksr_pack8(d8);
+                *reinterpret_cast<uint4*>(ta + ksr_wgf_off(tok, 4 * h + q)) = wgs_e[q];
+            }
+            __syncthreads();
+            const int g5 = lane >> 5, db = (lane >> 4) & 1, qq = (lane & 15) >> 2, p4 = lane & 3;
+            const int c2 = 2 * db + (p4 >> 1), jb = wv >> 1, kb = wv & 1;
+            auto tr = [&](const __bf16* tile, int row, int chunk) -> s16x4 {
+                return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4*)(tile + ksr_wgf_off(row, chunk) + 4 * (p4 & 1)));
+            };
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const __bf16* base = reinterpret_cast<const __bf16*>(sm.halo + w * KSR_XPOSE_FLOATS);
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const int r0 = 16 * st + 4 * g5 + qq;
+                    Op A, Bv;
+                    A.hv[0] = tr(base, r0, 4 * jb + c2); A.hv[1] = tr(base, r0 + 8, 4 * jb + c2);
+                    Bv.hv[0] = tr(base + 2048, r0, 4 * kb + c2); Bv.hv[1] = tr(base + 2048, r0 + 8, 4 * kb + c2);
+                    wgs_acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A.v, Bv.v, wgs_acc, 0, 0, 0);
+                }
+            }
+            if (kb == 0) {
+                const int ch = 32 * jb + (lane & 31);
+                float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    const __bf16* base = reinterpret_cast<const __bf16*>(sm.halo + (2 * g5 + w2) * KSR_XPOSE_FLOATS);
+#pragma unroll
+                    for (int r = 0; r < 32; r += 2) {
+                        s0 += (float)base[ksr_wgf_off(r, ch >> 3) + (ch & 7)];
+                        s1 += (float)base[ksr_wgf_off(r + 1, ch >> 3) + (ch & 7)];
+                    }
+                }
+                wgs_bias += s0 + s1;
+            }
+            // the barrier at the top of the next tile (or the one below) ends this phase
+        }
+    }
+    if constexpr (WGS) {
+        __syncthreads();
+        float* row = a.wg_slab + (long)blockIdx.x * KSR_WGF_ROW;
+        const int g5 = lane >> 5, jb = wv >> 1, kb = wv & 1;
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+            row[(32 * jb + (q & 3) + 8 * (q >> 2) + 4 * g5) * 64 + 32 * kb + (lane & 31)] = wgs_acc[q];
+        const float other = __shfl_xor(wgs_bias, 32, 64);
+        if (kb == 0 && g5 == 0) row[64 * 64 + 32 * jb + (lane & 31)] = wgs_bias + other;
     }
     if constexpr (WGF) ksr_wgf_finish(spatial ? sm.halo : sm.xpose, a.wg_slab + (long)blockIdx.x * KSR_WGF_ROW, tid, wgf);
     if (BEPI == BEPI_STEM && col_sums) {
@@ -543,6 +618,16 @@ int launch_dgrad_wgf(const BwdArgs& a, float* dW, float* db, hipStream_t s) {
     return ksr_slab_reduce(a.wg_slab, (int)grid, 64, 64, dW, db, s);
 }
 
+// <64, CONVT, SIGGRAD> with the 1x1 conv's weight gradient split over the waves, then the reduction of the partial rows.
+int launch_dgrad_wgs(const BwdArgs& a, float* dW, float* db, hipStream_t s) {
+    KSR_CHECK_ARG(a.wg_slab && dW && db, "fused weight gradient: null pointer");
+    KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "fused weight gradient: bf16 storage mode only (the other modes use ksr_wgrad)");
+    const unsigned grid = dgrad_grid(a, true);
+    hipLaunchKernelGGL((dgrad_kernel<KSR_BF16S, 64, BPRO_CONVT, BEPI_SIGGRAD, false, false, true>), dim3(grid), dim3(256), 0, s, a);
+    KSR_LAUNCH_CHECK("dgrad(weight gradient split over the waves)");
+    return ksr_slab_reduce(a.wg_slab, (int)grid, 64, 64, dW, db, s);
+}
+
 template <int KIN, int BPRO, int BEPI, bool AFF = false>
 int launch_dgrad(const BwdArgs& a, hipStream_t s) {
 #define KSR_CALL(P) return launch_dgrad_p<P, KIN, BPRO, BEPI, AFF>(a, s)
@@ -629,6 +714,18 @@ extern "C" int ksr_pw1_bwd(const float* ds, const float* dw_w, const float* pw1_
     a.halo_src = ds; a.dw_w = dw_w; a.dz_store = dt; a.dz_store_ld = 64; a.dz_store_c0 = 0; a.wt = pw1_w;
     a.e1 = y_saved; a.e1_ld = 64; a.out1 = dz_prev; a.out1_ld = 64; a.B = B; a.H = H; a.W = W;
     return launch_dgrad<64, BPRO_CONVT, BEPI_SIGGRAD>(a, stream);
+}
+
+// ksr_pw1_bwd with pointwise1's weight / bias gradient (dt^T y_saved) accumulated in the same pass (bf16 storage mode): dt,
+// which only fed that product, is not written.  slab: ksr_fused_wgrad_slab_floats() floats of workspace.
+extern "C" int ksr_pw1_bwd_wg(const float* ds, const float* dw_w, const float* pw1_w, const float* y_saved, float* dz_prev,
+                              float* slab, float* dW, float* db, int B, int H, int W, hipStream_t stream) {
+    KSR_CHECK_ARG(ds && dw_w && pw1_w && y_saved && dz_prev, "pw1_bwd_wg: null pointer");
+    if (int rc = dims_ok(B, H, W, "pw1_bwd_wg")) return rc;
+    BwdArgs a{};
+    a.halo_src = ds; a.dw_w = dw_w; a.wt = pw1_w; a.e1 = y_saved; a.e1_ld = 64; a.out1 = dz_prev; a.out1_ld = 64;
+    a.wg_slab = slab; a.B = B; a.H = H; a.W = W;
+    return launch_dgrad_wgs(a, dW, db, stream);
 }
 
 // QKV projection backward + residual: ds = resid + dqkv * W_in, optionally followed by the sigmoid

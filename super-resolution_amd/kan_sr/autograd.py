@@ -426,11 +426,17 @@ def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, t
     grads[q + "pointwise2.weight"], grads[q + "pointwise2.bias"] = gw, gb
     grads[q + "depthwise.weight"], grads[q + "depthwise.bias"] = _dwconv_wgrad(ws, sv["t3"], 64, 0, ds4, g,
                                                                              q + "depthwise.weight", q + "depthwise.bias")
-    dt3, dz2 = ws.act(N, 64), ws.act(N, 64)
-    check(L.ksr_pw1_bwd(ptr(ds4), ptr(p[q + "depthwise.weight"]), ptr(p[q + "pointwise1.weight"]), ptr(sv["x3"]),
-                        ptr(dt3), ptr(dz2), *_dims(g), stream()), "ksr_pw1_bwd")
+    dz2 = ws.act(N, 64)
     gw, gb = ws.grad(q + "pointwise1.weight", 64, 64, 1, 1), ws.grad(q + "pointwise1.bias", 64)
-    _wgrad(ws, dt3, 64, 0, 64, sv["x3"], 64, 0, 64, N, gw, gb)
+    if ws.fused_wgrad():
+        # bf16 storage: pointwise1's weight gradient inside the kernel (the conv-transposed gradient dt3 is not written)
+        check(L.ksr_pw1_bwd_wg(ptr(ds4), ptr(p[q + "depthwise.weight"]), ptr(p[q + "pointwise1.weight"]), ptr(sv["x3"]),
+                               ptr(dz2), ptr(ws.fused_slab()), ptr(gw), ptr(gb), *_dims(g), stream()), "ksr_pw1_bwd_wg")
+    else:
+        dt3 = ws.act(N, 64)
+        check(L.ksr_pw1_bwd(ptr(ds4), ptr(p[q + "depthwise.weight"]), ptr(p[q + "pointwise1.weight"]), ptr(sv["x3"]),
+                            ptr(dt3), ptr(dz2), *_dims(g), stream()), "ksr_pw1_bwd")
+        _wgrad(ws, dt3, 64, 0, 64, sv["x3"], 64, 0, 64, N, gw, gb)
     grads[q + "pointwise1.weight"], grads[q + "pointwise1.bias"] = gw, gb
     # ---- ffn2 (gated) + ffn1 ----
     _gated_backward(ws, dz2, "ffn2", p, pre, g, sv["t2"], sv["g2"], grads, None, stem_saves=sv["v"], x_img=x, stem_ab=sv["ab"])

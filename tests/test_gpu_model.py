@@ -578,6 +578,23 @@ def test_fused_weight_gradient_equals_separate_wgrad(B, H, W):
         dW2, db2 = torch.empty_like(dW1), torch.empty_like(db1)
         check(L.ksr_pw2_bwd_wg(ptr(dz), ptr(w), ptr(a4), ptr(ds1), ptr(slab), ptr(dW2), ptr(db2), *dims, stream()), "pw2_bwd_wg")
         assert torch.equal(dW1, dW2) and torch.equal(db1, db2)
+        # ---- FFN pointwise1 (stencil prologue; the product's blocks split over the four waves)
+        dww = torch.randn(64, 9, device="cuda") * 0.3
+        y3 = torch.rand(N, 64, device="cuda").bfloat16()
+        dt0 = torch.empty(N, 64, device="cuda").bfloat16()
+        dp0, dp1 = torch.empty(N, 64, device="cuda").bfloat16(), torch.full((N, 64), float("nan"), device="cuda").bfloat16()
+        check(L.ksr_pw1_bwd(ptr(dz), ptr(dww), ptr(w), ptr(y3), ptr(dt0), ptr(dp0), *dims, stream()), "pw1_bwd")
+        check(L.ksr_wgrad(ptr(dt0), c_int(64), c_int(0), c_int(64), ptr(y3), c_int(64), c_int(0), c_int(64), None, c_int(0), c_int(0),
+                          c_int64(N), ptr(ws), ptr(dW0), ptr(db0), c_int(0), c_int(0), stream()), "wgrad")
+        check(L.ksr_pw1_bwd_wg(ptr(dz), ptr(dww), ptr(w), ptr(y3), ptr(dp1), ptr(slab), ptr(dW1), ptr(db1), *dims, stream()), "pw1_bwd_wg")
+        assert torch.equal(dp0, dp1)
+        # both products see the conv-transposed gradient rounded to bf16 (as stored / as written to the LDS tile)
+        assert rel_l2(dW1.cpu(), (dt0.double().T @ y3.double()).cpu()) <= 1e-5
+        assert rel_l2(dW1.cpu(), dW0.cpu()) <= 1e-5
+        assert rel_l2(db1.cpu(), dt0.double().sum(0).cpu()) <= 1e-5 and rel_l2(db1.cpu(), db0.cpu()) <= 1e-5
+        dW2, db2 = torch.empty_like(dW1), torch.empty_like(db1)
+        check(L.ksr_pw1_bwd_wg(ptr(dz), ptr(dww), ptr(w), ptr(y3), ptr(dp1), ptr(slab), ptr(dW2), ptr(db2), *dims, stream()), "pw1_bwd_wg")
+        assert torch.equal(dW1, dW2) and torch.equal(db1, db2)
         engine.set_precision("fp32")
         rc = L.ksr_pw2_bwd_wg(ptr(dz), ptr(w), ptr(a4), ptr(ds1), ptr(slab), ptr(dW2), ptr(db2), *dims, stream())
         assert rc == -2
