@@ -643,6 +643,48 @@ __global__ void __launch_bounds__(256) bilinear_up_kernel(BilArgs a) {
     *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// The same values from a (64, 4) workgroup on a (column blocks, row blocks, image x plane) grid: a thread owns 4 output
+// columns of the R output rows of one source row (no index divisions; the R float4 stores of a wave row are 1 KB
+// contiguous each).  The expression per output is the one above, term for term.
+template <int R>
+__global__ void __launch_bounds__(256) bilinear_up_rows_kernel(BilArgs a) {
+    const int OW = a.W * R, OW4 = OW / 4;
+    const int x4 = blockIdx.x * 64 + threadIdx.x, ys = blockIdx.y * 4 + threadIdx.y;
+    if (x4 >= OW4 || ys >= a.H) return;
+    const int b = blockIdx.z / a.nc, c = blockIdx.z - b * a.nc;
+    const float sc = 1.0f / (float)R;
+    const float* p = a.in + (long)b * a.in_bstride + (long)(a.ic0 + c) * a.in_cstride;
+    int x0[4], x1[4];
+    float lx0[4], lx1[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int ox = x4 * 4 + e;
+        float sx = sc * ((float)ox + 0.5f) - 0.5f;
+        sx = sx < 0.f ? 0.f : sx;
+        x0[e] = (int)sx;
+        x1[e] = x0[e] + (x0[e] < a.W - 1 ? 1 : 0);
+        lx1[e] = sx - (float)x0[e];
+        lx0[e] = 1.f - lx1[e];
+    }
+    float* o = a.out + (long)b * a.out_bstride + (long)(a.oc0 + c) * a.out_cstride + (long)ys * R * OW + x4 * 4;
+#pragma unroll
+    for (int ry = 0; ry < R; ++ry) {
+        const int oy = ys * R + ry;
+        float sy = sc * ((float)oy + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        const int y0 = (int)sy;
+        const int y1 = y0 + (y0 < a.H - 1 ? 1 : 0);
+        const float ly1 = sy - (float)y0, ly0 = 1.f - ly1;
+        const float* r0 = p + (long)y0 * a.W;
+        const float* r1 = p + (long)y1 * a.W;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = ly0 * (lx0[e] * r0[x0[e]] + lx1[e] * r0[x1[e]]) + ly1 * (lx0[e] * r1[x0[e]] + lx1[e] * r1[x1[e]]);
+        *reinterpret_cast<float4*>(o + (long)ry * OW) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // Adjoint of bilinear_up_kernel: a.in = gradient of the upsampled planes, a.out = gradient of the source planes
 // (in / out keep the forward's roles in BilArgs: `out` strides describe the r x larger tensor).  Gather form: every
 // source pixel visits the upsampled pixels whose footprint can contain it and re-derives their weights.
@@ -872,7 +914,12 @@ extern "C" int ksr_bilinear_up(const float* in, float* out, int B, int n_channel
     a.ic0 = in_channel0; a.oc0 = out_channel0;
     const bool vec = ((W * r) % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                      (out_batch_stride % 4 == 0);
-    if (vec) {
+    const long planes = (long)B * n_channels;
+    if (vec && (r == 2 || r == 4) && planes <= 65535 && (H + 3) / 4 <= 65535) {
+        const dim3 grid((unsigned)((W * r / 4 + 63) / 64), (unsigned)((H + 3) / 4), (unsigned)planes), block(64, 4);
+        if (r == 4) hipLaunchKernelGGL(bilinear_up_rows_kernel<4>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(bilinear_up_rows_kernel<2>, grid, block, 0, stream, a);
+    } else if (vec) {
         const long total = (long)B * n_channels * (H * r) * (long)(W * r / 4);
         hipLaunchKernelGGL(bilinear_up_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     } else {
