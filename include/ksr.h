@@ -337,11 +337,14 @@ int ksr_ssim_y_grad(const float* maps, const float* pred, int64_t pred_batch_str
 /* Both terms of the reference's loss gradient (src/ml/pipelines/default.py:79-81) in one pass over the luma planes:
  * grad[b, y, x] = l1_grad_scale * sign(pred - tgt) / (B*H*W) + scale * d(SSIM sum)/d pred (written, not accumulated)
  * and l1_out[0] = mean |pred[:, 0] - tgt[:, 0]|: ksr_l1_y_loss followed by ksr_ssim_y_grad without the second read of
- * the planes.  l1_slab: ksr_ssim_l1_slab_floats(B, H, W) floats of workspace. */
+ * the planes.  l1_slab: ksr_ssim_l1_slab_floats(B, H, W) floats of workspace.  loss_out (optional; ssim_value is then the
+ * device scalar ksr_ssim_fwd wrote): loss_out[0] = l1_out[0] + ssim_weight * (1 - ssim_value[0]), the loss of
+ * default.py:79-81, each operation rounded to fp32 on its own. */
 int64_t ksr_ssim_l1_slab_floats(int B, int H, int W);
 int ksr_ssim_y_grad_l1(const float* maps, const float* pred, int64_t pred_batch_stride, const float* tgt,
                        int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W, float scale,
-                       float l1_grad_scale, float* l1_slab, float* l1_out, ksr_stream_t stream);
+                       float l1_grad_scale, float* l1_slab, float* l1_out, const float* ssim_value, float ssim_weight,
+                       float* loss_out, ksr_stream_t stream);
 
 /* The fused feed + KAN kernels with ONE WEIGHT MATRIX PER IMAGE (feed_w_per_image [B][P][64], P = r^2 (n_coef + 2); the
  * bias [P] is shared) and the pixel's 64 features at channels feat_c0 .. feat_c0 + 63 of rows of feat_ld elements.  This

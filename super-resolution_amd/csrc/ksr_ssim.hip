@@ -175,7 +175,11 @@ __global__ void __launch_bounds__(SV_T) ssim_fwd_cols_kernel(SsimArgs a, SsimWin
 
 // One workgroup: strided partial sums in double, a butterfly inside each wave, then the 16 wave sums in order
 // (deterministic).
-__global__ void __launch_bounds__(1024) ssim_finish_kernel(const float* slab, long G, double scale, float* out) {
+// With loss_out: loss_out[0] = out[0] + ssim_weight * (1 - ssim[0]), every operation rounded on its own (the sum a training
+// loop would otherwise form from the two one-element tensors).
+__global__ void __launch_bounds__(1024) ssim_finish_kernel(const float* slab, long G, double scale, float* out,
+                                                            const float* ssim = nullptr, float ssim_weight = 0.f,
+                                                            float* loss_out = nullptr) {
     __shared__ double part[16];
     double s = 0.0;
     for (long i = threadIdx.x; i < G; i += 1024) s += (double)slab[i];
@@ -187,7 +191,9 @@ __global__ void __launch_bounds__(1024) ssim_finish_kernel(const float* slab, lo
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) t += part[w];
-        out[0] = (float)(t * scale);
+        const float v = (float)(t * scale);
+        out[0] = v;
+        if (loss_out) loss_out[0] = __fadd_rn(v, __fmul_rn(__fsub_rn(1.0f, ssim[0]), ssim_weight));
     }
 }
 
@@ -386,11 +392,14 @@ extern "C" int64_t ksr_ssim_l1_slab_floats(int B, int H, int W) {
 
 // ksr_l1_y_loss and ksr_ssim_y_grad in one pass over the luma planes: grad[b, y, x] = l1_grad_scale * sign(pred - tgt) /
 // (B H W) + scale * dSSIM_sum/dpred (written, not accumulated), l1_out[0] = mean |pred - tgt|.
-// l1_slab: ksr_ssim_l1_slab_floats(B, H, W) floats of workspace.
+// l1_slab: ksr_ssim_l1_slab_floats(B, H, W) floats of workspace.  loss_out (optional, with ssim_value = the device scalar
+// ksr_ssim_fwd wrote): loss_out[0] = l1_out[0] + ssim_weight * (1 - ssim_value[0]).
 extern "C" int ksr_ssim_y_grad_l1(const float* maps, const float* pred, int64_t pred_batch_stride, const float* tgt,
                                   int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W,
-                                  float scale, float l1_grad_scale, float* l1_slab, float* l1_out, hipStream_t stream) {
+                                  float scale, float l1_grad_scale, float* l1_slab, float* l1_out, const float* ssim_value,
+                                  float ssim_weight, float* loss_out, hipStream_t stream) {
     KSR_CHECK_ARG(maps && pred && tgt && grad && l1_slab && l1_out && B > 0, "ssim_y_grad_l1: bad argument");
+    KSR_CHECK_ARG(!loss_out || ssim_value, "ssim_y_grad_l1: loss_out needs ssim_value");
     KSR_CHECK_ARG(H > 2 * SS_R && W > 2 * SS_R, "ssim_y_grad_l1: the image must be larger than the 11 x 11 window");
     SsimWin w;
     fill_window(w);
@@ -401,7 +410,8 @@ extern "C" int ksr_ssim_y_grad_l1(const float* maps, const float* pred, int64_t 
     KSR_CHECK_ARG((long)tiles * B < (1L << 31), "ssim_y_grad_l1: too many tiles for one launch");
     hipLaunchKernelGGL(ssim_grad_kernel<true>, dim3(tiles * B), dim3(256), 0, stream, a, w);
     KSR_LAUNCH_CHECK("ssim_y_grad_l1");
-    hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, l1_slab, (long)tiles * B, 1.0 / numel, l1_out);
+    hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, l1_slab, (long)tiles * B, 1.0 / numel, l1_out,
+                       ssim_value, ssim_weight, loss_out);
     KSR_LAUNCH_CHECK("ssim_y_grad_l1(finish)");
     return KSR_OK;
 }

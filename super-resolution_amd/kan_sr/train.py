@@ -185,6 +185,7 @@ class TrainStep:
         self.side = torch.cuda.Stream(device=dev) if self.comm is not None else None
         self.slab = torch.empty(256, device=dev, dtype=torch.float32)
         self._l1 = torch.zeros(1, device=dev, dtype=torch.float32)
+        self._total = torch.zeros(1, device=dev, dtype=torch.float32)
         self.loss = self._l1
         self.last_seed = 0
 
@@ -397,9 +398,9 @@ class TrainStep:
         # both terms' gradient in one pass over the luma planes (the SSIM forward's finish kernel has consumed slab)
         check(L.ksr_ssim_y_grad_l1(ptr(maps), ptr(out), c_int64(3 * plane), ptr(tgt), c_int64(tgt.shape[1] * plane), ptr(gy),
                                    c_int64(gy_stride), c_int(B), c_int(Hh), c_int(Wh), c_float(scale), c_float(1.0), ptr(slab),
-                                   ptr(self._l1), stream()), "ksr_ssim_y_grad_l1")
+                                   ptr(self._l1), ptr(val), c_float(0.15), ptr(self._total), stream()), "ksr_ssim_y_grad_l1")
         self.ssim = val
-        self.loss = self._l1 + (1.0 - val) * 0.15           # one-element tensors
+        self.loss = self._total             # = l1 + 0.15 (1 - ssim), formed by the kernel that finishes the L1 sum
 
     def set_epoch(self, epoch: int, T_0: int = 500, eta_min: float = 1e-5) -> float:
         """Applies the reference's CosineAnnealingWarmRestarts schedule for `epoch` and returns the new lr."""

@@ -189,12 +189,13 @@ def test_ssim_kernels_vs_oracle(B, H, W):
     pred2 = pred.detach().clone().requires_grad_()
     (torch.nn.functional.l1_loss(pred2[:, :1], tgt[:, :1]) + wgt * (1.0 - orc.ssim(pred2, tgt))).backward()
     g2 = torch.full((B, plane), 3.0, device="cuda")
-    l1 = torch.zeros(1, device="cuda")
+    l1, total = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
     slab2 = torch.empty(int(L.ksr_ssim_l1_slab_floats(c_int(B), c_int(H), c_int(W))), device="cuda")
     check(L.ksr_ssim_y_grad_l1(ptr(maps), ptr(p), c_int64(3 * plane), ptr(t_), c_int64(3 * plane), ptr(g2), c_int64(plane), c_int(B),
                                c_int(H), c_int(W), c_float(-wgt / (B * 3 * (H - 10) * (W - 10))), c_float(1.0), ptr(slab2), ptr(l1),
-                               stream()), "ssim_y_grad_l1")
+                               ptr(out), c_float(wgt), ptr(total), stream()), "ssim_y_grad_l1")
     assert abs(float(l1) - float(torch.nn.functional.l1_loss(pred[:, :1], tgt[:, :1]))) <= 1e-6
+    assert torch.equal(total, l1 + (1.0 - out) * wgt)            # the sum two one-element tensors would give
     assert rel_l2(g2.cpu(), pred2.grad[:, 0].reshape(B, plane)) <= 1e-5
 
 
