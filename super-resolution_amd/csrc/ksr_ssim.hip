@@ -36,8 +36,9 @@ __device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 
 constexpr int SS_RUN = 8, SS_RUNS = SS_T / SS_RUN, SS_SPAN = SS_RUN + SS_K - 1;   // 4 runs, 18 inputs each
 
 // ---------------------------------------------------------------------------------------------------------------
-// Forward, column-first.  A workgroup of 192 threads owns a strip of <= 192 input columns (<= 182 window columns) and a
-// band of 122 window rows, and walks down the band: thread = input column.  VERTICAL pass in registers: an input row
+// Forward, column-first.  A workgroup of 128 threads owns a strip of <= 128 input columns (<= 118 window columns) and a
+// band of window rows (the whole height whenever strips x planes alone fill the chip: no row is then filtered twice),
+// and walks down the band: thread = input column.  VERTICAL pass in registers: an input row
 // adds g[k] * (p, t, pp, tt, pt) to the running sums of the 11 window rows it belongs to (scatter form; the sums rotate
 // through 11 register sets, the loop over an 11-row batch is unrolled so that every index is static; the tap that
 // starts a window row overwrites its set) and completes one window row, whose five column sums go to LDS.  HORIZONTAL
@@ -46,15 +47,16 @@ constexpr int SS_RUN = 8, SS_RUNS = SS_T / SS_RUN, SS_SPAN = SS_RUN + SS_K - 1; 
 // pixels are requested before the horizontal pass.  Against the tile version (32 x 32 windows from 42 x 42 pixels,
 // filter passes that keep 3 and 2 of 4 waves busy): no rows are filtered twice, 6 % of the columns are, every thread
 // works in both passes.
-constexpr int SV_T = 192;
+constexpr int SV_T = 128;                       // two waves: four workgroups give every SIMD of a CU its two waves (three-wave
+                                                // workgroups left two of the four SIMDs with one, and the kernel is bound by
+                                                // vector-instruction issue)
 constexpr int SV_WO = SV_T - (SS_K - 1);        // window columns per strip at most
 constexpr int SV_R = SS_K;                      // input rows per batch
-constexpr int SV_BH = SS_K * SS_K + 1;          // window rows per band: 12 batches of input rows
 constexpr int SV_RUN = 11, SV_SPAN = SV_RUN + SS_K - 1;
 constexpr int SV_V1_LD = SV_T + 16;             // pitch of the e12 rows: the 4 batch rows of a wave fall on different banks
-constexpr int SV_GRID = 256 * 2;                // persistent workgroups: two fit a CU (registers)
+constexpr int SV_GRID = 256 * 4;                // persistent workgroups: four fit a CU (registers)
 
-__global__ void __launch_bounds__(SV_T) ssim_fwd_cols_kernel(SsimArgs a, SsimWin w, int ns, int wo, int nb) {
+__global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, SsimWin w, int ns, int wo, int nb, int bh) {
     __shared__ float4 v4[SV_R][SV_T];            // (mu_p, mu_t, E[pp], E[tt]) column sums of a batch's window rows
     __shared__ float v1[SV_R][SV_V1_LD];         // E[pt]
     __shared__ float red[SV_T / 64];
@@ -69,8 +71,8 @@ __global__ void __launch_bounds__(SV_T) ssim_fwd_cols_kernel(SsimArgs a, SsimWin
     float sum = 0.f;
     for (int t = t_begin; t < t_end; ++t) {
         const int strip = t % ns, band = (t / ns) % nb, c = (t / (ns * nb)) % a.C, b = t / (ns * nb * a.C);
-        const int x0 = strip * wo, y0 = band * SV_BH;
-        const int xo_end = min(Wi, x0 + wo), yo_end = min(Hi, y0 + SV_BH);      // windows [y0, yo_end) x [x0, xo_end)
+        const int x0 = strip * wo, y0 = band * bh;
+        const int xo_end = min(Wi, x0 + wo), yo_end = min(Hi, y0 + bh);      // windows [y0, yo_end) x [x0, xo_end)
         const int y_in_end = yo_end + SS_K - 1;                                  // input rows [y0, y_in_end)
         const int nbatch = (y_in_end - y0 + SV_R - 1) / SV_R;
         const int col = x0 + tid;
@@ -170,7 +172,12 @@ __global__ void __launch_bounds__(SV_T) ssim_fwd_cols_kernel(SsimArgs a, SsimWin
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) a.slab[blockIdx.x] = red[0] + red[1] + red[2];
+    if (threadIdx.x == 0) {
+        float s = red[0];
+#pragma unroll
+        for (int i = 1; i < SV_T / 64; ++i) s += red[i];
+        a.slab[blockIdx.x] = s;
+    }
 }
 
 // One workgroup: strided partial sums in double, a butterfly inside each wave, then the 16 wave sums in order
@@ -355,11 +362,15 @@ extern "C" int ksr_ssim_fwd(const float* pred, int64_t pred_batch_stride, const 
     fill_window(w);
     SsimArgs a{pred, (long)pred_batch_stride, tgt, (long)tgt_batch_stride, maps, slab, C, B, H, W};
     const int Hi = H - 2 * SS_R, Wi = W - 2 * SS_R;
-    // strips of equal width (<= 182 window columns), bands of 122 window rows
-    const int ns = (Wi + SV_WO - 1) / SV_WO, wo = (Wi + ns - 1) / ns, nb = (Hi + SV_BH - 1) / SV_BH;
+    // strips of equal width (<= 118 window columns); bands of equal height, as few as give every workgroup slot a task
+    // (a band re-filters the 10 rows above it), at least 23 window rows (three batches of input rows) each
+    const int ns = (Wi + SV_WO - 1) / SV_WO, wo = (Wi + ns - 1) / ns;
+    int nb = 1;
+    while ((long)ns * nb * C * B < SV_GRID * 9 / 10 && Hi / (nb + 1) >= 2 * SS_K + 1) ++nb;
+    const int bh = (Hi + nb - 1) / nb;
     KSR_CHECK_ARG((long)ns * nb * C * B < (1L << 31), "ssim_fwd: too many strips for one launch");
     const unsigned grid = (unsigned)std::min<long>((long)ns * nb * C * B, SV_GRID);
-    hipLaunchKernelGGL(ssim_fwd_cols_kernel, dim3(grid), dim3(SV_T), 0, stream, a, w, ns, wo, nb);
+    hipLaunchKernelGGL(ssim_fwd_cols_kernel, dim3(grid), dim3(SV_T), 0, stream, a, w, ns, wo, nb, bh);
     KSR_LAUNCH_CHECK("ssim_fwd");
     hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, slab, (long)grid,
                        1.0 / ((double)B * C * Hi * Wi), ssim_out);
