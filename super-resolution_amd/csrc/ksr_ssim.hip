@@ -54,10 +54,12 @@ constexpr int SV_WO = SV_T - (SS_K - 1);        // window columns per strip at m
 constexpr int SV_R = SS_K;                      // input rows per batch
 constexpr int SV_RUN = 11, SV_SPAN = SV_RUN + SS_K - 1;
 constexpr int SV_V1_LD = SV_T + 16;             // pitch of the e12 rows: the 4 batch rows of a wave fall on different banks
+static_assert(((SV_WO + SV_RUN - 1) / SV_RUN - 1) * SV_RUN + SV_SPAN <= SV_V1_LD, "the last run's columns stay inside a padded row");
 constexpr int SV_GRID = 256 * 4;                // persistent workgroups: four fit a CU (registers)
 
 __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, SsimWin w, int ns, int wo, int nb, int bh) {
-    __shared__ float4 v4[SV_R][SV_T];            // (mu_p, mu_t, E[pp], E[tt]) column sums of a batch's window rows
+    __shared__ float4 v4[SV_R][SV_V1_LD];        // (mu_p, mu_t, E[pp], E[tt]) column sums of a batch's window rows; the 16
+                                                 // columns of padding are only read for windows past the strip
     __shared__ float v1[SV_R][SV_V1_LD];         // E[pt]
     __shared__ float red[SV_T / 64];
     const int Hi = a.H - 2 * SS_R, Wi = a.W - 2 * SS_R;
@@ -75,18 +77,19 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
         const int xo_end = min(Wi, x0 + wo), yo_end = min(Hi, y0 + bh);      // windows [y0, yo_end) x [x0, xo_end)
         const int y_in_end = yo_end + SS_K - 1;                                  // input rows [y0, y_in_end)
         const int nbatch = (y_in_end - y0 + SV_R - 1) / SV_R;
-        const int col = x0 + tid;
-        const bool col_in = col < xo_end + SS_K - 1;
-        const float* P = a.pred + (long)b * a.pred_bs + (long)c * plane + col;
-        const float* T = a.tgt + (long)b * a.tgt_bs + (long)c * plane + col;
+        // uniform row pointers + the thread's column as an unsigned 32-bit offset: the address form with a scalar base.
+        // Rows past the band and columns past the strip are clamped into the plane and loaded like the others: they
+        // only reach window rows / windows that are never evaluated.
+        const float* P = a.pred + (long)b * a.pred_bs + (long)c * plane + x0;
+        const float* T = a.tgt + (long)b * a.tgt_bs + (long)c * plane + x0;
+        const unsigned tcol = (unsigned)(min(x0 + tid, a.W - 1) - x0);
         float pv[SV_R], tv[SV_R];
         auto fetch = [&](int m) {
 #pragma unroll
             for (int rr = 0; rr < SV_R; ++rr) {
-                const int y = y0 + SV_R * m + rr;
-                const bool in = col_in && y < y_in_end;
-                pv[rr] = in ? P[(long)y * a.W] : 0.f;
-                tv[rr] = in ? T[(long)y * a.W] : 0.f;
+                const long row = (long)min(y0 + SV_R * m + rr, a.H - 1) * a.W;
+                pv[rr] = (P + row)[tcol];
+                tv[rr] = (T + row)[tcol];
             }
         };
         fetch(0);
@@ -104,7 +107,7 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
 #pragma unroll
                 for (int k = 0; k < SS_K; ++k) {
                     const int j = (rr - k + SS_K) % SS_K;
-                    const float g = w.g[k];
+                    const float g = w.g[k < 6 ? k : 10 - k];      // the window is symmetric: six weights live in scalar registers
                     if (k == 0) { sa[j] = g * x; sb[j] = g * xx; sc[j] = g * pt; }
                     else { sa[j] += g * x; sb[j] += g * xx; sc[j] += g * pt; }
                 }
@@ -127,14 +130,14 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
                     for (int i = 0; i < SV_SPAN; ++i) {
                         // at most four columns' reads ahead of their use: hoisting all 21 costs 100 registers
                         if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-                        const int q = min(q0 + i, SV_T - 1);            // columns past the strip only feed windows past it
+                        const int q = q0 + i;        // < SV_T + 16; columns past the strip only feed windows past it
                         const float4 v = v4[rr][q];
                         const float vc = v1[rr][q];
                         const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
 #pragma unroll
                         for (int o = 0; o < SV_RUN; ++o) {
                             if (i - o < 0 || i - o >= SS_K) continue;
-                            const float g = w.g[i - o];
+                            const float g = w.g[i - o < 6 ? i - o : 10 - (i - o)];
                             ha[o] += g * va; hb[o] += g * vb; hc[o] += g * vc;
                         }
                     }
