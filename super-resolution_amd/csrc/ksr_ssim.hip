@@ -242,13 +242,20 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin 
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int ux = tx * SS_T - (SS_K - 1) + lane, uy0 = ty * SS_T - (SS_K - 1) + wv;
         const bool col_in = lane < SS_IN && ux >= 0 && ux < Wi;
-        const long first = ((long)b * Hi + uy0) * Wi + ux;
+        // every load is issued, from an address clamped into the image's maps (scalar base + 32-bit offset); windows
+        // outside the image contribute zero
+        const float* mb = a.maps + (long)b * Hi * Wi;
+        const int uxc = min(max(ux, 0), Wi - 1);
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int r = wv + 4 * it, uy = uy0 + 4 * it;
             const bool in = col_in && r < SS_IN && uy >= 0 && uy < Hi;
+            const unsigned o = (unsigned)(min(max(uy, 0), Hi - 1) * Wi + uxc);
 #pragma unroll
-            for (int m = 0; m < 3; ++m) mv[it][m] = in ? a.maps[m * msz + first + (long)(4 * it) * Wi] : 0.f;
+            for (int m = 0; m < 3; ++m) {
+                const float v = (mb + m * msz)[o];
+                mv[it][m] = in ? v : 0.f;
+            }
         }
     };
     if (t_begin < t_end) fetch(t_begin);
@@ -274,16 +281,15 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin 
         f32x2 sa[SS_RUN];
         float sc[SS_RUN];
 #pragma unroll
-        for (int o = 0; o < SS_RUN; ++o) { sa[o] = f32x2{0.f, 0.f}; sc[o] = 0.f; }
-#pragma unroll
         for (int i = 0; i < SS_SPAN; ++i) {
             const f32x2 va = {ms[0][r][q0 + i], ms[1][r][q0 + i]};
             const float vc = ms[2][r][q0 + i];
 #pragma unroll
             for (int o = 0; o < SS_RUN; ++o) {
                 if (i - o < 0 || i - o >= SS_K) continue;
-                const float g = w.g[SS_K - 1 - (i - o)];
-                sa[o] += g * va; sc[o] += g * vc;
+                const float g = w.g[i - o < 6 ? i - o : 10 - (i - o)];       // symmetric window: six weights in scalar registers
+                if (i == o) { sa[o] = g * va; sc[o] = g * vc; }      // a run's first tap starts its sums
+                else { sa[o] += g * va; sc[o] += g * vc; }
             }
         }
 #pragma unroll
@@ -295,16 +301,15 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin 
         f32x2 sa[SS_RUN];
         float sc[SS_RUN];
 #pragma unroll
-        for (int o = 0; o < SS_RUN; ++o) { sa[o] = f32x2{0.f, 0.f}; sc[o] = 0.f; }
-#pragma unroll
         for (int i = 0; i < SS_SPAN; ++i) {
             const f32x2 va = {hs[0][r0 + i][q], hs[1][r0 + i][q]};
             const float vc = hs[2][r0 + i][q];
 #pragma unroll
             for (int o = 0; o < SS_RUN; ++o) {
                 if (i - o < 0 || i - o >= SS_K) continue;
-                const float g = w.g[SS_K - 1 - (i - o)];
-                sa[o] += g * va; sc[o] += g * vc;
+                const float g = w.g[i - o < 6 ? i - o : 10 - (i - o)];       // symmetric window: six weights in scalar registers
+                if (i == o) { sa[o] = g * va; sc[o] = g * vc; }      // a run's first tap starts its sums
+                else { sa[o] += g * va; sc[o] += g * vc; }
             }
         }
         const int x = px0 + q;
@@ -312,16 +317,16 @@ __global__ void __launch_bounds__(256) ssim_grad_kernel(SsimGradArgs a, SsimWin 
         for (int o = 0; o < SS_RUN; ++o) {
             const int y = py0 + r0 + o;
             if (y >= a.H || x >= a.W) continue;
-            const long off = (long)y * a.W + x;
-            const float p = a.pred[(long)b * a.pred_bs + off], traw = a.tgt[(long)b * a.tgt_bs + off], tg = clamp01(traw);
+            const unsigned off = (unsigned)(y * a.W + x);
+            const float p = (a.pred + (long)b * a.pred_bs)[off], traw = (a.tgt + (long)b * a.tgt_bs)[off], tg = clamp01(traw);
             const float inside = (p >= 0.f && p <= 1.f) ? 1.f : 0.f;
             const float gs = a.scale * inside * (sa[o][0] + 2.f * clamp01(p) * sa[o][1] + tg * sc[o]);
             if constexpr (L1) {
                 const float d = p - traw;
                 l1acc += fabsf(d);
-                a.grad[(long)b * a.grad_bs + off] = (d > 0.f ? a.l1_inv : (d < 0.f ? -a.l1_inv : 0.f)) + gs;
+                (a.grad + (long)b * a.grad_bs)[off] = (d > 0.f ? a.l1_inv : (d < 0.f ? -a.l1_inv : 0.f)) + gs;
             } else {
-                a.grad[(long)b * a.grad_bs + off] += gs;
+                (a.grad + (long)b * a.grad_bs)[off] += gs;
             }
         }
     }
