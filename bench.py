@@ -32,7 +32,7 @@ PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16 matrix peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
-def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
+def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4, train: bool = True):
     """Per entry point: (bound, algorithmic flops per LR pixel per step, algorithmic HBM bytes per LR pixel per
     step, MFMA peak in TFLOP/s) summed over that entry point's launches in one training step.
     Flops: 2*Cin*Cout per 1x1 conv / linear, 2*9 per depthwise output; attention: 2 products of 64 flops per
@@ -57,12 +57,13 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
         "ksr_stem_gate_fwd": ("hbm", 2 * 2 * 64 * 64 + 2 * 9 * 64 * 3 + 400, 4 + 4 + (0 if fused else 512) + 3 * 256, pk),
         "ksr_gate_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64 + 64, 512 + 256 + 256, pk),            # ffn4's tail
         # ffn4.fn_1 (64 -> 128); without bf16 storage also both layers' in-projections (64 -> 192)
-        "ksr_pointwise_fwd": (("hbm", 2 * 64 * 128, 256 + 512, pk) if fused else
+        "ksr_pointwise_fwd": (("hbm", 2 * 64 * 128, 256 + 512, pk) if fused or S <= 8 else    # <= 8 images: in ksr_batch_tx_layer_fwd
                               ("hbm", 2 * 64 * 128 + 2 * 2 * 64 * 192, (256 + 512) + 2 * (256 + 768), pk)),
         # bf16 storage: in-projection inside the attention forward: x in, qkv (kept for the backward) and ctx out, both layers
         "ksr_batch_qkv_attn_fwd": ("hbm", 2 * (2 * 64 * 192 + 256 * S), 2 * (256 + 768 + 256), pk),
         "ksr_dwrelu_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 256 + 256 + 256, pk),
-        "ksr_batch_tx_layer_fwd": ("mfma", 2 * (2 * 64 * 192 + lin_post + 256 * S), 2 * 512, pk),
+        # one image (inference): softmax over a single key is 1, the context is the value projection: q and k are not needed
+        "ksr_batch_tx_layer_fwd": ("mfma", 2 * ((2 * 64 * 64 if S == 1 else 2 * 64 * 192 + 256 * S) + lin_post), 2 * 512, pk),
         # attention: the bf16-operand kernels are bound by memory and vector arithmetic (masks, exp, dropout hash), the
         # matrix pipe is < 10 % busy: priced against HBM; the exact fp32 kernels against the fp32 MFMA peak
         "ksr_batch_attn_fwd": ("hbm" if bf16 else "mfma", 2 * 256 * S, 2 * (768 + 256), f32),
@@ -109,6 +110,12 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4):
     fixed = {"ksr_ssim_fwd": 16 * 36, "ksr_ssim_y_grad": 16 * 28, "ksr_ssim_y_grad_l1": 16 * 24, "ksr_l1_y_loss": 16 * 12, "ksr_stem_fwd": 8, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_feed_kan_bwd": 64 + 4 + 128, "ksr_bilinear_up": 8 + 8 * 16,
              "ksr_gate_pw_fwd": 256 if act_bytes != 4 else 0, "ksr_batch_tx_layer_post_fwd": 128 if act_bytes != 4 else 0,
              "ksr_stem_gate_fwd": 8, "ksr_gate_pw_bwd_v": 4, "ksr_fn1_bwd_stem_v": 8, "ksr_dwconv_wgrad_v": 4}
+    if not train:
+        # eval mode keeps nothing for a backward pass: each launch reads its input and writes the one tensor the next reads
+        # (ffn1 + ffn2 + ffn3.pointwise1: Y in, x3 out; ffn3's tail: x3 in, x4 out; ffn4's tail: t5 in, x6 out)
+        for name, by in (("ksr_stem_gate_fwd", 4 + 256), ("ksr_dwrelu_pw_fwd", 256 + 256), ("ksr_gate_pw_fwd", 512 + 256)):
+            models[name] = (models[name][0], models[name][1], by, models[name][3])
+        fixed = {"ksr_stem_gate_fwd": 4, "ksr_feed_kan_fwd": 4 + 4 * 16, "ksr_bilinear_up": 8 + 8 * 16}
     out = {}
     for name, (bound, fl, by, peak) in models.items():
         fx = fixed.get(name, 0)
@@ -378,7 +385,8 @@ def main():
         avg_ms = sum(prof[dom]) / len(prof[dom])
         P = 16 * (5 + 3 + 2)
         bf16 = args.workload == "train" and args.precision != "fp32"
-        models = kernel_models(B, P, bf16, 2 if (args.workload == "train" and args.precision == "bf16s") else 4)
+        models = kernel_models(B, P, bf16, 2 if (args.workload == "train" and args.precision == "bf16s") else 4,
+                               train=args.workload != "infer")
         if unet:
             models.update(unet_kernel_models(P))
         kmodel = models.get(dom)

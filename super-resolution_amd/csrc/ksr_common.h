@@ -161,7 +161,7 @@ __device__ __forceinline__ unsigned ksr_xcd_contiguous(unsigned wg, unsigned tot
 
 // One hash serves two neighbouring keys (16 bits each): the keep probability is quantised to 1/65536.  `base` is
 // already a full hash of (seed, token, head); the key index enters as a Weyl step followed by ONE xorshift-multiply
-// round (the 32-bit multiply runs at quarter rate, and the attention kernels are bound by instruction issue).  Measured
+// round (the attention kernels are bound by instruction issue: five instructions per pair of keys instead of nine).  Measured
 // on 10^6 bases x 64 keys: mean keep 0.89999, variance of the per-query count 5.75-5.76 (binomial 5.76), largest
 // pairwise correlation between keys 0.005 (sampling noise 0.004).
 __device__ __forceinline__ unsigned ksr_attn_keep_word(unsigned base, int key_b) {   // low half: key_b & ~1, high half: key_b | 1
