@@ -92,7 +92,7 @@ def test_kan_cell_random_vs_oracle_large():
     assert_fwd(y, ref)
 
 
-@pytest.mark.parametrize("r,H,W", [(4, 16, 16), (2, 9, 11), (4, 5, 7), (3, 6, 5)])
+@pytest.mark.parametrize("r,H,W", [(4, 16, 16), (2, 9, 11), (4, 5, 7), (3, 6, 5), (2, 10, 70), (4, 7, 70)])
 def test_bilinear(r, H, W):
     from kan_sr import ops
     torch.manual_seed(1)
