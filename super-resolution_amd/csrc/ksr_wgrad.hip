@@ -416,11 +416,13 @@ struct RedArgs {
 };
 
 constexpr int RED_GROUPS = 32;     // slab groups per workgroup (1024 threads)
+constexpr int RED_GROUPS_FEW = 8;  // ... when there are few partial rows (batched Gram products: a handful per image)
 
-__global__ void __launch_bounds__(32 * RED_GROUPS) reduce_kernel(RedArgs a) {
-    // 32 outputs x 32 slab groups per workgroup (lanes = consecutive outputs: 128-byte rows of the slabs); every
+template <int GROUPS>
+__global__ void __launch_bounds__(32 * GROUPS) reduce_kernel(RedArgs a) {
+    // 32 outputs x GROUPS slab groups per workgroup (lanes = consecutive outputs: 128-byte rows of the slabs); every
     // thread keeps 4 independent partial sums; all partials are combined in a fixed order
-    __shared__ float part[RED_GROUPS][33];
+    __shared__ float part[GROUPS][33];
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int idx = blockIdx.x * 32 + o;
     const int total = a.J * a.K + (a.bias ? a.tail_len : 0);
@@ -429,20 +431,20 @@ __global__ void __launch_bounds__(32 * RED_GROUPS) reduce_kernel(RedArgs a) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (idx < total) {
         int g = grp;
-        for (; g + 3 * RED_GROUPS < a.G; g += 4 * RED_GROUPS) {
+        for (; g + 3 * GROUPS < a.G; g += 4 * GROUPS) {
             s0 += slab[(long)g * a.stride];
-            s1 += slab[(long)(g + RED_GROUPS) * a.stride];
-            s2 += slab[(long)(g + 2 * RED_GROUPS) * a.stride];
-            s3 += slab[(long)(g + 3 * RED_GROUPS) * a.stride];
+            s1 += slab[(long)(g + GROUPS) * a.stride];
+            s2 += slab[(long)(g + 2 * GROUPS) * a.stride];
+            s3 += slab[(long)(g + 3 * GROUPS) * a.stride];
         }
-        for (; g < a.G; g += RED_GROUPS) s0 += slab[(long)g * a.stride];
+        for (; g < a.G; g += GROUPS) s0 += slab[(long)g * a.stride];
     }
     part[grp][o] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (grp != 0 || idx >= total) return;
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < RED_GROUPS; ++r) s += part[r][o];
+    for (int r = 0; r < GROUPS; ++r) s += part[r][o];
     int j, k;
     if (is_bias) { j = idx - a.J * a.K; k = 0; }
     else { j = idx / a.K; k = idx - j * a.K; }
@@ -722,7 +724,9 @@ int launch_reduce(const float* slab, int G, int J, int K, long stride, float* ou
     if (tail_off < 0) { tail_off = J * K; tail_len = J; }
     RedArgs r{slab, G, J, K, stride, out, sj, sk, bias, kan_O, kan_Kc, kan_nbh, tail_off, tail_len, out_bstride};
     const int total = J * K + (bias ? tail_len : 0);
-    hipLaunchKernelGGL(reduce_kernel, dim3((total + 31) / 32, nb), dim3(32 * RED_GROUPS), 0, s, r);
+    // few partial rows (G <= 32: the per-image Gram products): 8 groups keep every thread of a workgroup at work
+    if (G <= 4 * RED_GROUPS_FEW) hipLaunchKernelGGL(reduce_kernel<RED_GROUPS_FEW>, dim3((total + 31) / 32, nb), dim3(32 * RED_GROUPS_FEW), 0, s, r);
+    else hipLaunchKernelGGL(reduce_kernel<RED_GROUPS>, dim3((total + 31) / 32, nb), dim3(32 * RED_GROUPS), 0, s, r);
     KSR_LAUNCH_CHECK("reduce");
     return KSR_OK;
 }

@@ -64,7 +64,7 @@ per_kernel = {r[0]: r[6] for r in rows}
 # ksr_wgrad launches one of several wgrad_kernel instances followed by one reduce_kernel: launch-weighted average
 wg = [r for r in rows if r[0].startswith(("wgrad_kernel<", "wgrad_fast_kernel<"))]
 if wg:
-    per_kernel["entry:ksr_wgrad"] = int(sum(r[6] * r[1] for r in wg) / sum(r[1] for r in wg) + per_kernel.get("reduce_kernel", 0))
+    per_kernel["entry:ksr_wgrad"] = int(sum(r[6] * r[1] for r in wg) / sum(r[1] for r in wg) + next((v for k, v in per_kernel.items() if k.startswith("reduce_kernel")), 0))
 # bench.py reads the default workload's file; other tags keep their own
 with open(os.path.join(OUT, "pmc_hbm_bytes_per_launch.json" if TAG == "r02_train_b64_bf16s" else f"{TAG}_pmc_hbm_bytes_per_launch.json"), "w") as fh:
     json.dump(per_kernel, fh, indent=1)
