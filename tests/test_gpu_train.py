@@ -199,6 +199,34 @@ def test_ssim_kernels_vs_oracle(B, H, W):
     assert rel_l2(g2.cpu(), pred2.grad[:, 0].reshape(B, plane)) <= 1e-5
 
 
+def test_ssim_forward_full_size_is_the_mean_over_half_batches():
+    """The SSIM forward at the size of the default training bench (64 x 3 planes of 512 x 512: one task per strip and plane,
+    walking the whole height) against the same kernel on the two halves of the batch, which it splits into two bands
+    per strip: the value is the mean of the halves' values and the derivative maps are the halves' maps."""
+    from ctypes import c_int, c_int64
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(7)
+    B, H, W = 64, 512, 512
+    p = (torch.rand(B, 3, H, W, device="cuda") * 1.2 - 0.1)
+    t_ = p + 0.1 * torch.randn(B, 3, H, W, device="cuda")
+    L = lib()
+    plane, win = H * W, (H - 10) * (W - 10)
+
+    def run(pp, tt, b):
+        slab = torch.empty(int(L.ksr_ssim_slab_floats(c_int(3), c_int(b), c_int(H), c_int(W))), device="cuda")
+        maps = torch.empty(3, b, win, device="cuda")
+        out = torch.zeros(1, device="cuda")
+        check(L.ksr_ssim_fwd(ptr(pp), c_int64(3 * plane), ptr(tt), c_int64(3 * plane), c_int(3), c_int(b), c_int(H), c_int(W),
+                             ptr(maps), ptr(slab), ptr(out), stream()), "ssim_fwd")
+        return float(out), maps
+
+    v, maps = run(p, t_, B)
+    v0, m0 = run(p[:32].contiguous(), t_[:32].contiguous(), 32)
+    v1, m1 = run(p[32:].contiguous(), t_[32:].contiguous(), 32)
+    assert 0.0 < v < 1.0 and abs(v - 0.5 * (v0 + v1)) <= 1e-6
+    assert torch.equal(maps[:, :32], m0) and torch.equal(maps[:, 32:], m1)
+
+
 def test_train_step_with_ssim_loss_vs_oracle():
     """TrainStep(loss='l1+ssim') = the reference's training_step loss: loss value and one Adam step against autograd of
     the oracle (eval mode, so no dropout)."""
