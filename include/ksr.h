@@ -383,6 +383,12 @@ int ksr_feed_kan_dx(const float* feat, const float* x_img, int64_t img_batch_str
                     ksr_stream_t stream);
 int ksr_stem_dx(const float* dpre, const float* pw1_w, const float* dw_w, float* gx, int64_t gx_batch_stride, int B, int H,
                 int W, ksr_stream_t stream);
+/* ksr_feed_kan_dx behind the channel-attention head (conv_sep_kan_attention.py:62-69): the per-image weights and feature row
+ * layout of ksr_feed_kan_fwd_img. */
+int ksr_feed_kan_dx_img(const float* feat, int feat_ld, int feat_c0, const float* x_img, int64_t img_batch_stride,
+                        const float* feed_w_per_image, const float* feed_b, const float* gout, int64_t gout_batch_stride,
+                        float* gx, int64_t gx_batch_stride, int B, int H, int W, int upscale, int n_coef, const float* knots,
+                        int n_knots, int spline_order, ksr_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Colour pre/post-processing: the steps either side of the model in the reference's data path

@@ -209,16 +209,18 @@ __global__ void __launch_bounds__(256, 2) feed_kan_dx_kernel(FeedArgs a, KsrKnot
     __shared__ FeedSmem<NB, false> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
-    ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.w, 64, a.bias, MapKan{C::O, KC}, MapHL{32}, tid, 256);
+    ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.w + (long)blockIdx.y * a.w_bstride, 64,
+                                           a.bias + (long)blockIdx.y * a.bias_bstride, MapKan{C::O, KC}, MapHL{32}, tid, 256);
     if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
     __syncthreads();
     const int HW = a.H * a.W;
-    const long N = (long)a.B * HW;
-    const long ntiles = (N + 127) / 128;
+    const FeedRange rg = feed_range(a);              // all pixels, or those of image blockIdx.y (per-image weights)
+    const long ntiles = (rg.count + 127) / 128;
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long n = tile * 128 + wv * 32 + tok;
-        const bool live = n < N;
-        const long nn = live ? n : 0;
+        const long r = tile * 128 + wv * 32 + tok;
+        const bool live = r < rg.count;
+        const long n = rg.first + r;
+        const long nn = live ? n : rg.first;
         const int b = (int)(nn / HW), hw = (int)(nn % HW);
         const int y = hw / a.W, x = hw % a.W;
         float f[32];
@@ -266,10 +268,8 @@ __global__ void __launch_bounds__(256, 2) feed_kan_dx_kernel(FeedArgs a, KsrKnot
 
 template <int R, int KC, int KORD>
 int launch_feed_dx(const FeedArgs& a, const KsrKnots& kn, float* gx, long gx_bstride, hipStream_t s) {
-    const long N = (long)a.B * a.H * a.W;
-    const long ntiles = (N + 127) / 128;
-    const unsigned grid = (unsigned)(ntiles < 768 ? ntiles : 768);
-#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_dx_kernel<P, R, KC, KORD>), dim3(grid), dim3(256), 0, s, a, kn, gx, gx_bstride)
+    const dim3 grid = feed_grid(a, 768);
+#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_dx_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn, gx, gx_bstride)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("feed_kan_dx");
@@ -532,18 +532,23 @@ extern "C" int ksr_feed_kan_bwd_img(const float* gout, int64_t gout_batch_stride
 
 // gx[b, y, x] (images gx_batch_stride elements apart) = d(out)/d(luma) contracted with gout, through the KAN evaluation's
 // direct dependence on the pixel's luma value (the path through the encoder is ksr_stem_dx).  Written, not accumulated.
-extern "C" int ksr_feed_kan_dx(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
-                               const float* feed_b, const float* gout, int64_t gout_batch_stride, float* gx,
-                               int64_t gx_batch_stride, int B, int H, int W, int upscale, int n_coef, const float* knots,
-                               int n_knots, int spline_order, hipStream_t stream) {
+namespace {
+int feed_kan_dx_impl(const float* feat, int feat_ld, int feat_c0, const float* x_img, int64_t img_batch_stride, const float* feed_w,
+                     int per_image, const float* feed_b, const float* gout, int64_t gout_batch_stride, float* gx,
+                     int64_t gx_batch_stride, int B, int H, int W, int upscale, int n_coef, const float* knots, int n_knots,
+                     int spline_order, hipStream_t stream) {
     KSR_CHECK_ARG(feat && x_img && feed_w && feed_b && gout && gx && knots, "feed_kan_dx: null pointer");
     KSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "feed_kan_dx: non-positive dimension");
+    KSR_CHECK_ARG(!per_image || B <= 65535, "feed_kan_dx: at most 65535 images with per-image weights");
+    KSR_CHECK_ARG(feat_ld >= 64 && feat_c0 >= 0 && feat_c0 + 64 <= feat_ld && feat_ld % 4 == 0 && feat_c0 % 4 == 0,
+                  "feed_kan_dx: bad feature row layout (ld %d, c0 %d)", feat_ld, feat_c0);
     KSR_CHECK_ARG(n_knots == n_coef + spline_order + 1 && n_knots <= KSR_MAX_KNOTS, "feed_kan_dx: bad knot count %d", n_knots);
     KSR_UNSUPPORTED(!ksr_feed_kan_supported(upscale, n_coef, spline_order), "feed_kan_dx: configuration has no fused kernel");
     FeedArgs a{};
     a.feat = feat; a.x_img = x_img; a.img_bstride = img_batch_stride; a.w = feed_w; a.bias = feed_b;
     a.gout = gout; a.out_bstride = gout_batch_stride; a.B = B; a.H = H; a.W = W;
-    a.feat_ld = 64; a.feat_c0 = 0;
+    a.feat_ld = feat_ld; a.feat_c0 = feat_c0;
+    a.w_bstride = per_image ? (long)upscale * upscale * (n_coef + 2) * 64 : 0;     // the bias is shared
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
@@ -551,4 +556,23 @@ extern "C" int ksr_feed_kan_dx(const float* feat, const float* x_img, int64_t im
     KSR_FEED_CONFIGS(KSR_X)
 #undef KSR_X
     return KSR_ERR_UNSUPPORTED;
+}
+}  // namespace
+
+extern "C" int ksr_feed_kan_dx(const float* feat, const float* x_img, int64_t img_batch_stride, const float* feed_w,
+                               const float* feed_b, const float* gout, int64_t gout_batch_stride, float* gx,
+                               int64_t gx_batch_stride, int B, int H, int W, int upscale, int n_coef, const float* knots,
+                               int n_knots, int spline_order, hipStream_t stream) {
+    return feed_kan_dx_impl(feat, 64, 0, x_img, img_batch_stride, feed_w, 0, feed_b, gout, gout_batch_stride, gx, gx_batch_stride,
+                            B, H, W, upscale, n_coef, knots, n_knots, spline_order, stream);
+}
+
+// The same with the per-image weights of ksr_feed_kan_fwd_img (and the features at channels feat_c0 .. of rows of feat_ld).
+extern "C" int ksr_feed_kan_dx_img(const float* feat, int feat_ld, int feat_c0, const float* x_img, int64_t img_batch_stride,
+                                   const float* feed_w_per_image, const float* feed_b, const float* gout,
+                                   int64_t gout_batch_stride, float* gx, int64_t gx_batch_stride, int B, int H, int W,
+                                   int upscale, int n_coef, const float* knots, int n_knots, int spline_order,
+                                   hipStream_t stream) {
+    return feed_kan_dx_impl(feat, feat_ld, feat_c0, x_img, img_batch_stride, feed_w_per_image, 1, feed_b, gout, gout_batch_stride,
+                            gx, gx_batch_stride, B, H, W, upscale, n_coef, knots, n_knots, spline_order, stream);
 }

@@ -89,7 +89,7 @@ EXPORTS = [
     "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",
     "ksr_stem_fwd", "ksr_stem_gate_fwd", "ksr_pointwise_fwd", "ksr_dwrelu_pw_fwd", "ksr_gate_pw_fwd",
     "ksr_batch_tx_layer_fwd", "ksr_batch_attn_fwd", "ksr_batch_qkv_attn_fwd", "ksr_batch_tx_layer_post_fwd",
-    "ksr_feed_kan_supported", "ksr_feed_kan_fwd", "ksr_feed_kan_fwd_img", "ksr_feed_kan_bwd_img", "ksr_gram_batched_kan", "ksr_feed_kan_dx", "ksr_stem_dx", "ksr_bilinear_up_bwd",
+    "ksr_feed_kan_supported", "ksr_feed_kan_fwd", "ksr_feed_kan_fwd_img", "ksr_feed_kan_bwd_img", "ksr_gram_batched_kan", "ksr_feed_kan_dx", "ksr_feed_kan_dx_img", "ksr_stem_dx", "ksr_bilinear_up_bwd",
     "ksr_feed_kan_lane_len", "ksr_feed_kan_bwd", "ksr_batch_tx_layer_bwd_token", "ksr_batch_tx_layer_bwd_attn",
     "ksr_batch_attn_bwd", "ksr_tx_bwd_wg_slab_floats", "ksr_batch_tx_layer_bwd_out_wg", "ksr_wgrad_affine_input",
     "ksr_gate_pw_bwd_v", "ksr_fn1_bwd_stem_v", "ksr_dwconv_wgrad_v", "ksr_in_proj_bwd", "ksr_in_proj_bwd_wg", "ksr_in_proj_bwd_wg_slab_floats", "ksr_gate_pw_bwd", "ksr_gate_pw_bwd_wg", "ksr_pw2_bwd_wg", "ksr_pw1_bwd_wg", "ksr_fused_wgrad_slab_floats", "ksr_fn1_bwd", "ksr_pw2_bwd", "ksr_pw1_bwd",

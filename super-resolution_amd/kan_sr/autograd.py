@@ -501,18 +501,23 @@ class _TrunkFn(torch.autograd.Function):
     def backward(ctx, gfeat):
         pre, g, p_drop, seed, names, precision = ctx.cfg
         engine.set_precision(precision)
-        if ctx.needs_input_grad[0]:
-            raise KsrError("gradient with respect to the input image is not implemented")
         grads: Dict[str, torch.Tensor] = {}
         ws = _Ws(ctx.x.device, None, g.N)
         trunk_backward(ws, gfeat.contiguous(), ctx.x, ctx.p, pre, g, ctx.sv, p_drop, seed, grads)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            # the trunk reads the luma plane only (ffn1's front): w1 * convT(dpre) into plane 0
+            gx = torch.zeros_like(ctx.x)
+            f = pre + "ffn1."
+            check(lib().ksr_stem_dx(ptr(ws.dpre), ptr(ctx.p[f + "pointwise1.weight"]), ptr(ctx.p[f + "depthwise.weight"]), ptr(gx),
+                                    c_int64(3 * g.H * g.W), *_dims(g), stream()), "ksr_stem_dx")
         ws.join()
         ctx.sv = None
         out = []
         for n, t in zip(names, ctx.p.values()):
             gr = grads.get(n)
             out.append(None if gr is None else gr.reshape(t.shape))
-        return (None, None, None, None, None, None, None, *out)
+        return (gx, None, None, None, None, None, None, *out)
 
 
 def trunk_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_drop: float, seed: int, precision: str = "fp32"):

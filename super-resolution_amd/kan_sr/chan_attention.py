@@ -156,22 +156,31 @@ class _AttnKanFn(torch.autograd.Function):
         check(L.ksr_feed_kan_fwd_img(ptr(qkv), c_int(192), c_int(128), ptr(x), c_int64(3 * HW), ptr(M), ptr(ba), ptr(out),
                                      c_int64(3 * HW * r * r), ptr(save_us), c_int(B), c_int(H), c_int(W), c_int(r), c_int(n_coef),
                                      kn, c_int(len(knots)), c_int(spline_order), stream()), "ksr_feed_kan_fwd_img")
-        ctx.save_for_backward(qkv, wa, A, S, nrm, M, save_us, x)
+        ctx.save_for_backward(qkv, wa, A, S, nrm, M, save_us, x, ba)
         ctx.cfg = (dims, precision, n_coef, knots, spline_order, r)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        qkv, wa, A, S, nrm, M, save_us, x = ctx.saved_tensors
+        qkv, wa, A, S, nrm, M, save_us, x, ba = ctx.saved_tensors
         (B, H, W), precision, n_coef, knots, spline_order, r = ctx.cfg
         HW = H * W
-        if ctx.needs_input_grad[3]:
-            raise KsrError("gradient with respect to the input image is not implemented for the attention head")
         engine.set_precision(precision)
         L = lib()
         dev = qkv.device
         P = wa.shape[0]
         gout = gout.contiguous()
+        gx = None
+        if ctx.needs_input_grad[3]:
+            # the image's own paths into the output: chroma through the bilinear upsampling, luma through the KAN
+            # evaluation's use of the pixel value (its path through the encoder trunk is the trunk function's gradient)
+            gx = torch.empty_like(x)
+            check(L.ksr_bilinear_up_bwd(ptr(gout), ptr(gx), c_int(B), c_int(2), c_int(H), c_int(W), c_int(r), c_int64(3 * HW),
+                                        c_int(1), c_int64(3 * HW * r * r), c_int(1), stream()), "ksr_bilinear_up_bwd")
+            check(L.ksr_feed_kan_dx_img(ptr(qkv), c_int(192), c_int(128), ptr(x), c_int64(3 * HW), ptr(M), ptr(ba), ptr(gout),
+                                        c_int64(3 * HW * r * r), ptr(gx), c_int64(3 * HW), c_int(B), c_int(H), c_int(W), c_int(r),
+                                        c_int(n_coef), host_floats(knots), c_int(len(knots)), c_int(spline_order), stream()),
+                  "ksr_feed_kan_dx_img")
         J = 2 * int(L.ksr_feed_kan_lane_len(c_int(r), c_int(n_coef)))
         gparam = _new(dev, B * HW, J)
         dqkv = _new(dev, B * HW, 192)
@@ -192,7 +201,7 @@ class _AttnKanFn(torch.autograd.Function):
                                   c_int(B), stream()), "ksr_chan_soft_bwd")
         check(L.ksr_chan_apply(ptr(qkv), c_int(192), c_int(0), c_int(128), ptr(Mqk), c_int(0), ptr(None), ptr(dqkv),
                                c_int(192), c_int(0), c_int(128), c_int(B), c_int(HW), stream()), "ksr_chan_apply")
-        return dqkv, g_wa, g_ba, None, None, None, None, None, None, None
+        return dqkv, g_wa, g_ba, gx, None, None, None, None, None, None
 
 
 def _to_nhwc(t):
