@@ -98,15 +98,22 @@ class _KanHead(torch.autograd.Function):
         y, w = ctx.saved_tensors
         n_coef, knots, spline_order, r = ctx.cfg
         B, _, H, W = y.shape
-        if ctx.needs_input_grad[0]:
-            raise _lib.KsrError("gradient with respect to the input image is not implemented")
         gout = _f32c(gout)
         gw = torch.empty_like(w)
         kn = host_floats(knots)
-        check(lib().ksr_kan_cell_bwd(ptr(y), ptr(w), ptr(gout), ptr(gw), ptr(None), c_int(B), c_int(1), c_int(r * r),
+        want_gx = ctx.needs_input_grad[0]
+        gy = torch.empty_like(y) if want_gx else None       # luma: the cell's own use of the pixel value
+        check(lib().ksr_kan_cell_bwd(ptr(y), ptr(w), ptr(gout), ptr(gw), ptr(gy), c_int(B), c_int(1), c_int(r * r),
                                      c_int(H), c_int(W), c_int(n_coef), kn, c_int(len(knots)), c_int(spline_order),
                                      c_int(1), c_int(r), c_int64(3 * H * r * W * r), stream()), "ksr_kan_cell_bwd")
-        return None, gw, None, None, None, None
+        gx = None
+        if want_gx:
+            gx = torch.empty(B, 3, H, W, device=y.device, dtype=torch.float32)
+            check(lib().ksr_bilinear_up_bwd(ptr(gout), ptr(gx), c_int(B), c_int(2), c_int(H), c_int(W), c_int(r),
+                                            c_int64(3 * H * W), c_int(1), c_int64(3 * H * r * W * r), c_int(1), stream()),
+                  "ksr_bilinear_up_bwd")
+            gx[:, :1].copy_(gy)
+        return gx, gw, None, None, None, None
 
 
 def kan_head(x: torch.Tensor, w: torch.Tensor, grid_size: int, spline_order: int, grid_range: Sequence[float],

@@ -159,9 +159,9 @@ def test_model_with_attention_head(r, G, B, H, W, fused, monkeypatch):
     params = {n: v.detach().clone() for n, v in m.state_dict().items()}
     x, gy = torch.rand(B, 3, H, W), torch.randn(B, 3, r * H, r * W)
     p_ref = {n: v.clone().requires_grad_() for n, v in params.items()}
-    # the fused wiring also returns the gradient with respect to the input image (chroma through the upsampling, luma
-    # through the KAN evaluation and through the trunk)
-    x_ref = x.clone().requires_grad_(fused)
+    # both wirings also return the gradient with respect to the input image (chroma through the upsampling, luma through
+    # the KAN evaluation and through the trunk)
+    x_ref = x.clone().requires_grad_()
     y_ref = orc.conv_sep_kan_forward(x_ref, p_ref, out_channels=[r * r], grid_size=G, spline_order=3, grid_range=[-1, 1],
                                      upscale=r, attention=True)
     (y_ref * gy).sum().backward()
@@ -169,14 +169,13 @@ def test_model_with_attention_head(r, G, B, H, W, fused, monkeypatch):
     m = m.cuda()
     with torch.no_grad():
         assert_fwd(m(x.cuda()), y_ref, atol=2e-5)
-    xg = x.cuda().requires_grad_(fused)
+    xg = x.cuda().requires_grad_()
     y = m(xg)
     assert_fwd(y, y_ref, atol=2e-5)
     y.backward(gy.cuda())
-    if fused:
-        assert xg.grad.shape == x.shape
-        for c in range(3):
-            assert rel_l2(xg.grad[:, c].cpu(), x_ref.grad[:, c]) <= 2e-4, (c, rel_l2(xg.grad[:, c].cpu(), x_ref.grad[:, c]))
+    assert xg.grad.shape == x.shape
+    for c in range(3):
+        assert rel_l2(xg.grad[:, c].cpu(), x_ref.grad[:, c]) <= 2e-4, (c, rel_l2(xg.grad[:, c].cpu(), x_ref.grad[:, c]))
     for n, prm in m.named_parameters():
         if ".a_dw." in n:
             assert prm.grad is None
