@@ -540,7 +540,8 @@ int feed_kan_dx_impl(const float* feat, int feat_ld, int feat_c0, const float* x
     KSR_CHECK_ARG(feat && x_img && feed_w && feed_b && gout && gx && knots, "feed_kan_dx: null pointer");
     KSR_CHECK_ARG(B > 0 && H > 0 && W > 0, "feed_kan_dx: non-positive dimension");
     KSR_CHECK_ARG(!per_image || B <= 65535, "feed_kan_dx: at most 65535 images with per-image weights");
-    KSR_CHECK_ARG(feat_ld >= 64 && feat_c0 >= 0 && feat_c0 + 64 <= feat_ld && feat_ld % 4 == 0 && feat_c0 % 4 == 0,
+    const int al = ksr_prec() == KSR_BF16S ? 8 : 4;        // elements per 16-byte piece of a feature row
+    KSR_CHECK_ARG(feat_ld >= 64 && feat_c0 >= 0 && feat_c0 + 64 <= feat_ld && feat_ld % al == 0 && feat_c0 % al == 0,
                   "feed_kan_dx: bad feature row layout (ld %d, c0 %d)", feat_ld, feat_c0);
     KSR_CHECK_ARG(n_knots == n_coef + spline_order + 1 && n_knots <= KSR_MAX_KNOTS, "feed_kan_dx: bad knot count %d", n_knots);
     KSR_UNSUPPORTED(!ksr_feed_kan_supported(upscale, n_coef, spline_order), "feed_kan_dx: configuration has no fused kernel");
