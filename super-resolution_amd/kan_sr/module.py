@@ -160,8 +160,9 @@ class ConvSepKan(nn.Module):
             from .ops import kan_head, kan_lin_head
             engine.set_precision(self.precision)
             net = self.layers[-1].encoder.encoder
-            if net.out_channels <= 512:
+            if net.out_channels <= 512 and not (torch.is_grad_enabled() and x.requires_grad):
                 # the [N, P] parameter tensor is never materialised: the KAN-cell kernels apply the UNet's last 1x1 conv
+                # (they return no gradient for the image: a pass that asks for one takes the materialised form below)
                 y4 = net.forward_nhwc(x[:, :1], fuse_head=True)
                 return kan_lin_head(x, y4, net, self.grid_size, self.spline_order, self.grid_range, self.upscale)
             w = net.forward_nhwc(x[:, :1])

@@ -444,6 +444,14 @@ class UNet(nn.Module):
         self._wgrad(draw1, c, B, H, W, a0=t["src0"], ca0=c0, a1=t["src1"], ca1=c1, Ha=H, Wa=W, out=self._KG[key + ".0"])
         if not need_input_grad:
             return None, None
+        if c0 % 4:
+            # the first block's single input channel (asked for only when the image itself requires a gradient): the conv
+            # kernels write channels in fours, so the transposed weights are padded with zero output channels
+            w1 = seq[0].weight.detach()                                   # [c][c0][3][3] -> taps flipped, [tap][c][c0 .. 4]
+            wp = torch.zeros(3, 3, c, 4, device=w1.device, dtype=torch.float32)
+            wp[..., :c0] = w1.permute(2, 3, 0, 1).flip(0, 1)
+            d4, _ = self._conv(draw1, c, wp, 4, B, H, W)
+            return d4.view(B, H, W, 4)[..., :c0].contiguous(), None
         d0, _ = self._conv(draw1, c, self._W[key + ".0.T0"], c0, B, H, W)
         d1 = None
         if c1:
@@ -556,9 +564,10 @@ class UNet(nn.Module):
             torch._foreach_add_(self._counters, 1)
         return out.view(B * H * W, -1)
 
-    def _backward(self, tape, dw):
+    def _backward(self, tape, dw, want_input_grad=False):
         """dw [B*H*W, P]: gradient of the output (with the head fused: [B*H*W, 4], gradient of reproj's input, reproj's
-        own parameter gradients being in self._KG["reproj"] already) -> {parameter name: gradient}."""
+        own parameter gradients being in self._KG["reproj"] already) -> {parameter name: gradient}; with want_input_grad
+        the gradient of the input plane [B,H,W,1] is left in self._input_grad."""
         self._tape = tape
         B, H, W = tape["reproj"]["dims"]
         self._ensure_prepared()
@@ -587,7 +596,8 @@ class UNet(nn.Module):
                 dout = torch.empty_like(g0)
                 check(lib().ksr_unet_grad_merge(ptr(g0), ptr(g1), ptr(dpooled), ptr(t["out"]), ptr(dout), c_int(Bq), c_int(h),
                                                 c_int(w), c_int(t["cout"]), stream()), "ksr_unet_grad_merge")
-            dpooled, _ = self._double_conv_bwd(key, dc, dout, need_input_grad=lvl > 0)
+            dpooled, _ = self._double_conv_bwd(key, dc, dout, need_input_grad=lvl > 0 or want_input_grad)
+        self._input_grad = dpooled if want_input_grad else None
         self._tape = None
         return self._collect_grads()
 
@@ -604,7 +614,7 @@ class UNet(nn.Module):
             raise KsrError(f"UNet needs at least 16x16 pixels (four 2x2 poolings), got {H}x{W}")
         x = y_plane.contiguous()
         names, params = self._named_params()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
             return _UNetFn.apply(x, self, names, fuse_head, *params)
         with torch.no_grad():
             return self._run(x, self.training, None, fuse_head)
@@ -622,15 +632,17 @@ class _UNetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, net, names, fuse_head, *params):
-        if x.requires_grad:
-            raise KsrError("gradient with respect to the input image is not implemented")
         ctx.net, ctx.names, ctx.tape = net, names, {}
         return net._run(x, net.training, ctx.tape, fuse_head)
 
     @staticmethod
     def backward(ctx, dw):
-        grads = ctx.net._backward(ctx.tape, dw.contiguous())
+        want_gx = ctx.needs_input_grad[0]
+        grads = ctx.net._backward(ctx.tape, dw.contiguous(), want_input_grad=want_gx)
         ctx.tape = None
+        gx = None
+        if want_gx:         # [B,H,W,1] is [B,1,H,W]
+            gx, ctx.net._input_grad = ctx.net._input_grad.view(-1, 1, *ctx.net._input_grad.shape[1:3]), None
         if ctx.net.grad_sink is not None:
-            return (None,) * (4 + len(ctx.names))
-        return (None, None, None, None) + tuple(grads[n].contiguous() for n in ctx.names)
+            return (gx,) + (None,) * (3 + len(ctx.names))
+        return (gx, None, None, None) + tuple(grads[n].contiguous() for n in ctx.names)

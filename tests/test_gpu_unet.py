@@ -232,6 +232,28 @@ def test_model_with_unet_backbone_trains():
     _check_grads({n: q.grad for n, q in m.named_parameters()}, {n: p[n].grad for n, _ in m.named_parameters()})
 
 
+@pytest.mark.parametrize("train", [False, True])
+def test_model_with_unet_backbone_input_gradient(train):
+    """Gradient with respect to the input image through ConvSepKan(backbone='unet') (chroma through the upsampling, luma
+    through the KAN evaluation and through the UNet's first conv) against the oracle's autograd."""
+    from kan_sr.module import ConvSepKan
+    torch.manual_seed(6)
+    m = ConvSepKan([1], [16], [3], 5, 3, 0.1, [-1, 1], 4, backbone="unet").cuda().train(train)
+    p = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    x, gy = torch.rand(2, 3, 32, 48), torch.randn(2, 3, 128, 192)
+    x_ref = x.clone().requires_grad_()
+    ref = orc.conv_sep_kan_forward(x_ref, p, out_channels=[16], grid_size=5, spline_order=3, grid_range=[-1, 1], upscale=4,
+                                   backbone="unet", train=train)
+    (ref * gy).sum().backward()
+    xg = x.cuda().requires_grad_()
+    y = m(xg)
+    assert_close(y, ref.detach(), "model")
+    y.backward(gy.cuda())
+    for c in range(3):
+        err = float((xg.grad[:, c].cpu() - x_ref.grad[:, c]).norm() / x_ref.grad[:, c].norm())
+        assert err <= 5e-4, (c, err)
+
+
 @pytest.mark.parametrize("loss", ["l1", "l1+ssim"])
 def test_unet_train_step_vs_oracle_adam(loss):
     """TrainStep on the UNet backbone (tape backward into the flat buffer, fused Adam): loss value, gradients of the
