@@ -18,7 +18,7 @@ struct DwArgs {
     int ld, groups, B, H, W;
 };
 
-template <bool FLIP>
+template <class ST, bool FLIP>      // ST: storage type of in / out (float, or __bf16 in the bf16-storage mode)
 __global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
     __shared__ __attribute__((aligned(16))) float halo[HALO_FLOATS];
     __shared__ __attribute__((aligned(16))) float dww[3 * 9 * 64];
@@ -42,13 +42,13 @@ __global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
         const long n = live ? (long)b * HW + (long)y * a.W + x : 0;
         for (int gi = 0; gi < a.groups; ++gi) {
             __syncthreads();
-            ksr_stage_halo<float>(halo, a.in, a.ld, 64 * gi, b, y0, x0, a.H, a.W, tid);
+            ksr_stage_halo<ST>(halo, a.in, a.ld, 64 * gi, b, y0, x0, a.H, a.W, tid);
             __syncthreads();
             float g[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = dwb[gi * 64 + 32 * h + i];
             ksr_dwconv_lane(halo, dww + gi * 576, wv, tok, h, g);
-            if (live) ksr_store32(a.out + n * a.ld + 64 * gi + 32 * h, g);
+            if (live) ksr_storen<ST, 32>(a.out, n * a.ld + 64 * gi + 32 * h, g);
         }
     }
 }
@@ -71,6 +71,7 @@ __global__ void __launch_bounds__(256) chan_apply_kernel(ApArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
+    using ST = typename KsrStore<PREC>::T;
     ksr_stage_weights<PREC, KH, NB, TRANS>(frag, biasfrag, a.w + (long)b * a.w_bstride, a.ldw, a.bias,
                                           MapSplit{a.nout_h}, MapSplit{a.kin_h}, tid, 256);
     __syncthreads();
@@ -80,24 +81,49 @@ __global__ void __launch_bounds__(256) chan_apply_kernel(ApArgs a) {
         const bool live = t < a.HW;
         const long n = (long)b * a.HW + (live ? t : 0);
         float x[KH];
-        const float4* src = reinterpret_cast<const float4*>(a.in + n * a.in_ld + a.in_c0 + h * a.kin_h);
+        if constexpr (sizeof(ST) == 4) {
+            const float4* src = reinterpret_cast<const float4*>(a.in + n * a.in_ld + a.in_c0 + h * a.kin_h);
 #pragma unroll
-        for (int q = 0; q < KH / 4; ++q) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (4 * q < a.kin_h) v = src[q];
-            x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            for (int q = 0; q < KH / 4; ++q) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (4 * q < a.kin_h) v = src[q];
+                x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
+        } else {
+            // bf16 storage: 16-byte pieces of 8 channels (the host checks that the halves are multiples of 8)
+            const uint4* src = reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(a.in) + n * a.in_ld + a.in_c0 + h * a.kin_h);
+#pragma unroll
+            for (int q = 0; q < KH / 8; ++q) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (8 * q < a.kin_h) v = src[q];
+                ksr_unpack8(v, x + 8 * q);
+            }
         }
         f32x16 acc[NB];
         ksr_wave_gemm<PREC, KH, NB>(frag, biasfrag, x, acc, lane);
         if (live) {
-            float4* dst = reinterpret_cast<float4*>(a.out + n * a.out_ld + a.out_c0 + h * a.nout_h);
+            if constexpr (sizeof(ST) == 4) {
+                float4* dst = reinterpret_cast<float4*>(a.out + n * a.out_ld + a.out_c0 + h * a.nout_h);
 #pragma unroll
-            for (int blk = 0; blk < NB; ++blk)
+                for (int blk = 0; blk < NB; ++blk)
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4)
-                    if (16 * blk + 4 * q4 < a.nout_h)
-                        dst[4 * blk + q4] = make_float4(acc[blk][4 * q4 + 0], acc[blk][4 * q4 + 1], acc[blk][4 * q4 + 2],
-                                                        acc[blk][4 * q4 + 3]);
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        if (16 * blk + 4 * q4 < a.nout_h)
+                            dst[4 * blk + q4] = make_float4(acc[blk][4 * q4 + 0], acc[blk][4 * q4 + 1], acc[blk][4 * q4 + 2],
+                                                            acc[blk][4 * q4 + 3]);
+            } else {
+                uint4* dst = reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + n * a.out_ld + a.out_c0 + h * a.nout_h);
+#pragma unroll
+                for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+                    for (int q8 = 0; q8 < 2; ++q8)
+                        if (16 * blk + 8 * q8 < a.nout_h) {
+                            float o[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) o[j] = acc[blk][8 * q8 + j];
+                            dst[2 * blk + q8] = ksr_pack8(o);
+                        }
+            }
         }
     }
 }
@@ -123,7 +149,11 @@ int launch_apply_p(const ApArgs& a, int B, hipStream_t s) {
 
 template <int KH, int NB, bool TRANS>
 int launch_apply(const ApArgs& a, int B, hipStream_t s) {
-    KSR_UNSUPPORTED(ksr_prec() == KSR_BF16S, "chan_apply: the channel-attention kernels have no bf16-storage variant");
+    if (ksr_prec() == KSR_BF16S) {
+        KSR_UNSUPPORTED(a.kin_h % 8 || a.nout_h % 8 || a.in_ld % 8 || a.in_c0 % 8 || a.out_ld % 8 || a.out_c0 % 8,
+                        "chan_apply: bf16 storage needs channel halves, row lengths and offsets that are multiples of 8");
+        return launch_apply_p<KSR_BF16S, KH, NB, TRANS>(a, B, s);
+    }
     return ksr_prec() == KSR_BF16 ? launch_apply_p<KSR_BF16, KH, NB, TRANS>(a, B, s) : launch_apply_p<KSR_F32, KH, NB, TRANS>(a, B, s);
 }
 
@@ -290,11 +320,14 @@ int dims_ok(int B, int H, int W, const char* who) {
 extern "C" int ksr_chan_dw_fwd(const float* in, const float* dw_w, const float* dw_b, float* out, int ld, int groups,
                                int B, int H, int W, hipStream_t stream) {
     KSR_CHECK_ARG(in && dw_w && dw_b && out, "chan_dw_fwd: null pointer");
-    KSR_CHECK_ARG(groups >= 1 && groups <= 3 && ld >= 64 * groups && ld % 4 == 0, "chan_dw_fwd: bad channel layout");
+    const bool st16 = ksr_prec() == KSR_BF16S;      // in / out are bf16 tensors in the bf16-storage mode
+    KSR_CHECK_ARG(groups >= 1 && groups <= 3 && ld >= 64 * groups && ld % (st16 ? 8 : 4) == 0, "chan_dw_fwd: bad channel layout");
     if (int rc = dims_ok(B, H, W, "chan_dw_fwd")) return rc;
     DwArgs a{in, dw_w, dw_b, out, ld, groups, B, H, W};
     const long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
-    hipLaunchKernelGGL(chan_dw_kernel<false>, dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(256), 0, stream, a);
+    const dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024));
+    if (st16) hipLaunchKernelGGL((chan_dw_kernel<__bf16, false>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((chan_dw_kernel<float, false>), grid, dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("chan_dw_fwd");
     return KSR_OK;
 }
@@ -303,11 +336,14 @@ extern "C" int ksr_chan_dw_fwd(const float* in, const float* dw_w, const float* 
 extern "C" int ksr_chan_dw_bwd(const float* dout, const float* dw_w, float* din, int ld, int groups, int B, int H, int W,
                                hipStream_t stream) {
     KSR_CHECK_ARG(dout && dw_w && din, "chan_dw_bwd: null pointer");
-    KSR_CHECK_ARG(groups >= 1 && groups <= 3 && ld >= 64 * groups && ld % 4 == 0, "chan_dw_bwd: bad channel layout");
+    const bool st16 = ksr_prec() == KSR_BF16S;
+    KSR_CHECK_ARG(groups >= 1 && groups <= 3 && ld >= 64 * groups && ld % (st16 ? 8 : 4) == 0, "chan_dw_bwd: bad channel layout");
     if (int rc = dims_ok(B, H, W, "chan_dw_bwd")) return rc;
     DwArgs a{dout, dw_w, nullptr, din, ld, groups, B, H, W};
     const long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
-    hipLaunchKernelGGL(chan_dw_kernel<true>, dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(256), 0, stream, a);
+    const dim3 grid((unsigned)(ntiles < 1024 ? ntiles : 1024));
+    if (st16) hipLaunchKernelGGL((chan_dw_kernel<__bf16, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((chan_dw_kernel<float, true>), grid, dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("chan_dw_bwd");
     return KSR_OK;
 }

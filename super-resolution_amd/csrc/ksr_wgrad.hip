@@ -842,6 +842,7 @@ extern "C" int ksr_wgrad(const float* dz, int dz_ld, int dz_c0, int J, const flo
             fast = true;                                                                                                 \
         }
         KSR_WG_FAST(12, 1) else KSR_WG_FAST(16, 1) else KSR_WG_FAST(24, 2) else KSR_WG_FAST(28, 3)
+        else KSR_WG_FAST(32, 3)      // 192 x 64: the q | k | v projections of the channel-attention head
 #undef KSR_WG_FAST
     }
     if (!fast)

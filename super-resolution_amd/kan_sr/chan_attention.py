@@ -23,6 +23,12 @@ def _new(dev, *shape):
     return torch.empty(*shape, device=dev, dtype=torch.float32)
 
 
+def _act(dev, *shape):
+    """[N, C] activation (or activation-gradient) tensor in the storage type of the current precision mode: bfloat16 in
+    the bf16-storage mode, which forward_kan's chain of kernels supports."""
+    return torch.empty(*shape, device=dev, dtype=engine.act_dtype())
+
+
 def _gram(dz, dz_c0, J, a, a_c0, HW, B, want_sq):
     """Per-image sum over pixels of dz[:, dz_c0:dz_c0+J]^T a[:, a_c0:a_c0+64]; returns (out [B,J,64], tail)."""
     L = lib()
@@ -45,10 +51,10 @@ class _QkvFn(torch.autograd.Function):
         engine.set_precision(precision)
         L = lib()
         N = x.shape[0]
-        pq = _new(x.device, N, 192)
+        pq = _act(x.device, N, 192)
         check(L.ksr_pointwise_fwd(ptr(x), ptr(w), ptr(b), ptr(pq), c_int(192), c_int(0), c_int(B), c_int(H), c_int(W),
                                   stream()), "ksr_pointwise_fwd")
-        qkv = _new(x.device, N, 192)
+        qkv = _act(x.device, N, 192)
         check(L.ksr_chan_dw_fwd(ptr(pq), ptr(dw_w), ptr(dw_b), ptr(qkv), c_int(192), c_int(3), c_int(B), c_int(H),
                                 c_int(W), stream()), "ksr_chan_dw_fwd")
         ctx.save_for_backward(x, w, dw_w, pq)
@@ -64,7 +70,7 @@ class _QkvFn(torch.autograd.Function):
         dev = x.device
         N = x.shape[0]
         dqkv = dqkv.contiguous()
-        dpq = _new(dev, N, 192)
+        dpq = _act(dev, N, 192)
         check(L.ksr_chan_dw_bwd(ptr(dqkv), ptr(dw_w), ptr(dpq), c_int(192), c_int(3), c_int(B), c_int(H), c_int(W),
                                 stream()), "ksr_chan_dw_bwd")
         g_dw_w, g_dw_b = _new(dev, 192, 9), _new(dev, 192)
@@ -79,7 +85,7 @@ class _QkvFn(torch.autograd.Function):
                           stream()), "ksr_wgrad")
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _new(dev, N, 64)
+            dx = _act(dev, N, 64)
             check(L.ksr_pointwise_bwd(ptr(dpq), c_int(192), ptr(w), ptr(dx), c_int(B), c_int(H), c_int(W), stream()),
                   "ksr_pointwise_bwd")
         return dx, g_w, g_b, g_dw_w, g_dw_b, None, None
@@ -182,8 +188,8 @@ class _AttnKanFn(torch.autograd.Function):
                                         c_int(n_coef), host_floats(knots), c_int(len(knots)), c_int(spline_order), stream()),
                   "ksr_feed_kan_dx_img")
         J = 2 * int(L.ksr_feed_kan_lane_len(c_int(r), c_int(n_coef)))
-        gparam = _new(dev, B * HW, J)
-        dqkv = _new(dev, B * HW, 192)
+        gparam = _act(dev, B * HW, J)
+        dqkv = _act(dev, B * HW, 192)
         kn = host_floats(knots)
         # gradient of the per-pixel parameters (lane order) and, through M_b, of v: written into the v third of dqkv
         check(L.ksr_feed_kan_bwd_img(ptr(gout), c_int64(3 * HW * r * r), ptr(x), c_int64(3 * HW), ptr(M), ptr(save_us), ptr(dqkv),
@@ -210,7 +216,8 @@ def _to_nhwc(t):
 
 
 class ConvSepKanAttention(nn.Module):
-    """Drop-in for the reference class of the same name; `precision` ("fp32" | "bf16") is the only addition."""
+    """Drop-in for the reference class of the same name; `precision` ("fp32" | "bf16"; "bf16s" = bf16 activation storage,
+    for forward_kan only) is the only addition."""
 
     def __init__(self, in_channels: int, mid_channels: int, out_channels: int):
         super().__init__()
@@ -257,8 +264,10 @@ class ConvSepKanAttention(nn.Module):
         if self.in_channels != 64 or self.mid_channels != 64 or self.out_channels != r * r * (n_coef + 2):
             raise KsrError(f"ConvSepKanAttention({self.in_channels}, {self.mid_channels}, {self.out_channels}) does not produce "
                            f"the parameters of a KAN cell with upscale {r} and {n_coef} coefficients")
-        if not feat.is_cuda or feat.dtype != torch.float32:
-            raise KsrError("ConvSepKanAttention needs fp32 GPU tensors (the HIP path is the only path)")
+        want = torch.bfloat16 if self.precision == "bf16s" else torch.float32
+        if not feat.is_cuda or feat.dtype != want:
+            raise KsrError(f"ConvSepKanAttention(precision={self.precision!r}) needs {want} GPU features (the HIP path is the "
+                           "only path)")
         qkv = self._qkv(feat, dims)
         return _AttnKanFn.apply(qkv, self.a_proj.weight.reshape(self.out_channels, 64), self.a_proj.bias, x_img.contiguous(),
                                 dims, self.precision, n_coef, tuple(knots), spline_order, r)

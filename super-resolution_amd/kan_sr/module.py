@@ -186,16 +186,18 @@ class ConvSepKan(nn.Module):
         """Encoder trunk -> channel attention head -> KAN + pixel shuffle + chroma."""
         from .ops import kan_head
         head = self.layers[-1].encoder.encoder.feed
-        # bf16 storage: the encoder trunk runs in that mode; the head's kernels keep fp32 tensors (bf16 operands), so the
+        # bf16 storage: the encoder trunk runs in that mode, and so does the head when its last step runs inside the fused
+        # feed+KAN kernel; the head with a materialised parameter tensor keeps fp32 tensors (bf16 operands), so there the
         # 64-channel features are widened once at the boundary (and their gradient narrowed by autograd's cast)
-        head.precision = "bf16" if self.precision == "bf16s" else self.precision
+        head_bf16s = self.precision == "bf16s" and FUSED_ATTENTION_HEAD
+        head.precision = self.precision if (self.precision != "bf16s" or head_bf16s) else "bf16"
         with torch.set_grad_enabled(needs_grad):
             if needs_grad:
                 from .autograd import trunk_train
                 feat = trunk_train(x, p, pre, g, p_drop, seed, self.precision)
             else:
                 feat = engine.encoder_forward(x, p, pre, g, None, p_drop, seed)
-            if feat.dtype is not torch.float32:
+            if feat.dtype is not torch.float32 and not head_bf16s:
                 feat = feat.float()
             if FUSED_ATTENTION_HEAD:
                 # the head's last 1x1 map (one matrix per image) runs inside the fused feed+KAN kernel: no [N, P] tensor
