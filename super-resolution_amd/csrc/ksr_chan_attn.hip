@@ -239,12 +239,20 @@ __global__ void __launch_bounds__(1024) chan_soft_bwd_kernel(SoftBwdArgs a) {
         if (tid < 64) { nq[tid] = cl; pq[tid] = pr; } else { nk[tid - 64] = cl; pk[tid - 64] = pr; }
     }
     const float* Gd = a.Gd + (long)b * a.P * 64;
-    // dA = W_a^T Gd
-    for (int idx = tid; idx < 4096; idx += 1024) {
-        const int c = idx >> 6, cc = idx & 63;
-        float acc = 0.f;
-        for (int p = 0; p < a.P; ++p) acc += a.Wa[p * 64 + c] * Gd[p * 64 + cc];
-        dS[c][cc] = acc;
+    // dA = W_a^T Gd: a wave owns rows c = wave + 16 k (k < 4), lane = column; per p one coalesced read of Gd's row and four
+    // wave-uniform (scalar) reads of W_a feed four independent sums
+    {
+        const int c0 = __builtin_amdgcn_readfirstlane(tid >> 6), cc = tid & 63;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int p = 0; p < a.P; ++p) {
+            const float gv = Gd[p * 64 + cc];
+            const float* wr = a.Wa + p * 64 + c0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] += wr[16 * k] * gv;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dS[c0 + 16 * k][cc] = acc[k];
     }
     __syncthreads();
     if (tid < 256) {   // softmax derivative, row sums of dS * S
@@ -288,14 +296,22 @@ __global__ void __launch_bounds__(1024) chan_soft_bwd_kernel(SoftBwdArgs a) {
         }
         Mqk[idx] = v;
     }
-    // dW_a contribution of this image: Gd A^T
-    for (int idx = tid; idx < a.P * 64; idx += 1024) {
-        const int p = idx >> 6, c = idx & 63;
-        const float* g = Gd + p * 64;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int cc = 0; cc < 64; ++cc) acc += g[cc] * As[c][cc];
-        a.dWa_part[(long)b * a.P * 64 + idx] = acc;
+    // dW_a contribution of this image: Gd A^T.  A wave owns rows p = wave + 16 k, lane = column c: row c of A stays in
+    // registers, Gd's row is read through wave-uniform (scalar) loads
+    {
+        const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+        float ar[64];
+#pragma unroll
+        for (int cc = 0; cc < 64; ++cc) ar[cc] = As[c][cc];
+        for (int p = w0; p < a.P; p += 16) {
+            const float* g = Gd + p * 64;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 64; cc += 4) {
+                s0 += g[cc] * ar[cc]; s1 += g[cc + 1] * ar[cc + 1]; s2 += g[cc + 2] * ar[cc + 2]; s3 += g[cc + 3] * ar[cc + 3];
+            }
+            a.dWa_part[(long)b * a.P * 64 + p * 64 + c] = (s0 + s1) + (s2 + s3);
+        }
     }
 }
 
