@@ -205,13 +205,31 @@ __global__ void __launch_bounds__(256) chan_soft_fwd_kernel(SoftArgs a) {
         a.S[(long)b * 4096 + c * 64 + part * 16 + j] = s[j];
     }
     __syncthreads();
-    for (int idx = tid; idx < a.P * 64; idx += 256) {
-        const int p = idx >> 6, cc = idx & 63;
-        const float* w = a.Wa + p * 64;
-        float acc = 0.f;
-#pragma unroll 8
-        for (int ci = 0; ci < 64; ++ci) acc += w[ci] * As[ci][cc];
-        a.M[(long)b * a.P * 64 + idx] = acc;
+    // M = W_a A: a wave owns rows p = wave + 4 k, lane = column cc; A's column stays in registers, W_a's row is read through
+    // wave-uniform (scalar) loads; two rows at a time for two independent chains (each row's sum keeps its order)
+    {
+        const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6), cc = tid & 63;
+        float ar[64];
+#pragma unroll
+        for (int ci = 0; ci < 64; ++ci) ar[ci] = As[ci][cc];
+        float* Mb = a.M + (long)b * a.P * 64;
+        int p = w0;
+        for (; p + 4 < a.P; p += 8) {
+            const float* wa = a.Wa + p * 64;
+            const float* wb = wa + 4 * 64;
+            float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+            for (int ci = 0; ci < 64; ++ci) { acc0 += wa[ci] * ar[ci]; acc1 += wb[ci] * ar[ci]; }
+            Mb[p * 64 + cc] = acc0;
+            Mb[(p + 4) * 64 + cc] = acc1;
+        }
+        for (; p < a.P; p += 4) {
+            const float* wa = a.Wa + p * 64;
+            float acc0 = 0.f;
+#pragma unroll
+            for (int ci = 0; ci < 64; ++ci) acc0 += wa[ci] * ar[ci];
+            Mb[p * 64 + cc] = acc0;
+        }
     }
 }
 
