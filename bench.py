@@ -62,8 +62,9 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4, train: bool = 
         # bf16 storage: in-projection inside the attention forward: x in, qkv (kept for the backward) and ctx out, both layers
         "ksr_batch_qkv_attn_fwd": ("hbm", 2 * (2 * 64 * 192 + 256 * S), 2 * (256 + 768 + 256), pk),
         "ksr_dwrelu_pw_fwd": ("hbm", 2 * 64 * 64 + 2 * 9 * 64, 256 + 256 + 256, pk),
-        # one image (inference): softmax over a single key is 1, the context is the value projection: q and k are not needed
-        "ksr_batch_tx_layer_fwd": ("mfma", 2 * ((2 * 64 * 64 if S == 1 else 2 * 64 * 192 + 256 * S) + lin_post), 2 * 512, pk),
+        # one image (inference): softmax over a single key is 1, the context is the value projection, and the out-projection of
+        # a linear function of the token is one 64 x 64 matrix (W_out W_v): lin_post alone
+        "ksr_batch_tx_layer_fwd": ("mfma", 2 * ((0 if S == 1 else 2 * 64 * 192 + 256 * S) + lin_post), 2 * 512, pk),
         # attention: the bf16-operand kernels are bound by memory and vector arithmetic (masks, exp, dropout hash), the
         # matrix pipe is < 10 % busy: priced against HBM; the exact fp32 kernels against the fp32 MFMA peak
         "ksr_batch_attn_fwd": ("hbm" if bf16 else "mfma", 2 * 256 * S, 2 * (768 + 256), f32),
