@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Timing of the attention-head configuration (G=16, ConvSepKanAttention(64, 64, 336) in place of feed): forward +
-backward through autograd, 64 patches of 128x128, per entry point.  python tools/cfg4_time.py [fp32|bf16|bf16s]"""
+backward through autograd and the native training step, 64 patches of 128x128, per entry point.  python tools/cfg4_time.py [fp32|bf16|bf16s]"""
 import os
 import sys
 import time
@@ -34,6 +34,18 @@ for prec in (sys.argv[1:] or ["fp32", "bf16", "bf16s"]):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 10
     print(f"{prec}: {dt * 1e3:.2f} ms/step, {64 * 512 * 512 / 1e6 / dt:.1f} output MP/s", flush=True)
+    # the native training step (fused loss + Adam, tape backward into the flat gradient buffer)
+    from kan_sr.train import TrainStep  # noqa: E402
+    ts = TrainStep(m, lr=1e-3, loss="l1+ssim")
+    for _ in range(3):
+        ts.step(x, tgt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        ts.step(x, tgt)
+    torch.cuda.synchronize()
+    dts = (time.perf_counter() - t0) / 10
+    print(f"{prec}: TrainStep(l1+ssim) {dts * 1e3:.2f} ms/step, {64 * 512 * 512 / 1e6 / dts:.1f} output MP/s", flush=True)
     _lib.PROFILE = {}
     for _ in range(3):
         step()
