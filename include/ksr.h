@@ -417,6 +417,9 @@ int ksr_bilinear_up_to_rgb(const float* x_lr, const float* y_hr, int64_t y_batch
  *           ksr_chan_soft_fwd -> ksr_chan_apply(v, M).
  * Backward: ksr_gram_batched(dy, v) -> ksr_chan_soft_bwd -> ksr_chan_apply(dy, M^T) / ksr_chan_apply([q|k], Mqk)
  *           -> ksr_chan_dw_bwd -> ksr_dwconv_wgrad x3, ksr_wgrad, ksr_pointwise_bwd.
+ * In the bf16-storage mode (ksr_set_precision) the [N, C] tensors of ksr_chan_dw_fwd / _bwd and ksr_chan_apply are bf16 like
+ * those of every other kernel of the chain (channel counts, row lengths and offsets then multiples of 8); the per-image
+ * matrices stay fp32.
  * ------------------------------------------------------------------------------------------- */
 
 /* Depthwise 3x3 (zero pad 1) over `groups` (1..3) blocks of 64 channels of an NHWC tensor with ld channels
