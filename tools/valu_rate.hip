@@ -1,7 +1,9 @@
 // Issue rate of a few integer vector instructions on one GPU: hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate
 // Every thread runs 8 independent chains of one instruction; 4 waves per SIMD on every CU.  Prints wave-instructions per
 // SIMD and microsecond; the ratio between the rows is what matters.
-// MI355X: all eight within 15 % of each other (≈ 420-500 per us: one instruction per 4-5 cycles); the 32-bit multiply is a full-rate instruction.
+// MI355X: the integer instructions within 15 % of each other (≈ 420-500 per us: one per ≈ 5 cycles; the 32-bit multiply is a
+// full-rate instruction); v_fma_f32 670 per us; v_pk_fma_f32 347 per us (two multiply-adds per lane at half the instruction rate:
+// the same flops as v_fma_f32, fewer instructions to issue); v_rcp_f32 / v_exp_f32 219 per us; v_cvt_pk_bf16_f32 458 per us.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
@@ -21,6 +23,11 @@ __global__ void __launch_bounds__(256) rate_kernel(unsigned* out, unsigned seed,
             if (OP == 5) asm volatile("v_alignbit_b32 %0, %0, %0, 13" : "+v"(x[i]));
             if (OP == 6) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[i]) : "v"(seed));
             if (OP == 7) asm volatile("v_perm_b32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(seed));
+            if (OP == 8) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(x[i]) : "v"(seed));
+            if (OP == 9 && (i & 1) == 0) asm volatile("v_pk_fma_f32 %0, %0, %1, %0" : "+v"(*reinterpret_cast<unsigned long long*>(&x[i])) : "v"(*reinterpret_cast<unsigned long long*>(&x[(i + 2) & 7])));
+            if (OP == 10) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[i]));
+            if (OP == 11) asm volatile("v_exp_f32 %0, %0" : "+v"(x[i]));
+            if (OP == 12) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(x[i]) : "v"(seed));
         }
     }
     unsigned s = 0;
@@ -56,6 +63,11 @@ int main() {
     run<3>("v_mad_u32_u24", out);
     run<5>("v_alignbit_b32", out);
     run<7>("v_perm_b32", out);
+    run<8>("v_fma_f32", out);
+    run<9>("v_pk_fma_f32 x1/2", out);     // half as many instructions per iteration: a rate equal to v_fma_f32's shows as half
+    run<10>("v_rcp_f32", out);
+    run<11>("v_exp_f32", out);
+    run<12>("v_cvt_pk_bf16_f32", out);
     hipFree(out);
     return 0;
 }
