@@ -29,16 +29,23 @@ typedef struct ihipStream_t* ksr_stream_t; /* == hipStream_t */
 int ksr_version(void);
 const char* ksr_last_error(void);
 
-/* Precision mode of the kernels below (a property of the CALLING THREAD, read at launch time; every thread starts in
- * mode 0, so concurrent callers with different modes do not interfere):
+/* Precision mode of the kernels below.  The mode is a property of the CALLING THREAD (thread-local storage inside the
+ * library), read by each entry point at launch time: ksr_set_precision changes it for the thread that calls it and for
+ * no other, ksr_get_precision returns the calling thread's mode, and EVERY NEW THREAD STARTS IN MODE 0.  A program that
+ * sets the mode on one thread and launches from another (a worker pool; autograd's backward thread) must set it again on
+ * the launching thread: in mode 2 the activation buffers are bf16, and an entry point that runs in mode 0 would read them
+ * as fp32 (twice the bytes: an out-of-bounds read, not an error code).  Concurrent callers with different modes do not
+ * interfere.
  *   0  exact fp32 MFMA, fp32 storage: the mode in which parity with the reference's fp32 results is stated;
  *   1  bf16 MFMA operands with fp32 accumulation (1x1 convs / linears, attention products, weight gradients),
  *      fp32 storage (the reference has no such mode; separately stated tolerance);
  *   2  as 1, and every [N, C] activation / activation-gradient tensor exchanged between the kernels of the
  *      hyper-encoder path is STORED AS bf16: in this mode the `float*` parameters that carry such tensors
  *      point to bf16 buffers of the same shape.  Images, outputs, per-pixel scalars (v, rstd, dpre),
- *      parameters, parameter gradients and workspaces stay fp32.  The KAN-cell, bilinear, loss, optimiser and
- *      channel-attention entry points have no mode-2 variant (fp32 tensors only).
+ *      parameters, parameter gradients and workspaces stay fp32.  The stand-alone KAN-cell, bilinear, loss,
+ *      optimiser and UNet entry points have no mode-2 variant (fp32 tensors only); of the channel-attention entry points
+ *      ksr_chan_dw_* and ksr_chan_apply_* take bf16 tensors in mode 2 (stated at their declarations), the per-image
+ *      algebra (ksr_chan_soft_*) stays fp32.
  * The spline basis, LayerNorm, softmax and all accumulation are fp32 in every mode.
  * out_f32_copy / in_f32_copy arguments: the one tensor whose bf16 rounding matters (the sigmoid output that
  * enters the first transformer layer's residual + LayerNorm: values 0.5 +- 1e-3 at initialisation) can be kept

@@ -26,7 +26,7 @@
 // accumulation (v_mfma_f32_32x32x16_bf16, 16x the rate).  Storage in HBM and all other arithmetic stay fp32.
 enum { KSR_F32 = 0, KSR_BF16 = 1, KSR_BF16S = 2 };   // KSR_BF16S: bf16 MFMA operands AND bf16 activation storage
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-int ksr_prec();   // process-wide setting (ksr_set_precision)
+int ksr_prec();   // the calling thread's mode (ksr_set_precision; thread-local, a new thread starts in KSR_F32)
 // Runs CALL(PREC) for the current mode; CALL is a macro taking the mode constant.
 #define KSR_DISPATCH_PREC(CALL)                                   \
     do {                                                          \

@@ -118,7 +118,7 @@ class ConvSepKan(nn.Module):
 
     backbone="unet" (keyword only) selects the reference's UNet (conv_sep_kan/unet.py) as the hyper-encoder in place
     of GazeTR, i.e. `self.encoder = UNet(in_channels, out_channels)` at conv_sep_kan_encoder.py:17; state_dict keys
-    `layers.N.encoder.encoder.{proj,down1..4,up1..4,att1..4,reproj}.*`.  Forward (inference) only."""
+    `layers.N.encoder.encoder.{proj,down1..4,up1..4,att1..4,reproj}.*`.  Forward and backward (fp32 only)."""
 
     def __init__(self, in_channels: list, out_channels: list, kernel_sizes: list, grid_size, spline_order,
                  residual_std, grid_range, upscale, *, attention: bool = False, backbone: str = "gazetr"):

@@ -223,6 +223,13 @@ class TrainStep:
             raise KsrError(f"TrainStep.step: tgt must be a float32 tensor [{want[0]}, >=1 (3 with the SSIM term), {want[1]}, "
                            f"{want[2]}] on the input's device, got {tgt.dtype} {tuple(tgt.shape)}")
         tgt = tgt.contiguous()
+        if self.tape_backward and (self.capture or self.device_state) and self._tape_dropout_live():
+            # The tape path draws its dropout seed on the host inside ConvSepKan.forward and passes it by value: a recorded
+            # graph would replay one set of masks for ever; and the device-resident seed word is a per-thread setting that
+            # autograd's backward thread does not see, so forward and backward masks would differ.
+            raise KsrError("TrainStep(capture=True / device_state=True) with live dropout is only supported for the GazeTR "
+                           "encoder with the plain feed head; put the model in eval() mode or construct the step without "
+                           "capture / device_state")
         if self.device_state and self._lr_on_dev != float(self.lr):
             self._lr_dev.fill_(float(self.lr))
             self._lr_on_dev = float(self.lr)
@@ -243,6 +250,13 @@ class TrainStep:
             if hasattr(encoder, "invalidate_prepared"):
                 encoder.invalidate_prepared()         # the weights changed under the cached kernel layouts
         return self.loss
+
+    def _tape_dropout_live(self) -> bool:
+        """Whether a forward of the model on the autograd tape would draw dropout masks (GazeTR trunk in train mode)."""
+        m = self.model
+        if not m.training or getattr(m, "backbone", "gazetr") != "gazetr":
+            return False
+        return m.layers[-1].encoder.encoder.encoder.layers[0].p_drop > 0
 
     def _adam_in_body(self) -> bool:
         return self.device_state and self.comm is None

@@ -406,13 +406,16 @@ def test_dropout_masks_change_with_the_device_step_counter():
     assert a != b and a == c
 
 
-def test_gradient_exchange_schedule_order():
+@pytest.mark.parametrize("precision,side_wgrad", [("fp32", False), ("bf16s", False), ("bf16s", True)])
+def test_gradient_exchange_schedule_order(precision, side_wgrad, monkeypatch):
     """The two-bucket exchange of the GazeTR step, with a recording stand-in for the communicator and the library
     calls logged in launch order: bucket 1 (feed + transformer layers + final norm) is issued after the last launch
-    that writes into it (layer 0's in_proj weight gradient) and before the first launch of the conv-trunk backward
-    (ffn4's gate_pw backward); bucket 2 after the last backward launch; Adam after both.  The buckets are the two
-    halves [0, tail_end) and [tail_end, total) of the flat gradient buffer."""
-    from kan_sr import _lib
+    that writes into it (layer 0's in-projection weight gradient) and before the first launch of the conv-trunk
+    backward (ffn4's gate_pw backward); bucket 2 after the last backward launch; Adam after both.  The buckets are the
+    two halves [0, tail_end) and [tail_end, total) of the flat gradient buffer.  Run in the exact mode and in bf16 storage
+    (the benchmarked mode, whose backward uses other entry points: weight gradients accumulated inside the data-gradient
+    kernels), there also with the parameter-gradient reductions on the second stream."""
+    from kan_sr import _lib, autograd
     from kan_sr.train import TrainStep
     log = []
 
@@ -425,8 +428,11 @@ def test_gradient_exchange_schedule_order():
         def close(self):
             pass
 
+    monkeypatch.setattr(autograd, "SIDE_STREAM_FOR_WGRAD", side_wgrad)
+    monkeypatch.setattr(autograd, "SIDE_STREAM_MIN_TOKENS", 0)
     m, _ = _model(4, seed=2)
     m = m.cuda().eval()
+    m.precision = precision
     ts = TrainStep(m, world_size=2, rank=0, comm=Recorder(), loss="l1+ssim")
     proxy = _lib.lib()
     orig_getattr = type(proxy).__getattr__
@@ -437,34 +443,51 @@ def test_gradient_exchange_schedule_order():
             return fn
 
         def wrapped(*a):
-            log.append((name,))
+            log.append((name, torch.cuda.current_stream().cuda_stream))
             return fn(*a)
         return wrapped
 
     type(proxy).__getattr__ = logging_getattr
     try:
-        x, tgt = torch.rand(2, 3, 16, 32).cuda(), torch.rand(2, 3, 64, 128).cuda()
+        x, tgt = torch.rand(4, 3, 16, 32).cuda(), torch.rand(4, 3, 64, 128).cuda()
         ts.step(x, tgt)
         torch.cuda.synchronize()
     finally:
         type(proxy).__getattr__ = orig_getattr
+        from kan_sr import engine
+        engine.set_precision("fp32")
     names = [e[0] for e in log]
     ar = [i for i, n in enumerate(names) if n == "allreduce"]
     assert len(ar) == 2
     b1, b2 = log[ar[0]], log[ar[1]]
     assert b1[1] == ts.flat_g.data_ptr() and b1[2] == ts.tail_end
     assert b2[1] == ts.flat_g.data_ptr() + 4 * ts.tail_end and b2[2] == ts.flat_g.numel() - ts.tail_end
-    assert b1[3] == b2[3] == ts.side.cuda_stream != torch.cuda.current_stream().cuda_stream
-    in_proj_bwd = [i for i, n in enumerate(names) if n == "ksr_in_proj_bwd"]
+    main = torch.cuda.current_stream().cuda_stream
+    assert b1[3] == b2[3] == ts.side.cuda_stream != main
+    # launches that write bucket-1 gradients: the feed + KAN backward and its weight gradient, every transformer-layer
+    # backward kernel, the in-projection backward (bf16 storage: data and weight gradient in one kernel)
+    in_proj = "ksr_in_proj_bwd_wg" if precision == "bf16s" else "ksr_in_proj_bwd"
+    in_proj_bwd = [i for i, n in enumerate(names) if n == in_proj]
     assert len(in_proj_bwd) == 2
+    tail_only = ("ksr_feed_kan_bwd", "ksr_batch_tx_layer_bwd_token", "ksr_batch_tx_layer_bwd_out_wg", "ksr_batch_attn_bwd",
+                 "ksr_batch_tx_layer_bwd_attn", "ksr_wgrad_affine_input", in_proj)
+    tail_launches = [i for i, n in enumerate(names) if n in tail_only]
+    assert names.count("ksr_batch_tx_layer_bwd_token") == 2
+    if precision == "bf16s":
+        assert names.count("ksr_batch_tx_layer_bwd_out_wg") == 2 and "ksr_in_proj_bwd" not in names
     last_tail_wgrad = max(i for i, n in enumerate(names) if n == "ksr_wgrad" and i < in_proj_bwd[1])
-    first_trunk = min(i for i, n in enumerate(names) if n in ("ksr_gate_pw_bwd", "ksr_gate_pw_bwd_wg"))
-    assert last_tail_wgrad < in_proj_bwd[1] < ar[0]          # after every launch that writes a bucket-1 gradient
+    trunk_first = "ksr_gate_pw_bwd_wg" if precision == "bf16s" else "ksr_gate_pw_bwd"
+    first_trunk = min(i for i, n in enumerate(names) if n == trunk_first)
+    assert last_tail_wgrad < ar[0] and max(tail_launches) < ar[0]     # after every launch that writes a bucket-1 gradient
     assert ar[0] < first_trunk, (ar[0], first_trunk)
-    backward_launches = [i for i, n in enumerate(names) if n.endswith(("_bwd", "_wgrad", "_wg", "outer2"))]
+    backward_launches = [i for i, n in enumerate(names) if n.endswith(("_bwd", "_wgrad", "_wg", "outer2", "_bwd_stem_v",
+                                                                       "_wgrad_v", "_bwd_v"))]
     assert ar[1] > max(backward_launches)
+    used_side = {e[1] for e in log if e[0] != "allreduce"} - {main}
+    assert bool(used_side) == side_wgrad, "parameter-gradient reductions on the second stream: not as requested"
     adam = names.index("ksr_adam_step")
     assert adam > ar[1] and adam == len(names) - 1
+    assert log[adam][1] == main
     # the 1/world scaling is applied by Adam: a second, exchange-free step on the same data with doubled gradients
     # is not needed here; the gloo test in test_host_logic.py covers the arithmetic
     ts.close()

@@ -240,3 +240,54 @@ def test_unet(tag):
         for n, v in p.items():
             if v.requires_grad:
                 assert rel_l2(v.grad, t(g[f"{tag}.g.{n}"])) <= 5e-4, n
+
+
+def test_attention_head_gradients_are_ill_conditioned_for_bf16_features():
+    """Why the cfg-4 wiring (channel-attention head, G = 16) has its own bf16 gradient bound: in the ORACLE itself, rounding
+    nothing but the head's input features (the trunk's final-LayerNorm output) to bf16 in the forward moves the parameter
+    gradients outside the bf16 contract tolerance of the plain model (cosine >= 0.999, rel-L2 <= 5e-2 for tensors of >= 64
+    elements).  The head's normalised Gram product + softmax amplifies a 2^-9 relative perturbation of its input about
+    twenty-fold in the gradients, so no bf16 evaluation of the trunk can meet that bound; the HIP path's bf16 modes are held
+    to cosine >= 0.99 / rel-L2 <= 0.15 there (tests/test_gpu_chan_attention.py)."""
+    class RoundFwd(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x.bfloat16().float()
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    torch.manual_seed(5)
+    r, G, B, H, W = 4, 16, 16, 32, 32
+    from kan_sr.module import ConvSepKan          # parameter container only (default initialisation); no kernel runs
+    m = ConvSepKan([1], [r * r], [3], G, 3, 0.1, [-1, 1], r, attention=True).eval()
+    with torch.no_grad():
+        for n, prm in m.named_parameters():
+            if "norm" in n:
+                prm.add_(0.1 * torch.randn_like(prm))
+    params = {n: v.detach().clone() for n, v in m.state_dict().items()}
+    x = torch.rand(B, 3, H, W)
+    gy = torch.randn(B, 3, r * H, r * W, generator=torch.Generator().manual_seed(5))
+    grads = []
+    orig = orc.chan_attention
+    for rounded in (False, True):
+        orc.chan_attention = (lambda xx, p, prefix, **kw: orig(RoundFwd.apply(xx), p, prefix, **kw)) if rounded else orig
+        try:
+            p = {n: v.clone().requires_grad_() for n, v in params.items()}
+            y = orc.conv_sep_kan_forward(x, p, out_channels=[r * r], grid_size=G, spline_order=3, grid_range=[-1, 1], upscale=r,
+                                         attention=True)
+            (y * gy).sum().backward()
+        finally:
+            orc.chan_attention = orig
+        grads.append({n: v.grad for n, v in p.items() if v.grad is not None})
+    outside = []
+    for n, ref in grads[0].items():
+        if ref.numel() < 64:
+            continue
+        a, b = grads[1][n].double().flatten(), ref.double().flatten()
+        cos = float(a @ b / (a.norm() * b.norm()).clamp_min(1e-30))
+        if cos < 0.999 or rel_l2(a, b) > 5e-2:
+            outside.append((n, cos))
+    assert len(outside) >= 5, outside          # measured: 20 of the tensors, worst cosine 0.9977 (layer 1 linear1.weight)
+    assert all(c >= 0.99 for _, c in outside), outside
