@@ -322,7 +322,24 @@ def main():
         tgt = torch.rand(B, 3, 4 * H, 4 * W, device=dev)
         # UNet step: forward + loss + backward replayed from a HIP graph (recorded on the third step; the step is bound by
         # the host's launch rate otherwise).  The per-kernel timing run further down runs uncaptured.
-        ts = TrainStep(model, world_size=world, rank=rank, loss=args.loss, capture=graph and not args.no_graph)
+        ts, err = None, ""
+        try:
+            ts = TrainStep(model, world_size=world, rank=rank, loss=args.loss, capture=graph and not args.no_graph)
+        except Exception as e:       # e.g. ksr_comm_init: the RCCL message is in the exception text
+            err = f"rank {rank}: {type(e).__name__}: {e}"
+        if dist is not None:
+            # every rank learns whether every rank has its communicator BEFORE the first barrier: a rank that failed must
+            # not leave the others waiting in a collective
+            ok = torch.tensor([0 if ts is None else 1], dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                print(err or f"rank {rank}: another rank could not create the gradient communicator", file=sys.stderr, flush=True)
+                if ts is not None:
+                    ts.close()
+                dist.destroy_process_group()
+                raise SystemExit(3)
+        elif ts is None:
+            raise SystemExit(err)
         mode = {"fp32": "exact fp32", "bf16": "bf16 MFMA operands / fp32 accumulate and storage",
                 "bf16s": "bf16 MFMA operands and activation storage / fp32 accumulate"}[args.precision]
         wl = (f"x4 SR training step, {mode} (fwd + loss {args.loss} + bwd + RCCL gradient all-reduce + Adam), {B} patches of 128x128 per "

@@ -9,7 +9,19 @@ Under Lightning the same pair goes into the strategy's constructor (`lightning_s
 the reference's pipeline (DefaultPipeline.training_step, configure_optimizers, ModelCheckpoint) stays as it is, and
 `kan_sr.checkpoint` reads and writes its `last.ckpt` files.  The native step `kan_sr.train.TrainStep` remains the
 faster path (flat buffers, two overlapped buckets, fused Adam); this module is for users who keep the reference's
-trainer."""
+trainer.
+
+Communicators.  libksr holds ONE RCCL communicator per process (ksr_comm_init / ksr_comm_destroy), and KsrCommState
+creates it: do not run a kan_sr.train.TrainStep with world_size > 1 (which owns and, in close(), destroys the same
+communicator) in a process that also uses this hook.  The hook always reduces over ALL ranks of that communicator, so the
+DDP instance must span the default process group (KsrCommState checks the world size against torch.distributed's; a DDP
+built on a sub-group is refused by the size check or would be averaged over the wrong ranks - do not do that).  torch DDP
+itself only needs its process group for the parameter broadcast at construction and for its bucket bookkeeping once the
+hook carries the gradients: initialise torch.distributed with the "gloo" backend (as bench.py does) and no second RCCL
+communicator exists in the process; with the "nccl" backend the two communicators coexist (tested with one rank only: no
+multi-GPU machine was available to this build) and each takes its own share of device memory and channels.
+The hook returns a COMPLETED future: the collective and the division are enqueued on the stream DDP calls the hook on
+(its current stream), and DDP's copy-back of the bucket into the parameters' .grad runs on that same stream afterwards."""
 from ctypes import c_void_p
 from typing import Optional
 
@@ -27,6 +39,10 @@ class KsrCommState:
     def __init__(self, rank: int, world_size: int, comm=None):
         if world_size < 1 or not (0 <= rank < world_size):
             raise KsrError(f"bad rank / world size: {rank} / {world_size}")
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() != world_size:
+            raise KsrError(f"KsrCommState(world_size={world_size}) in a process group of {dist.get_world_size()} ranks: the "
+                           "hook reduces over every rank of libksr's communicator, which must be DDP's default group")
         self.rank, self.world_size = rank, world_size
         self.comm = comm if comm is not None else RcclComm(rank, world_size)
         self.buckets_reduced = 0
@@ -40,9 +56,11 @@ def ksr_allreduce_hook(state: KsrCommState, bucket: torch.distributed.GradBucket
     libksr) and divides by the world size - the mean DDP's default hook produces.  The collective is enqueued on the
     stream DDP calls the hook on, so the completed future it returns is ordered before DDP's copy-back."""
     buf = bucket.buffer()
-    if buf.dtype is not torch.float32 or not buf.is_cuda:
+    rccl = isinstance(state.comm, RcclComm)
+    if buf.dtype is not torch.float32 or (rccl and not buf.is_cuda):
         raise KsrError(f"ksr_allreduce_hook needs float32 GPU gradient buckets, got {buf.dtype} on {buf.device}")
-    state.comm.allreduce_sum(buf, c_void_p(torch.cuda.current_stream().cuda_stream))
+    # (a communicator that is not libksr's RCCL wrapper - the CPU stand-in of the multi-process tests - takes CPU buckets)
+    state.comm.allreduce_sum(buf, c_void_p(torch.cuda.current_stream().cuda_stream) if buf.is_cuda else None)
     if state.world_size > 1:
         buf.div_(state.world_size)
     state.buckets_reduced += 1

@@ -143,6 +143,70 @@ def test_two_rank_gloo_gradient_exchange(tmp_path):
         assert p.returncode == 0 and f"OK {r}" in o, o[-2000:]
 
 
+DDP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["KSR_ROOT"]); sys.path.insert(0, os.path.join(os.environ["KSR_ROOT"], "super-resolution_amd"))
+from torch.nn.parallel import DistributedDataParallel as DDP
+from kan_sr.ddp import KsrCommState, ksr_allreduce_hook
+from kan_sr.train import GlooComm
+from kan_sr._lib import KsrError
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+def net():
+    torch.manual_seed(7)
+    return torch.nn.Sequential(torch.nn.Conv2d(1, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1))
+torch.manual_seed(100 + rank)                       # every rank its own shard
+x, tgt = torch.rand(3, 1, 8, 8), torch.rand(3, 4, 8, 8)
+def grads(model):
+    model.zero_grad(set_to_none=True)
+    (model(x) - tgt).abs().mean().backward()
+    return [p.grad.clone() for p in model.parameters()]
+plain = net()
+local = grads(plain)                                # this rank's own gradients
+state = KsrCommState(rank, world, comm=GlooComm(world))
+hooked = DDP(net(), bucket_cap_mb=0.0005)           # tiny buckets: several hook calls per backward
+hooked.register_comm_hook(state, ksr_allreduce_hook)
+got = grads(hooked)
+assert state.buckets_reduced >= 1
+default = grads(DDP(net()))                         # torch's own all-reduce hook: the mean over ranks
+for a, b in zip(got, default):
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-8), float((a - b).abs().max())
+# and the mean of the per-rank gradients, gathered by hand
+for g_loc, g_got in zip(local, got):
+    parts = [torch.zeros_like(g_loc) for _ in range(world)]
+    dist.all_gather(parts, g_loc)
+    assert torch.allclose(sum(parts) / world, g_got, rtol=1e-6, atol=1e-8)
+    assert not torch.equal(parts[0], parts[1])      # the shards really differ
+# a second backward through the same hook (buckets rebuilt after the first iteration)
+got2 = grads(hooked)
+for a, b in zip(got, got2):
+    assert torch.allclose(a, b, rtol=1e-6, atol=1e-8)
+assert state.buckets_reduced >= 2, state.buckets_reduced
+# a state whose world size disagrees with the process group is refused
+try:
+    KsrCommState(0, 1, comm=GlooComm(1)); raise SystemExit("world-size mismatch accepted")
+except KsrError:
+    pass
+dist.destroy_process_group()
+print("OK", rank)
+'''
+
+
+def test_two_rank_ddp_comm_hook_over_gloo(tmp_path):
+    """kan_sr.ddp.ksr_allreduce_hook under real torch DistributedDataParallel with TWO ranks (CPU, gloo, a CPU stand-in for
+    the RCCL communicator): the divide-by-world branch and the completed-future contract give the gradients of DDP's own
+    all-reduce (= the mean of the per-rank gradients), over two iterations (DDP rebuilds its buckets after the first)."""
+    script = tmp_path / "ddp_worker.py"
+    script.write_text(DDP_WORKER)
+    env = dict(os.environ, KSR_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2",
+               OMP_NUM_THREADS="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"OK {r}" in o, o[-2000:]
+
+
 def test_cosine_warm_restarts_schedule_matches_torch():
     """The host-side lr schedule against torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(T_0=500, eta_min=1e-5)
     (src/ml/pipelines/default.py:66-68)."""
