@@ -9,7 +9,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _both(B, C, Hh, Wh, seed):
+def _both(B, C, Hh, Wh, seed, check_device_free=False):
     from kan_sr._lib import check, lib, ptr, stream
     L = lib()
     g = torch.Generator().manual_seed(seed)
@@ -29,6 +29,15 @@ def _both(B, C, Hh, Wh, seed):
                                  c_int(B), c_int64(plane), c_float(1.0), ptr(lb), stream()), "ksr_l1_y_loss_static")
     assert torch.cuda.memory_allocated() == before
     torch.cuda.synchronize()
+    if check_device_free:
+        # torch's counter only sees torch's own allocator: the free bytes the driver reports (hipMemGetInfo) also see a
+        # hipMalloc made inside the library.  Checked on a warmed-up call (the first call on a device looks the array's
+        # address up; nothing is allocated then either, but the runtime may load the code object lazily).
+        free0 = torch.cuda.mem_get_info()[0]
+        check(L.ksr_l1_y_loss_static(ptr(pred), c_int64(3 * plane), ptr(tgt), c_int64(C * plane), ptr(gb), c_int64(plane),
+                                     c_int(B), c_int64(plane), c_float(1.0), ptr(lb), stream()), "ksr_l1_y_loss_static")
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] >= free0, "the allocation-free entry point took device memory"
     ref = (pred[:, 0] - tgt[:, 0]).abs().mean()
     assert abs(float(la) - float(ref)) <= 1e-6
     assert torch.equal(la, lb), (float(la), float(lb))
@@ -39,7 +48,7 @@ def _both(B, C, Hh, Wh, seed):
 def test_static_l1_equals_workspace_l1_twice_second_smaller():
     _both(6, 3, 256, 384, seed=1)       # 256 workgroups: every partial sum of the array is written
     _both(1, 1, 8, 12, seed=2)          # one workgroup: the other 255 entries keep the first call's sums
-    _both(3, 3, 64, 100, seed=3)
+    _both(3, 3, 64, 100, seed=3, check_device_free=True)
 
 
 def test_static_l1_rejects_sizes_beyond_its_maximum():
