@@ -1,6 +1,8 @@
 // Error channel and version for libksr.
 #include "ksr_common.h"
 #include <stdarg.h>
+#include <map>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -37,4 +39,22 @@ const unsigned long long* ksr_seed_dev() { return g_seed_dev; }
 extern "C" int ksr_set_dropout_seed_source(const uint64_t* device_word) {
     g_seed_dev = reinterpret_cast<const unsigned long long*>(device_word);
     return KSR_OK;
+}
+
+long ksr_wg_slots(const void* kernel, int block) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, long> cache;      // one process drives identical GPUs
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(kernel, block);
+    const auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, dev = 0, cus = 0;
+    long slots = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, block, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+        slots = (long)per_cu * cus;
+    else
+        (void)hipGetLastError();       // an unknown occupancy is not an error: the caller falls back to its cap
+    cache[key] = slots;
+    return slots;
 }

@@ -589,11 +589,17 @@ __global__ void __launch_bounds__(1024) colsum_reduce_kernel(ColRedArgs a) {
     a.out[l][(e >> 6) * a.stride[l] + (e & 63)] = s;
 }
 
-unsigned dgrad_grid(const BwdArgs& a, bool spatial) {
+// Stencil (spatial) kernels: at most 512 workgroups (their halo tiles allow two per CU; the stem's column-sum reduction
+// relies on this count).  Plain kernels: one round of persistent workgroups, at most 768 (the fused weight gradient's slab).
+unsigned dgrad_grid_spatial(const BwdArgs& a) {
+    const long ntiles = (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32);
+    return (unsigned)(ntiles < 512 ? ntiles : 512);
+}
+template <class K>
+unsigned dgrad_grid(K kernel, const BwdArgs& a, bool spatial) {
+    if (spatial) return dgrad_grid_spatial(a);
     const long N = (long)a.B * a.H * a.W;
-    const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
-    const long cap = spatial ? 512 : 768;
-    return (unsigned)(ntiles < cap ? ntiles : cap);
+    return ksr_persistent_grid(kernel, (N + 127) / 128, 768);
 }
 
 template <int PREC, int KIN, int BPRO, int BEPI, bool AFF = false>
@@ -601,8 +607,9 @@ int launch_dgrad_p(const BwdArgs& a, hipStream_t s) {
     const long N = (long)a.B * a.H * a.W;
     const bool spatial = BPRO != BPRO_PLAIN;
     const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
-    const long cap = spatial ? 512 : 768;
-    hipLaunchKernelGGL((dgrad_kernel<PREC, KIN, BPRO, BEPI, false, AFF>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(256), 0, s, a);
+    (void)ntiles;
+    hipLaunchKernelGGL((dgrad_kernel<PREC, KIN, BPRO, BEPI, false, AFF>),
+                       dim3(dgrad_grid(dgrad_kernel<PREC, KIN, BPRO, BEPI, false, AFF>, a, spatial)), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("dgrad");
     return KSR_OK;
 }
@@ -612,7 +619,7 @@ template <int BPRO, int BEPI, bool AFF = false>
 int launch_dgrad_wgf(const BwdArgs& a, float* dW, float* db, hipStream_t s) {
     KSR_CHECK_ARG(a.wg_slab && dW && db, "fused weight gradient: null pointer");
     KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "fused weight gradient: bf16 storage mode only (the other modes use ksr_wgrad)");
-    const unsigned grid = dgrad_grid(a, BPRO != BPRO_PLAIN);
+    const unsigned grid = dgrad_grid(dgrad_kernel<KSR_BF16S, 64, BPRO, BEPI, true, AFF>, a, BPRO != BPRO_PLAIN);
     hipLaunchKernelGGL((dgrad_kernel<KSR_BF16S, 64, BPRO, BEPI, true, AFF>), dim3(grid), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("dgrad(fused weight gradient)");
     return ksr_slab_reduce(a.wg_slab, (int)grid, 64, 64, dW, db, s);
@@ -622,7 +629,7 @@ int launch_dgrad_wgf(const BwdArgs& a, float* dW, float* db, hipStream_t s) {
 int launch_dgrad_wgs(const BwdArgs& a, float* dW, float* db, hipStream_t s) {
     KSR_CHECK_ARG(a.wg_slab && dW && db, "fused weight gradient: null pointer");
     KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "fused weight gradient: bf16 storage mode only (the other modes use ksr_wgrad)");
-    const unsigned grid = dgrad_grid(a, true);
+    const unsigned grid = dgrad_grid(dgrad_kernel<KSR_BF16S, 64, BPRO_CONVT, BEPI_SIGGRAD, false, false, true>, a, true);
     hipLaunchKernelGGL((dgrad_kernel<KSR_BF16S, 64, BPRO_CONVT, BEPI_SIGGRAD, false, false, true>), dim3(grid), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("dgrad(weight gradient split over the waves)");
     return ksr_slab_reduce(a.wg_slab, (int)grid, 64, 64, dW, db, s);
@@ -683,7 +690,7 @@ extern "C" int ksr_fn1_bwd(float* dt, const float* dgate, const float* gate_w, c
         }
         if (int rc = launch_dgrad<128, BPRO_CONVT_G, BEPI_STEM>(a, stream)) return rc;
         if (sums_slab) {
-            ColRedArgs r{sums_slab, (int)dgrad_grid(a, true), {dt_sums, dt_sums + 64, dx_sums}, {128, 128, dx_row_stride}};
+            ColRedArgs r{sums_slab, (int)dgrad_grid_spatial(a), {dt_sums, dt_sums + 64, dx_sums}, {128, 128, dx_row_stride}};
             hipLaunchKernelGGL(colsum_reduce_kernel, dim3(3, 4), dim3(1024), 0, stream, r);
             KSR_LAUNCH_CHECK("fn1_bwd(column sums)");
         }

@@ -51,6 +51,20 @@ void ksr_set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+// Workgroups of `kernel` (with `block` threads) that the current device holds at once: workgroups per CU by registers and
+// LDS (hipOccupancyMaxActiveBlocksPerMultiprocessor) x CUs, looked up once per kernel (ksr_api.hip).  A persistent
+// (grid-stride) kernel launched with more workgroups than that runs in rounds, and a last round that is not full leaves
+// part of the chip idle for its whole length (768 workgroups at two per CU on 256 CUs: 512 + 256).
+long ksr_wg_slots(const void* kernel, int block);
+// Grid of a persistent kernel over ntiles tiles: every tile its own workgroup while they all fit at once, else exactly one
+// full round (never more than cap, the size a caller's per-workgroup workspace allows).
+template <class K>
+inline unsigned ksr_persistent_grid(K kernel, long ntiles, long cap, int block = 256) {
+    long slots = ksr_wg_slots(reinterpret_cast<const void*>(kernel), block);
+    if (slots <= 0 || slots > cap) slots = cap;
+    return (unsigned)(ntiles < slots ? ntiles : slots);
+}
+
 struct KsrKnots {
     float t[KSR_MAX_KNOTS];
     int M;  // number of knots = G + 2k + 1
@@ -190,6 +204,21 @@ __device__ __forceinline__ void ksr_dma16(const void* gsrc, void* lds_wave_base)
     else
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep_m0) : "s"(base), "v"(gsrc) : "memory");
+}
+
+// The 4-byte form: lane l moves one dword from its own global address to lds_wave_base + 4 l.
+__device__ __forceinline__ void ksr_dma4(const void* gsrc, void* lds_wave_base) {
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base);
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0) : "s"(base), "v"(gsrc) : "memory");
+}
+// This wave's transfers have landed, except that its YOUNGER most recent vector-memory instructions (stores issued after
+// the transfers) may still be in flight; no workgroup barrier (wave-private staging).  See ksr_dma_barrier_but.
+template <int YOUNGER>
+__device__ __forceinline__ void ksr_dma_wait_but() {
+    static_assert(YOUNGER >= 0 && YOUNGER < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(YOUNGER) : "memory");
 }
 
 // every wave's LDS writes are complete and visible, every wave has arrived

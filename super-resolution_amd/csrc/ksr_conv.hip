@@ -410,8 +410,9 @@ int launch_conv_p(const ConvArgs& a, hipStream_t s) {
     const bool spatial = (PRO == PRO_DWRELU || PRO == PRO_GATE);
     const long N = (long)a.B * a.H * a.W;
     const long ntiles = spatial ? (long)a.B * ((a.H + 3) / 4) * ((a.W + 31) / 32) : (N + 127) / 128;
-    const long cap = spatial ? 512 : 1024;
-    const unsigned grid = (unsigned)(ntiles < cap ? ntiles : cap);
+    // stencil kernels: two workgroups per CU (halo tiles); plain 1x1 kernels: one round of persistent workgroups
+    const unsigned grid = spatial ? (unsigned)(ntiles < 512 ? ntiles : 512)
+                                  : ksr_persistent_grid(conv_fwd_kernel<PREC, PRO, NOUT, ACT>, ntiles, 1024);
     hipLaunchKernelGGL((conv_fwd_kernel<PREC, PRO, NOUT, ACT>), dim3(grid), dim3(256), 0, s, a);
     KSR_LAUNCH_CHECK("conv_fwd");
     return KSR_OK;

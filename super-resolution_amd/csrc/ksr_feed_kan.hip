@@ -71,10 +71,14 @@ struct FeedCfg {
 
 template <int NB, bool COAL>
 struct __attribute__((aligned(16))) FeedSmem {
-    float frag[NB * 32 * 64];
+    float frag[NB * 32 * 64 / (COAL ? 2 : 1)];        // bf16 storage implies bf16 fragments: half the bytes
     float biasfrag[NB * 32];
     float knots[KSR_MAX_KNOTS];
-    float xpose[COAL ? 4 * KSR_XPOSE_FLOATS : 4];     // per-wave transposers of the coalesced feature loads
+    float xpose[COAL ? 4 * 32 * KSR_XPOSE16_LD : 4];  // per-wave transposers of the coalesced (uw, S) stores
+    // bf16 storage: per wave two staging buffers for the LDS-DMA of its 32 feature rows (128 bytes each, 16-byte chunk c of
+    // row r at chunk position c ^ ((r >> 1) & 7): conflict-free row reads) and of the 32 pixels' luma values
+    __bf16 stage[COAL ? 4 * 2 * 32 * 64 : 8];
+    float xstage[COAL ? 4 * 2 * 64 : 4];
 };
 
 template <int PREC, int R, int KC, int KORD>
@@ -98,37 +102,66 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
     const FeedRange rg = feed_range(a);
     const long N = rg.count;                         // pixels of this workgroup's range, which starts at rg.first
     const long ntiles = (N + 127) / 128;
-    float* xb = sm.xpose + (COAL ? wv * KSR_XPOSE_FLOATS : 0);
-    KsrTile<ST> ahead;
-    auto fetch_tile = [&](long t) {
+    float* xb = sm.xpose + (COAL ? wv * 32 * KSR_XPOSE16_LD : 0);
+    // bf16 storage: a tile's feature rows and luma values travel global -> LDS by LDS-DMA, requested one tile ahead.  The
+    // transfers are issued from inline assembly and waited for explicitly, so the only vector-memory instructions the
+    // compiler keeps count of are the tile's stores, for which nothing ever waits: a tile's stores drain while the next
+    // tile is computed.  (With the tile fetched into registers the compiler's wait at the top of the loop was vmcnt(0):
+    // loads and stores of a wave complete in issue order under ONE counter, so every tile waited for the previous tile's
+    // stores - a full memory round trip per tile, 2.6 TB/s.)
+    auto issue_tile = [&](long t, int buf) {
         const long r0 = t * 128 + wv * 32;
         const int nv = (N - r0) < 32 ? (int)(N - r0 > 0 ? N - r0 : 0) : 32;
-        ksr_co_fetch<ST, true>(a.feat, rg.first + r0, nv, a.feat_ld, a.feat_c0, lane, ahead);
+        const long nb = rg.first + (nv > 0 ? r0 : 0);
+        const int last = nv > 0 ? nv - 1 : 0;              // rows past the end re-read the last real row: never stored
+        const int r8 = lane >> 3, cp = lane & 7;
+        __bf16* st = sm.stage + (wv * 2 + buf) * 32 * 64;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = 8 * j + r8, c = cp ^ ((r >> 1) & 7);
+            const int rc = r < last ? r : last;
+            ksr_dma16<true>(reinterpret_cast<const __bf16*>(a.feat) + (nb + rc) * a.feat_ld + a.feat_c0 + 8 * c, st + j * 512);
+        }
+        const long nt = nb + (tok < last ? tok : last);
+        ksr_dma4(a.x_img + (nt / HW) * a.img_bstride + (nt % HW), sm.xstage + (wv * 2 + buf) * 64);
     };
-    if (COAL && (long)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    // One tile.  FULL (every tile but a ragged last one): all 128 pixels exist, nothing in the body is predicated and the
+    // wave issues a fixed number of stores per tile (NST: 2 of the output, 4 of the (uw, S) pairs when they are kept).
+    auto body = [&](long tile, int it, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
         const long nl = tile * 128 + wv * 32 + tok;
-        const bool live = nl < N;
+        const bool live = FULL || nl < N;
         const long n = rg.first + nl;
         const long nn = live ? n : rg.first;
         const int b = (int)(nn / HW), hw = (int)(nn % HW);
         const int y = hw / a.W, x = hw % a.W;
 
         float f[32];
+        float xv;
         if constexpr (COAL) {
-            ksr_co_finish<ST>(xb, lane, ahead, f);
-            if (tile + gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
+            // the transfers of this tile were issued before the previous tile's stores (none before the first tile)
+            if (it == 0) ksr_dma_wait_but<0>();
+            else if (a.save_us) ksr_dma_wait_but<(2 * C::OH == 16) ? R / 2 + 4 : 0>();
+            else ksr_dma_wait_but<R / 2>();
+            const __bf16* st = sm.stage + (wv * 2 + (it & 1)) * 32 * 64;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                ksr_unpack8(*reinterpret_cast<const uint4*>(st + tok * 64 + 8 * ((4 * h + q) ^ ((tok >> 1) & 7))), f + 8 * q);
+            xv = sm.xstage[(wv * 2 + (it & 1)) * 64 + tok];
+            if (!live) xv = 0.f;
+            ksr_wave_fence();
+            if (tile + gridDim.x < ntiles) issue_tile(tile + gridDim.x, (it + 1) & 1);
         } else {
             if (live) ksr_loadn<ST, 32>(a.feat, n * a.feat_ld + a.feat_c0 + 32 * h, f);
             else {
 #pragma unroll
                 for (int i = 0; i < 32; ++i) f[i] = 0.f;
             }
+            xv = live ? a.x_img[(long)b * a.img_bstride + hw] : 0.f;
         }
         f32x16 acc[NB];
         ksr_wave_gemm<PREC, 32, NB>(sm.frag, sm.biasfrag, f, acc, lane);
 
-        const float xv = live ? a.x_img[(long)b * a.img_bstride + hw] : 0.f;
         float Nv[KSR_MAX_ORDER + 1], bv[KC];
         const int m = basis_any<KORD>(xv, sm.knots, kn.M, Nv);
         dense_basis<KC>(m, Nv, KORD, bv);
@@ -148,7 +181,15 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
             yv[ol] = rw * sl + uw * S;
             us[2 * ol] = uw; us[2 * ol + 1] = S;
         }
-        if (a.save_us && live) {
+        if constexpr (COAL && 2 * C::OH == 16) {
+            // (uw, S) pairs: a pixel's 2 * O = 32 floats are one 128-byte row and the wave's 32 pixels 4 KB of consecutive
+            // memory; through the wave's transposer they leave as lane-linear 16-byte pieces
+            if (a.save_us) {
+                const long r0 = tile * 128 + wv * 32;
+                const int nv = (N - r0) < 32 ? (int)(N - r0 > 0 ? N - r0 : 0) : 32;
+                ksr_store16_co<float, false, true, FULL>(xb, a.save_us, rg.first + r0, nv, lane, us);
+            }
+        } else if (a.save_us && live) {
             // (uw, S) of this lane's OH outputs: 2 * OH consecutive floats
             float* sp = a.save_us + (n * C::O + h * C::OH) * 2;
             if constexpr ((2 * C::OH) % 4 == 0) {
@@ -172,11 +213,19 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
                     *reinterpret_cast<float2*>(op + (long)rr * a.W * R) = make_float2(yv[rr * R + 0], yv[rr * R + 1]);
             }
         }
-    }
+    };
+    if (COAL && (long)blockIdx.x < ntiles) issue_tile(blockIdx.x, 0);
+    const long nfull = N / 128;                      // tiles [0, nfull) are complete; at most one ragged tile follows
+    long tile = blockIdx.x;
+    int it = 0;
+    for (; tile < nfull; tile += gridDim.x, ++it) body(tile, it, std::true_type{});
+    if (tile < ntiles) body(tile, it, std::false_type{});
+    if constexpr (COAL) ksr_dma_wait_but<0>();       // no transfer outlives the wave (none is pending: the last tile requests nothing)
 }
 
 // Grid of the feed kernels: tiles over all pixels, or (tiles of one image, image) with per-image weights
 dim3 feed_grid(const FeedArgs& a, long cap) {
+    if (cap <= 0) cap = 512;
     if (a.w_bstride == 0) {
         const long ntiles = ((long)a.B * a.H * a.W + 127) / 128;
         return dim3((unsigned)(ntiles < cap ? ntiles : cap));
@@ -189,8 +238,13 @@ dim3 feed_grid(const FeedArgs& a, long cap) {
 
 template <int R, int KC, int KORD>
 int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
-    const dim3 grid = feed_grid(a, 768);
-#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_fwd_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn)
+    // one round of persistent workgroups (bf16 storage: 73 KB of LDS, two workgroups per CU: 768 ran as 512 + 256, half the
+    // chip idle for the second half of the kernel)
+#define KSR_CALL(P)                                                                                                      \
+    do {                                                                                                                 \
+        const dim3 grid = feed_grid(a, ksr_wg_slots(reinterpret_cast<const void*>(feed_kan_fwd_kernel<P, R, KC, KORD>), 256)); \
+        hipLaunchKernelGGL((feed_kan_fwd_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn);                         \
+    } while (0)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("feed_kan_fwd");
@@ -329,7 +383,14 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
             }
         }
         float us[C::OH * 2];
-        {
+        const long n0w = rg.first + tile * 128 + wv * 32;            // the wave's 32 consecutive pixels
+        __bf16* tl = sm.tile + (COAL ? wv * TILE : 0);
+        if constexpr (COAL && 2 * C::OH == 16) {
+            // the wave's 4 KB of (uw, S) pairs in lane-linear 16-byte pieces, transposed through the (still unused) tile
+            static_assert(TILE * 2 >= 32 * KSR_XPOSE16_LD * 4, "the tile holds 32 rows of 36 floats");
+            const int nv = (N - n0w) < 32 ? (int)(N - n0w > 0 ? N - n0w : 0) : 32;
+            ksr_load16_co<float>(reinterpret_cast<float*>(tl), a.save_us, n0w, nv, lane, us);
+        } else {
             const float4* up = reinterpret_cast<const float4*>(a.save_us + (n * C::O + h * C::OH) * 2);
 #pragma unroll
             for (int q = 0; q < C::OH / 2; ++q) {
@@ -354,8 +415,6 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
                 dp[e] = 0.f;
             }
         }
-        const long n0w = rg.first + tile * 128 + wv * 32;            // the wave's 32 consecutive pixels
-        __bf16* tl = sm.tile + (COAL ? wv * TILE : 0);
         if constexpr (COAL) {
             // rows of gparam are [half 0: KH | half 1: KH] per pixel: one lane half at a time through the tile
             static_assert(KH % 8 == 0, "16-byte pieces");
@@ -406,8 +465,11 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
 
 template <int R, int KC, int KORD>
 int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
-    const dim3 grid = feed_grid(a, 512);
-#define KSR_CALL(P) hipLaunchKernelGGL((feed_kan_bwd_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn)
+#define KSR_CALL(P)                                                                                                      \
+    do {                                                                                                                 \
+        const dim3 grid = feed_grid(a, ksr_wg_slots(reinterpret_cast<const void*>(feed_kan_bwd_kernel<P, R, KC, KORD>), 256)); \
+        hipLaunchKernelGGL((feed_kan_bwd_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn);                         \
+    } while (0)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("feed_kan_bwd");

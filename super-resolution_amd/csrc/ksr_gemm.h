@@ -297,6 +297,31 @@ __device__ __forceinline__ void ksr_co_fetch(const void* __restrict__ base, long
         }
     }
 }
+// The same request with neither branches nor selects on the loaded values: rows past nvalid re-read the tile's last real
+// row (row 0 of the tensor when the tile is empty), so the result registers are not touched between the request and their
+// first use and the loads can stay in flight across a loop iteration.  For callers that never store or sum rows past
+// nvalid (token-per-lane kernels, whose columns do not mix).
+template <class T>
+__device__ __forceinline__ void ksr_co_fetch_clamped(const void* __restrict__ base, long n0, int nvalid, int ld, int c0, int lane,
+                                                     KsrTile<T>& t) {
+    const long nb = nvalid > 0 ? n0 : 0;
+    const int last = nvalid > 0 ? nvalid - 1 : 0;
+    if constexpr (sizeof(T) == 4) {
+        const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + r4;
+            t.v[i] = ksr_ld_stream(reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + (nb + (row < last ? row : last)) * ld + c0 + c4));
+        }
+    } else {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + r8;
+            t.v[i] = ksr_ld_stream(reinterpret_cast<const uint4*>(reinterpret_cast<const __bf16*>(base) + (nb + (row < last ? row : last)) * ld + c0 + c8));
+        }
+    }
+}
 // fetched tile -> fp32 LDS tile [32][KSR_XPOSE_LD] (caller fences)
 template <class T>
 __device__ __forceinline__ void ksr_co_to_lds(float* __restrict__ xb, int lane, const KsrTile<T>& t) {
@@ -384,7 +409,7 @@ __device__ __forceinline__ void ksr_store32_co(float* __restrict__ xb, void* __r
 // 32-channel rows (lane half h holds channels 16h .. 16h+15): same scheme with rows padded to 36 floats.
 constexpr int KSR_XPOSE16_LD = 36;
 // fp32 LDS tile [32][36] <-> rows of a tensor with ld elements per row, channels c0 .. c0+31
-template <class T, bool TWO_PATH = true, bool NT = false>
+template <class T, bool TWO_PATH = true, bool NT = false, bool FULLTILE = false>     // FULLTILE: the caller knows nvalid == 32: no predicate, no branch
 __device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                   int ld, int c0, int lane) {
     // full tiles (all but the last one of a tensor) take a path without per-row predicates; nvalid is wave-uniform.
@@ -411,7 +436,8 @@ __device__ __forceinline__ void ksr_co16_from_lds(const float* __restrict__ xb, 
         }
     }
     };
-    if (TWO_PATH && __builtin_amdgcn_readfirstlane(nvalid) == 32) body(std::false_type{});
+    if constexpr (FULLTILE) body(std::false_type{});
+    else if (TWO_PATH && __builtin_amdgcn_readfirstlane(nvalid) == 32) body(std::false_type{});
     else body(std::true_type{});
 }
 // registers of one fetched 32 x 32 tile
@@ -475,7 +501,7 @@ __device__ __forceinline__ void ksr_load16_co(float* __restrict__ xb, const void
     ksr_co16_fetch<T>(base, n0, nvalid, lane, t);
     ksr_co16_finish<T>(xb, lane, t, x);
 }
-template <class T, bool TWO_PATH = true, bool NT = false>
+template <class T, bool TWO_PATH = true, bool NT = false, bool FULLTILE = false>
 __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid,
                                                int lane, const float (&x)[16]) {
     float* wp = xb + (lane & 31) * KSR_XPOSE16_LD + 16 * (lane >> 5);
@@ -483,7 +509,7 @@ __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __r
 #pragma unroll
     for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
     ksr_wave_fence();
-    ksr_co16_from_lds<T, TWO_PATH, NT>(xb, base, n0, nvalid, 32, 0, lane);
+    ksr_co16_from_lds<T, TWO_PATH, NT, FULLTILE>(xb, base, n0, nvalid, 32, 0, lane);
 }
 
 // Sum of v over the two lanes that share a token (lanes l and l^32).

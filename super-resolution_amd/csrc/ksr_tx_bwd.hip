@@ -451,12 +451,17 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     KSR_CHECK_ARG(!(p_drop > 0.f) || a.da || !a.dctx, "batch_tx_layer_bwd_token: dropout needs the da output");
     a.N = (long)N; a.p_drop = p_drop; a.seed = seed; a.seed_dev = ksr_seed_dev();
     const long ntiles = (N + 127) / 128;
-#define KSR_CALL(P) hipLaunchKernelGGL(tx_bwd_token_kernel<P>, dim3((unsigned)(ntiles < 768 ? ntiles : 768)), dim3(256), 0, stream, a)
+    unsigned grid = 0;
+#define KSR_CALL(P)                                                                  \
+    do {                                                                             \
+        grid = ksr_persistent_grid(tx_bwd_token_kernel<P>, ntiles, 768);             \
+        hipLaunchKernelGGL(tx_bwd_token_kernel<P>, dim3(grid), dim3(256), 0, stream, a); \
+    } while (0)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token");
     if (ln_slab) {
-        LnRedArgs r{ln_slab, (int)(ntiles < 768 ? ntiles : 768), {a.nf_w ? ln_grads[0] : nullptr, ln_grads[1], ln_grads[2]}, ln_row_stride};
+        LnRedArgs r{ln_slab, (int)grid, {a.nf_w ? ln_grads[0] : nullptr, ln_grads[1], ln_grads[2]}, ln_row_stride};
         hipLaunchKernelGGL(ln_reduce_kernel, dim3(3, 4), dim3(1024), 0, stream, r);
         KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token(ln reduce)");
     }
@@ -488,7 +493,7 @@ extern "C" int ksr_batch_tx_layer_bwd_out_wg(const float* du1, const float* ctx,
     KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "batch_tx_layer_bwd_out_wg: bf16 storage mode only");
     TxBwdOutArgs a{du1, ctx, out_w, dctx, wg_slab, (long)N, p_drop, seed, ksr_seed_dev()};
     const long ntiles = (N + 127) / 128;
-    const unsigned grid = (unsigned)(ntiles < KSR_WGF_MAX_GRID ? ntiles : KSR_WGF_MAX_GRID);
+    const unsigned grid = ksr_persistent_grid(tx_bwd_out_wg_kernel, ntiles, KSR_WGF_MAX_GRID);
     hipLaunchKernelGGL(tx_bwd_out_wg_kernel, dim3(grid), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_out_wg");
     return ksr_slab_reduce(wg_slab, (int)grid, 64, 64, dW, db, stream);

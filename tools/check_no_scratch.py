@@ -3,7 +3,7 @@
 vector-memory instructions the wave has issued since the transfers it needs) uses scratch memory.  A spill adds
 vector-memory instructions the count does not know about; the wait would then be too weak and a stage would be read
 before its transfer has landed - silently wrong results, not a fault.
-Usage: check_no_scratch.py <remarks file written by hipcc -Rpass-analysis=kernel-resource-usage> <kernel name part>..."""
+Usage: check_no_scratch.py <remarks file written by hipcc -Rpass-analysis=kernel-resource-usage> <regex over mangled kernel names>..."""
 import re
 import sys
 
@@ -15,7 +15,7 @@ def main():
     seen, bad = set(), []
     for b in blocks:
         fn = b.split()[0]
-        hit = [n for n in names if n in fn]
+        hit = [n for n in names if re.search(n, fn)]
         if not hit:
             continue
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b)

@@ -6,11 +6,4 @@ rc=$?
 tail -5 gpurun_out/gputest.log
 [ $rc -ne 0 ] && exit $rc
 timeout -k 10 300 python bench.py --no-cpu-baseline --headline-only > gpurun_out/bench_quick.log 2>&1 || { tail -5 gpurun_out/bench_quick.log; exit 1; }
-python - <<'PY'
-import json
-l=[x for x in open('gpurun_out/bench_quick.log') if x.startswith('{')][-1]
-d=json.loads(l)
-print('ms_per_step', d['ms_per_step'], 'value', d['value'])
-ep=d['roofline']['ms_per_step_by_entry_point']
-print(' '.join(f"{k[4:]}={v:.3f}" for k,v in sorted(ep.items(), key=lambda kv:-kv[1])))
-PY
+python tools/show_bench.py gpurun_out/bench_quick.log
