@@ -316,6 +316,20 @@ int64_t ksr_tx_bwd_wg_slab_floats(void);
 int ksr_batch_tx_layer_bwd_out_wg(const float* du1, const float* ctx, const float* out_w, float* dctx, int64_t N,
                                   float p_drop, uint64_t seed, float* wg_slab, float* dW, float* db, ksr_stream_t stream);
 
+/* Deferred slab reductions (no counterpart in the reference, whose parameter gradients come from autograd:
+ * src/ml/pipelines/default.py:75-84).  Every entry point that accumulates a parameter gradient writes per-workgroup
+ * partial rows into its slab and ends with a small fixed-order reduction launch.  After ksr_reduce_defer(1) the CALLING
+ * THREAD's entry points only record that reduction (up to 30; a full list is flushed on the stream of the call that
+ * overflows it) and ksr_reduce_flush(stream) runs every recorded one in a single launch: same sums, same order, same
+ * bits as the immediate form.  While the mode is on the caller gives every such call its OWN slab, keeps slabs and
+ * outputs alive and untouched until the flush, and orders the flush after every producer (same stream, or an event).
+ * Reductions over at most 32 partial rows and the batched (per-image) ones are never deferred.
+ * ksr_reduce_defer(0) ends the mode (error if reductions are still recorded), ksr_reduce_defer(-1) ends it and drops what
+ * was recorded (a caller's error path); ksr_reduce_pending() = recorded count. */
+int ksr_reduce_defer(int on);
+int ksr_reduce_flush(ksr_stream_t stream);
+int ksr_reduce_pending(void);
+
 /* Weight gradient of a linear map fed by a LayerNorm output s = xhat * gain + shift (linear1 after norm1,
  * gazetr.py:56-58) when the product was taken with xhat instead of s, which then need not be kept for the backward:
  * dW[j][k] <- dW[j][k] * gain[k] + db[j] * shift[k], in place. */

@@ -419,15 +419,14 @@ constexpr int RED_GROUPS = 32;     // slab groups per workgroup (1024 threads)
 constexpr int RED_GROUPS_FEW = 8;  // ... when there are few partial rows (batched Gram products: a handful per image)
 
 template <int GROUPS>
-__global__ void __launch_bounds__(32 * GROUPS) reduce_kernel(RedArgs a) {
+__device__ __forceinline__ void reduce_body(const RedArgs& a, int bx, int by, float (*part)[33]) {
     // 32 outputs x GROUPS slab groups per workgroup (lanes = consecutive outputs: 128-byte rows of the slabs); every
     // thread keeps 4 independent partial sums; all partials are combined in a fixed order
-    __shared__ float part[GROUPS][33];
     const int o = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + o;
+    const int idx = bx * 32 + o;
     const int total = a.J * a.K + (a.bias ? a.tail_len : 0);
     const bool is_bias = idx >= a.J * a.K;
-    const float* slab = a.slab + (long)blockIdx.y * a.G * a.stride + (is_bias ? a.tail_off + idx - a.J * a.K : idx);
+    const float* slab = a.slab + (long)by * a.G * a.stride + (is_bias ? a.tail_off + idx - a.J * a.K : idx);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (idx < total) {
         int g = grp;
@@ -453,8 +452,29 @@ __global__ void __launch_bounds__(32 * GROUPS) reduce_kernel(RedArgs a) {
         j = MapKan{a.kan_O, a.kan_Kc}(h, e);
         if (j < 0) return;
     }
-    if (is_bias) a.bias[(long)blockIdx.y * a.tail_len + j] = s;
-    else a.out[(long)blockIdx.y * a.out_bstride + (long)j * a.sj + (long)k * a.sk] = s;
+    if (is_bias) a.bias[(long)by * a.tail_len + j] = s;
+    else a.out[(long)by * a.out_bstride + (long)j * a.sj + (long)k * a.sk] = s;
+}
+
+template <int GROUPS>
+__global__ void __launch_bounds__(32 * GROUPS) reduce_kernel(RedArgs a) {
+    __shared__ float part[GROUPS][33];
+    reduce_body<GROUPS>(a, blockIdx.x, blockIdx.y, part);
+}
+
+// Several reductions in one launch (the deferred form, ksr_reduce_defer / ksr_reduce_flush): workgroup -> (entry, block
+// of 32 outputs) through the prefix table.  Same arithmetic and summation order per output as reduce_kernel<RED_GROUPS>.
+constexpr int RED_BATCH_MAX = 30;
+struct RedBatch {
+    RedArgs e[RED_BATCH_MAX];
+    int first[RED_BATCH_MAX + 1];      // first workgroup of entry i; first[n] = grid size
+    int n;
+};
+__global__ void __launch_bounds__(32 * RED_GROUPS) reduce_batch_kernel(RedBatch b) {
+    __shared__ float part[RED_GROUPS][33];
+    int e = 0;
+    while (e + 1 < b.n && (int)blockIdx.x >= b.first[e + 1]) ++e;
+    reduce_body<RED_GROUPS>(b.e[e], (int)blockIdx.x - b.first[e], 0, part);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -718,12 +738,38 @@ __global__ void __launch_bounds__(256) outer2_kernel(float* out, const float* r,
     if (c_copy && k == 0) c_copy[j] = c[j];
 }
 
+// Deferred reductions of the calling thread (ksr_reduce_defer): collected here instead of launched, until ksr_reduce_flush.
+thread_local bool g_red_defer = false;
+thread_local RedBatch g_red_batch;           // g_red_batch.n entries collected so far
+
+int flush_reduce_batch(hipStream_t s) {
+    RedBatch& b = g_red_batch;
+    if (b.n == 0) return KSR_OK;
+    const int blocks = b.first[b.n];
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)blocks), dim3(32 * RED_GROUPS), 0, s, b);
+    b.n = 0;
+    KSR_LAUNCH_CHECK("reduce(batch)");
+    return KSR_OK;
+}
+
 int launch_reduce(const float* slab, int G, int J, int K, long stride, float* out, int sj, int sk, float* bias,
                   int kan_O, int kan_Kc, int kan_nbh, hipStream_t s, int tail_off = -1, int tail_len = -1, int nb = 1,
                   long out_bstride = 0) {
     if (tail_off < 0) { tail_off = J * K; tail_len = J; }
     RedArgs r{slab, G, J, K, stride, out, sj, sk, bias, kan_O, kan_Kc, kan_nbh, tail_off, tail_len, out_bstride};
     const int total = J * K + (bias ? tail_len : 0);
+    if (g_red_defer && nb == 1 && G > 4 * RED_GROUPS_FEW) {
+        // (the few-row form sums in another grouping and batched entries keep their own launch: results stay bit-equal)
+        RedBatch& b = g_red_batch;
+        if (b.n == RED_BATCH_MAX) {
+            if (int rc = flush_reduce_batch(s)) return rc;
+        }
+        if (b.n == 0) b.first[0] = 0;
+        b.e[b.n] = r;
+        b.first[b.n + 1] = b.first[b.n] + (total + 31) / 32;
+        ++b.n;
+        return KSR_OK;
+    }
     // few partial rows (G <= 32: the per-image Gram products): 8 groups keep every thread of a workgroup at work
     if (G <= 4 * RED_GROUPS_FEW) hipLaunchKernelGGL(reduce_kernel<RED_GROUPS_FEW>, dim3((total + 31) / 32, nb), dim3(32 * RED_GROUPS_FEW), 0, s, r);
     else hipLaunchKernelGGL(reduce_kernel<RED_GROUPS>, dim3((total + 31) / 32, nb), dim3(32 * RED_GROUPS), 0, s, r);
@@ -795,6 +841,25 @@ long gram_grid(int Jp, int K, int nb, long tokens) {
 }  // namespace
 
 extern "C" int ksr_wgrad_slab_floats(int J, int K) { return WG_GRID * (J * K + J); }
+
+// Deferred slab reductions.  Every entry point that accumulates a parameter gradient writes per-workgroup partial rows into
+// a workspace ("slab") and finishes with a small fixed-order reduction launch.  After ksr_reduce_defer(1) the calling thread's
+// entry points only RECORD that reduction (up to 30; a full list is flushed on the stream of the call that overflows it), and
+// ksr_reduce_flush(stream) runs all recorded ones in a single launch: same sums, same order, same bits.  The caller must
+// then give every such call its OWN slab and keep slabs and outputs alive and untouched until the flush, and must order the
+// flush after every producer (same stream, or an event).  ksr_reduce_defer(0) ends the mode (the list must be empty).
+extern "C" int ksr_reduce_defer(int on) {
+    if (on < 0) {                 // abandon: drop what was recorded (error paths of the caller)
+        g_red_batch.n = 0;
+        g_red_defer = false;
+        return KSR_OK;
+    }
+    KSR_CHECK_ARG(on || g_red_batch.n == 0, "reduce_defer(0): %d recorded reductions were never flushed", g_red_batch.n);
+    g_red_defer = on != 0;
+    return KSR_OK;
+}
+extern "C" int ksr_reduce_flush(hipStream_t stream) { return flush_reduce_batch(stream); }
+extern "C" int ksr_reduce_pending(void) { return g_red_batch.n; }
 
 // Fixed-order sum of G partial rows [J*K | J] (written by a kernel that accumulated the products itself) to dW, db.
 int ksr_slab_reduce(const float* slab, int G, int J, int K, float* dW, float* db, hipStream_t stream) {

@@ -32,6 +32,13 @@ PARAM_ORDER = (
 _SIDE_STREAMS: dict = {}
 SIDE_STREAM_FOR_WGRAD = os.environ.get("KSR_SIDE_WGRAD", "1") != "0"
 SIDE_STREAM_MIN_TOKENS = 1 << 19          # LR pixels per backward pass from which the second stream is used
+# One launch for all slab reductions of a gradient bucket (ksr_reduce_defer / ksr_reduce_flush) instead of one per weight
+# gradient.  Pays where the step is bound by its launch count (8 patches of 128 x 128 per GPU: 0.913 -> 0.884 ms); with many
+# pixels the immediate reduction reads its slab while it is still in the caches and the deferred one re-reads all slabs
+# (170 MB) from memory (64 patches: 4.48 -> 4.65 ms), so it is used below DEFER_BELOW_TOKENS pixels per pass.
+# KSR_DEFER_REDUCTIONS=0 / 1 forces it off / on.
+DEFER_REDUCTIONS = os.environ.get("KSR_DEFER_REDUCTIONS", "auto")
+DEFER_BELOW_TOKENS = 1 << 19
 
 
 def _side_stream(dev):
@@ -51,6 +58,14 @@ class _Ws:
 
     def __init__(self, dev, arena=None, n_tokens=0, allow_side_stream=True):
         self.dev = dev
+        # Deferred reductions: every weight-gradient kernel leaves per-workgroup partial rows in a slab of its own and only
+        # RECORDS the fixed-order sum that finishes it; flush() runs all recorded sums in one launch (21 launches of ~5 us
+        # per step otherwise: a tenth of the step at 8 patches per GPU).  Same sums, same order, same bits.
+        self.defer = dev.type == "cuda" and (DEFER_REDUCTIONS == "1" or (DEFER_REDUCTIONS != "0" and 0 < n_tokens < DEFER_BELOW_TOKENS))
+        self._held = []           # slabs of recorded reductions: alive until the flush
+        self._after_flush = []    # launches that continue from a reduced gradient (the affine map of linear1's)
+        if self.defer:
+            check(lib().ksr_reduce_defer(c_int(1)), "ksr_reduce_defer")
         self._slab = None
         self._ln_slab = None
         self._sums_slab = None
@@ -77,6 +92,31 @@ class _Ws:
     def join(self):
         if self.wstream is not None:
             torch.cuda.current_stream().wait_stream(self.wstream)
+
+    def flush(self):
+        """Main stream waits for the second stream, then every recorded reduction runs (one launch) and what was waiting
+        for their results follows."""
+        self.join()
+        if self.defer:
+            check(lib().ksr_reduce_flush(stream()), "ksr_reduce_flush")
+        for fn in self._after_flush:
+            fn()
+        self._after_flush.clear()
+        self._held.clear()
+
+    def after_reduction(self, fn):
+        """Runs fn (launches that read a gradient some reduction writes) now, or after the flush when reductions are deferred."""
+        if self.defer:
+            self._after_flush.append(fn)
+        else:
+            fn()
+
+    def close(self, ok=True):
+        if self.defer:
+            if ok:
+                self.flush()
+            check(lib().ksr_reduce_defer(c_int(0 if ok else -1)), "ksr_reduce_defer")
+            self.defer = False
 
     def new(self, *shape):
         return torch.empty(*shape, device=self.dev, dtype=torch.float32)
@@ -107,11 +147,15 @@ class _Ws:
     def fused_slab(self):
         """Workspace of the weight gradients that data-gradient kernels accumulate themselves.  All of those launches are
         on the caller's stream, in order, and each call's reduction has consumed the rows before the next call's kernel
-        starts; it must stay apart from slab(), which the reductions on the second stream use concurrently."""
-        if self._fused_slab is None:
-            n = max(int(lib().ksr_fused_wgrad_slab_floats()), int(lib().ksr_in_proj_bwd_wg_slab_floats()),
-                    int(lib().ksr_tx_bwd_wg_slab_floats()))
-            self._fused_slab = torch.empty(n, device=self.dev, dtype=torch.float32)
+        starts; it must stay apart from slab(), which the reductions on the second stream use concurrently.
+        With deferred reductions every call gets a workspace of its own, kept until the flush."""
+        if self._fused_slab is None or self.defer:
+            if getattr(_Ws, "_fused_n", None) is None:
+                _Ws._fused_n = max(int(lib().ksr_fused_wgrad_slab_floats()), int(lib().ksr_in_proj_bwd_wg_slab_floats()),
+                                   int(lib().ksr_tx_bwd_wg_slab_floats()))
+            self._fused_slab = torch.empty(_Ws._fused_n, device=self.dev, dtype=torch.float32)
+            if self.defer:
+                self._held.append(self._fused_slab)
         return self._fused_slab
 
     def sums_slab(self):
@@ -125,6 +169,10 @@ class _Ws:
         return self._ln_slab
 
     def slab(self, nfloats):
+        if self.defer:            # one workspace per call, kept until the flush
+            t = torch.empty(max(nfloats, 1), device=self.dev, dtype=torch.float32)
+            self._held.append(t)
+            return t
         if self._slab is None or self._slab.numel() < nfloats:
             self._slab = torch.empty(max(nfloats, 1024 * (192 * 64 + 192)), device=self.dev, dtype=torch.float32)
         return self._slab
@@ -197,9 +245,15 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     else:
         # the forward did not keep LayerNorm 1's output s1 = xhat1 * gain + shift: product with xhat1, then the affine map
         _wgrad(ws, dpre, 32, 0, 32, sv["xhat1"], 64, 0, 64, N, gw, gb)
-        with ws.side(gw, gb):
-            check(L.ksr_wgrad_affine_input(ptr(gw), ptr(gb), ptr(p[q + "norm1.weight"]), ptr(p[q + "norm1.bias"]), c_int(32),
-                                           c_int(64), stream()), "ksr_wgrad_affine_input")
+
+        def fold(gw=gw, gb=gb, n1w=p[q + "norm1.weight"], n1b=p[q + "norm1.bias"]):
+            check(L.ksr_wgrad_affine_input(ptr(gw), ptr(gb), ptr(n1w), ptr(n1b), c_int(32), c_int(64), stream()),
+                  "ksr_wgrad_affine_input")
+        if ws.defer:
+            ws.after_reduction(fold)          # the product's reduction is recorded, not run: the map follows the flush
+        else:
+            with ws.side(gw, gb):
+                fold()
     grads[q + "linear1.weight"], grads[q + "linear1.bias"] = gw, gb
     gw, gb = ws.grad(q + "self_attn.out_proj.weight", 64, 64), ws.grad(q + "self_attn.out_proj.bias", 64)
     if fused:
@@ -358,22 +412,26 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
     N = g.N
     ws = _Ws(x.device, arena, g.N, allow_side_stream)      # one stream while a HIP graph is being recorded
     grads: Dict[str, torch.Tensor] = {}
-    # ---- feed + KAN ----
-    lane_len = int(L.ksr_feed_kan_lane_len(c_int(g.r), c_int(g.n_coef)))
-    gfeat = ws.act(N, 64)
-    gparam = ws.act(N, 2 * lane_len)
-    check(L.ksr_feed_kan_bwd(ptr(gout), c_int64(gout_batch_stride), ptr(x),
-                             c_int64(3 * g.H * g.W), ptr(p[pre + "feed.weight"]), ptr(save_us), ptr(gfeat), ptr(gparam),
-                             *_dims(g), c_int(g.r), c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k),
-                             stream()), "ksr_feed_kan_bwd")
-    P = g.r * g.r * (g.n_coef + 2)
-    gw, gb = ws.grad(pre + "feed.weight", P, 64, 1, 1), ws.grad(pre + "feed.bias", P)
-    _wgrad(ws, gparam, 2 * lane_len, 0, 2 * lane_len, sv["feat"], 64, 0, 64, N, gw, gb, kan=(g.r, g.n_coef))
-    grads[pre + "feed.weight"], grads[pre + "feed.bias"] = gw, gb
-    trunk_backward(ws, gfeat, x, p, pre, g, sv, p_drop, seed, grads, on_tail_done)
-    ws.join()
-    if want_input_grad:
-        grads["__input__"] = _input_gradient(ws, gout, gout_batch_stride, gout_chroma, x, p, pre, g, sv)
+    try:
+        # ---- feed + KAN ----
+        lane_len = int(L.ksr_feed_kan_lane_len(c_int(g.r), c_int(g.n_coef)))
+        gfeat = ws.act(N, 64)
+        gparam = ws.act(N, 2 * lane_len)
+        check(L.ksr_feed_kan_bwd(ptr(gout), c_int64(gout_batch_stride), ptr(x),
+                                 c_int64(3 * g.H * g.W), ptr(p[pre + "feed.weight"]), ptr(save_us), ptr(gfeat), ptr(gparam),
+                                 *_dims(g), c_int(g.r), c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k),
+                                 stream()), "ksr_feed_kan_bwd")
+        P = g.r * g.r * (g.n_coef + 2)
+        gw, gb = ws.grad(pre + "feed.weight", P, 64, 1, 1), ws.grad(pre + "feed.bias", P)
+        _wgrad(ws, gparam, 2 * lane_len, 0, 2 * lane_len, sv["feat"], 64, 0, 64, N, gw, gb, kan=(g.r, g.n_coef))
+        grads[pre + "feed.weight"], grads[pre + "feed.bias"] = gw, gb
+        trunk_backward(ws, gfeat, x, p, pre, g, sv, p_drop, seed, grads, on_tail_done)
+        ws.close()                # joins the second stream and runs the recorded reductions
+        if want_input_grad:
+            grads["__input__"] = _input_gradient(ws, gout, gout_batch_stride, gout_chroma, x, p, pre, g, sv)
+    except BaseException:
+        ws.close(ok=False)
+        raise
     return grads
 
 
@@ -408,7 +466,7 @@ def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, t
     d = _tx_layer_backward(ws, gfeat, 1, p, pre, g, sv["tx1"], p_drop, seed, grads, None)
     dz6 = _tx_layer_backward(ws, d, 0, p, pre, g, sv["tx0"], p_drop, seed, grads, sv["x6"])
     if on_tail_done is not None:
-        ws.join()                 # the first bucket's gradients include side-stream reductions
+        ws.flush()                # the first bucket's gradients include second-stream and recorded reductions
         on_tail_done()
     # ---- ffn4 (gated) ----
     dx4 = _gated_backward(ws, dz6, "ffn4", p, pre, g, sv["t5"], sv["g6"], grads, sv["x4"])
@@ -503,15 +561,19 @@ class _TrunkFn(torch.autograd.Function):
         engine.set_precision(precision)
         grads: Dict[str, torch.Tensor] = {}
         ws = _Ws(ctx.x.device, None, g.N)
-        trunk_backward(ws, gfeat.contiguous(), ctx.x, ctx.p, pre, g, ctx.sv, p_drop, seed, grads)
-        gx = None
-        if ctx.needs_input_grad[0]:
-            # the trunk reads the luma plane only (ffn1's front): w1 * convT(dpre) into plane 0
-            gx = torch.zeros_like(ctx.x)
-            f = pre + "ffn1."
-            check(lib().ksr_stem_dx(ptr(ws.dpre), ptr(ctx.p[f + "pointwise1.weight"]), ptr(ctx.p[f + "depthwise.weight"]), ptr(gx),
-                                    c_int64(3 * g.H * g.W), *_dims(g), stream()), "ksr_stem_dx")
-        ws.join()
+        try:
+            trunk_backward(ws, gfeat.contiguous(), ctx.x, ctx.p, pre, g, ctx.sv, p_drop, seed, grads)
+            gx = None
+            if ctx.needs_input_grad[0]:
+                # the trunk reads the luma plane only (ffn1's front): w1 * convT(dpre) into plane 0
+                gx = torch.zeros_like(ctx.x)
+                f = pre + "ffn1."
+                check(lib().ksr_stem_dx(ptr(ws.dpre), ptr(ctx.p[f + "pointwise1.weight"]), ptr(ctx.p[f + "depthwise.weight"]), ptr(gx),
+                                        c_int64(3 * g.H * g.W), *_dims(g), stream()), "ksr_stem_dx")
+            ws.close()
+        except BaseException:
+            ws.close(ok=False)
+            raise
         ctx.sv = None
         out = []
         for n, t in zip(names, ctx.p.values()):

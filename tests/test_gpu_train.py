@@ -430,6 +430,7 @@ def test_gradient_exchange_schedule_order(precision, side_wgrad, monkeypatch):
 
     monkeypatch.setattr(autograd, "SIDE_STREAM_FOR_WGRAD", side_wgrad)
     monkeypatch.setattr(autograd, "SIDE_STREAM_MIN_TOKENS", 0)
+    monkeypatch.setattr(autograd, "DEFER_REDUCTIONS", "1")
     m, _ = _model(4, seed=2)
     m = m.cuda().eval()
     m.precision = precision
@@ -483,6 +484,13 @@ def test_gradient_exchange_schedule_order(precision, side_wgrad, monkeypatch):
     backward_launches = [i for i, n in enumerate(names) if n.endswith(("_bwd", "_wgrad", "_wg", "outer2", "_bwd_stem_v",
                                                                        "_wgrad_v", "_bwd_v"))]
     assert ar[1] > max(backward_launches)
+    # the slab reductions are recorded and run in one launch per bucket: each exchange follows the flush that completes
+    # its gradients (and the affine map of linear1's gradient, which continues from a reduced gradient)
+    flushes = [i for i, n in enumerate(names) if n == "ksr_reduce_flush"]
+    assert len(flushes) == 2, flushes
+    assert max(i for i in tail_launches if names[i] != "ksr_wgrad_affine_input") < flushes[0] < ar[0]
+    assert all(flushes[0] < i < ar[0] for i, n in enumerate(names) if n == "ksr_wgrad_affine_input")
+    assert max(backward_launches) < flushes[1] < ar[1]
     used_side = {e[1] for e in log if e[0] != "allreduce"} - {main}
     assert bool(used_side) == side_wgrad, "parameter-gradient reductions on the second stream: not as requested"
     adam = names.index("ksr_adam_step")
@@ -534,3 +542,34 @@ def test_lightning_strategy_reports_missing_package():
     except ImportError:
         with pytest.raises(KsrError, match="lightning"):
             lightning_strategy()
+
+
+def test_deferred_slab_reductions_are_bit_equal(monkeypatch):
+    """The slab reductions of a backward pass recorded and run in one launch per bucket (ksr_reduce_defer / ksr_reduce_flush)
+    give the bits of the immediate form: whole step in bf16 storage and in the exact mode, flat gradient buffers compared."""
+    from kan_sr import autograd, engine
+    from kan_sr.train import TrainStep
+    for precision in ("bf16s", "fp32"):
+        flats = []
+        for mode in ("0", "1", "0"):
+            monkeypatch.setattr(autograd, "DEFER_REDUCTIONS", mode)
+            m, _ = _model(4, seed=6)
+            m = m.cuda().eval()
+            m.precision = precision
+            ts = TrainStep(m, lr=0.0, loss="l1+ssim")
+            torch.manual_seed(11)
+            x, tgt = torch.rand(5, 3, 24, 40).cuda(), torch.rand(5, 3, 96, 160).cuda()
+            loss = ts.step(x, tgt)
+            torch.cuda.synchronize()
+            flats.append((float(loss), ts.flat_g.clone()))
+            ts.close()
+            assert int(_lib_pending()) == 0
+        engine.set_precision("fp32")
+        assert flats[0][0] == flats[1][0] == flats[2][0]
+        assert torch.equal(flats[0][1], flats[1][1]) and torch.equal(flats[0][1], flats[2][1]), precision
+        assert float(flats[0][1].abs().max()) > 0
+
+
+def _lib_pending():
+    from kan_sr._lib import lib
+    return lib().ksr_reduce_pending()
