@@ -454,3 +454,99 @@ def unet(x: torch.Tensor, p: Params, prefix: str = "", train: bool = False, stat
         up = F.pad(up, [dx // 2, dx - dx // 2, dy // 2, dy - dy // 2])
         y = double_conv(torch.cat([skip, up], dim=1), p, prefix + f"up{i}.conv.double_conv.", train, stats)
     return F.conv2d(y, p[prefix + "reproj.conv.weight"], p[prefix + "reproj.conv.bias"])
+
+
+# --------------------------------------------------------------------------- SeemoRe blocks (conv_sep_kan/seemore.py)
+# The top class SeemoRe (seemore.py:13-77) and its RME / ResGroup (:84-107, :162-181) cannot be constructed (RME passes
+# mlp_ratio= to a GatedFFN that has no such argument, :176 vs :355-358); the blocks below can, and are pinned on fixtures
+# generated from the reference's own modules (tests/golden/seemore.npz).  Forward only.
+def sm_layer_norm_cf(x: torch.Tensor, p: Params, prefix: str, eps: float = 1e-6) -> torch.Tensor:
+    """LayerNorm(data_format='channels_first') (seemore.py:386-410): per pixel over the channel axis of [B,C,H,W],
+    biased variance, eps inside the square root."""
+    mu = x.mean(dim=1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=1, keepdim=True)
+    xh = (x - mu) / torch.sqrt(var + eps)
+    return xh * p[prefix + "weight"][None, :, None, None] + p[prefix + "bias"][None, :, None, None]
+
+
+def sm_striped_conv(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """StripedConv2d(depthwise=True) (seemore.py:325-341): 1 x ks then ks x 1 depthwise convolutions, zero padding ks // 2."""
+    C = x.shape[1]
+    w0, w1 = p[prefix + "conv.0.weight"], p[prefix + "conv.1.weight"]
+    ks = w0.shape[-1]
+    h = F.conv2d(x, w0, p[prefix + "conv.0.bias"], padding=(0, ks // 2), groups=C)
+    return F.conv2d(h, w1, p[prefix + "conv.1.bias"], padding=(ks // 2, 0), groups=C)
+
+
+def sm_gated_ffn(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """seemore.py's GatedFFN with GELU (:354-382): t = gelu(fn_1(x)) [2C]; value, gate = halves; gelu(fn_2(value * dw3x3(gate)))."""
+    t = F.gelu(F.conv2d(x, p[prefix + "fn_1.0.weight"], p[prefix + "fn_1.0.bias"]))
+    c = t.shape[1] // 2
+    val, g = t[:, :c], t[:, c:]
+    ks = p[prefix + "gate.weight"].shape[-1]
+    g = F.conv2d(g, p[prefix + "gate.weight"], p[prefix + "gate.bias"], padding=ks // 2, groups=c)
+    return F.gelu(F.conv2d(val * g, p[prefix + "fn_2.0.weight"], p[prefix + "fn_2.0.bias"]))
+
+
+def sm_striped_conv_former(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """StripedConvFormer (seemore.py:134-155): q, v = halves of gelu(to_qv(x)); proj(striped(q) * v)."""
+    t = F.gelu(F.conv2d(x, p[prefix + "to_qv.0.weight"], p[prefix + "to_qv.0.bias"]))
+    c = t.shape[1] // 2
+    q = sm_striped_conv(t[:, :c], p, prefix + "attn.")
+    return F.conv2d(q * t[:, c:], p[prefix + "proj.weight"], p[prefix + "proj.bias"])
+
+
+def sm_sme(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """SME (seemore.py:114-129): x + block(norm_1(x)), then + ffn(norm_2(.))."""
+    x = x + sm_striped_conv_former(sm_layer_norm_cf(x, p, prefix + "norm_1."), p, prefix + "block.")
+    return x + sm_gated_ffn(sm_layer_norm_cf(x, p, prefix + "norm_2."), p, prefix + "ffn.")
+
+
+def sm_expert(x: torch.Tensor, k: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """Expert (seemore.py:289-302): conv_3(conv_2(k) * conv_1(x)), all 1x1, through a low-dimensional space."""
+    a = F.conv2d(x, p[prefix + "conv_1.weight"], p[prefix + "conv_1.bias"])
+    b = F.conv2d(k, p[prefix + "conv_2.weight"], p[prefix + "conv_2.bias"])
+    return F.conv2d(a * b, p[prefix + "conv_3.weight"], p[prefix + "conv_3.bias"])
+
+
+def sm_router(x: torch.Tensor, p: Params, prefix: str) -> torch.Tensor:
+    """Router (seemore.py:305-318): global average pool, then a bias-free linear map to one logit per expert."""
+    return x.mean(dim=(2, 3)) @ p[prefix + "body.2.weight"].t()
+
+
+def sm_moe_layer(x: torch.Tensor, k: torch.Tensor, p: Params, prefix: str, topk: int) -> torch.Tensor:
+    """MoELayer (seemore.py:261-285): per image, softmax over the router's logits, the top-k experts weighted by their
+    probabilities (not renormalised) added to the input.  The reference's train branch evaluates every expert and zeroes
+    the others' weights, its eval branch (one image) only the selected ones: the same sum."""
+    n_exp = p[prefix + "gate.body.2.weight"].shape[0]
+    w = torch.softmax(sm_router(x, p, prefix + "gate."), dim=1)
+    top = torch.topk(w, topk, dim=1).indices
+    mask = torch.zeros_like(w).scatter_(1, top, 1.0)
+    out = x.clone()
+    for e in range(n_exp):
+        we = (w * mask)[:, e]
+        if bool((we != 0).any()):
+            out = out + sm_expert(x, k, p, f"{prefix}experts.{e}.") * we[:, None, None, None]
+    return out
+
+
+def sm_moe_block(x: torch.Tensor, p: Params, prefix: str, topk: int, recursive: int, use_shuffle: bool = False) -> torch.Tensor:
+    """MoEBlock (seemore.py:188-258): conv_1 (3x3, GELU, 1x1 to 2C) -> [optional channel shuffle in 2 groups] -> halves x, k;
+    x = gelu(striped3(x)); k = k + bilinear(conv(agg_conv^recursive(k))) (agg_conv: depthwise 4x4 stride 4 + GELU; conv:
+    depthwise 3x3 then 1x1); proj(moe_layer(x, k))."""
+    t = F.conv2d(x, p[prefix + "conv_1.0.weight"], p[prefix + "conv_1.0.bias"], padding=1)
+    t = F.conv2d(F.gelu(t), p[prefix + "conv_1.2.weight"], p[prefix + "conv_1.2.bias"])
+    B, C2, H, W = t.shape
+    if use_shuffle:
+        t = t.reshape(B, 2, C2 // 2, H, W).transpose(1, 2).reshape(B, C2, H, W)
+    c = C2 // 2
+    xs, k = t[:, :c], t[:, c:]
+    xs = F.gelu(sm_striped_conv(xs, p, prefix + "conv_2.0."))
+    a = k
+    for _ in range(recursive):
+        a = F.gelu(F.conv2d(a, p[prefix + "agg_conv.0.weight"], p[prefix + "agg_conv.0.bias"], stride=4, groups=c))
+    a = F.conv2d(a, p[prefix + "conv.0.weight"], p[prefix + "conv.0.bias"], padding=1, groups=c)
+    a = F.conv2d(a, p[prefix + "conv.1.weight"], p[prefix + "conv.1.bias"])
+    k = k + F.interpolate(a, size=(H, W), mode="bilinear", align_corners=False)
+    y = sm_moe_layer(xs, k, p, prefix + "moe_layer.", topk)
+    return F.conv2d(y, p[prefix + "proj.weight"], p[prefix + "proj.bias"])

@@ -351,6 +351,66 @@ def gold_model_input_grad():
     save("model_input_grad", **out)
 
 
+def gold_seemore():
+    """Blocks of conv_sep_kan/seemore.py that can be constructed (the top class SeemoRe and RME / ResGroup raise in their
+    constructors): StripedConv2d, LayerNorm(channels_first), GatedFFN(GELU), StripedConvFormer, SME, Expert, Router,
+    MoELayer (train mode, batch 2; eval mode, batch 1: the reference's eval branch squeezes the batch axis) and MoEBlock
+    for the three lr_space rules (train mode, batch 2, 32 x 20: the second aggregation step floors) + eval mode (second image) +
+    use_shuffle (32 x 16, one aggregation step, 4 experts, top 1).
+    Every case: the module's state_dict, the input(s) and the forward output; no gradients (forward kernels only)."""
+    from conv_sep_kan import seemore as sm
+    gen = torch.Generator().manual_seed(777)
+    out = {}
+
+    def randomise(m):
+        with torch.no_grad():
+            for p_ in m.parameters():
+                p_.copy_(p_ + 0.05 * torch.randn(p_.shape, generator=gen))
+
+    def put(tag, m, y):
+        for n, v in m.state_dict().items():
+            out[f"{tag}.p.{n}"] = v
+        out[f"{tag}.y"] = y
+
+    C = 64
+    x = torch.randn(2, C, 16, 20, generator=gen)
+    k = torch.randn(2, C, 16, 20, generator=gen)
+    xb = torch.randn(2, C, 32, 20, generator=gen)       # inputs are stored once: x, k (small blocks), xb (MoEBlock)
+    out["x"], out["k"], out["xb"] = x, k, xb
+    for ks in (3, 11):
+        m = sm.StripedConv2d(C, kernel_size=ks, depthwise=True).eval(); randomise(m)
+        put(f"striped{ks}", m, m(x))
+    m = sm.LayerNorm(C, data_format="channels_first").eval(); randomise(m)
+    put("ln", m, m(x))
+    m = sm.GatedFFN(C, kernel_size=3, act_layer=torch.nn.GELU()).eval(); randomise(m)
+    put("gffn", m, m(x))
+    m = sm.StripedConvFormer(C, kernel_size=11).eval(); randomise(m)
+    put("scf", m, m(x))
+    m = sm.SME(C, kernel_size=11).eval(); randomise(m)
+    put("sme", m, m(x))
+    for low in (2, 7, 64):
+        m = sm.Expert(C, low).eval(); randomise(m)
+        put(f"expert{low}", m, m(x, k))
+    m = sm.Router(C, 6).eval(); randomise(m)
+    put("router", m, m(x))
+    experts = [sm.Expert(C, i + 2) for i in range(6)]
+    m = sm.MoELayer(experts=experts, gate=sm.Router(C, 6), num_expert=2); randomise(m)
+    m.train()
+    put("moelayer_train", m, m(x, k))
+    m.eval()
+    out["moelayer_eval.y"] = m(x[:1], k[:1])       # same parameters, first image
+    for space in ("linear", "exp", "double"):
+        m = sm.MoEBlock(C, num_experts=6, topk=2, use_shuffle=False, lr_space=space, recursive=2); randomise(m)
+        m.train()
+        put(f"moeblock_{space}_train", m, m(xb))
+        m.eval()
+        out[f"moeblock_{space}_eval.y"] = m(xb[1:])
+    m = sm.MoEBlock(C, num_experts=4, topk=1, use_shuffle=True, lr_space="exp", recursive=1); randomise(m)
+    m.train()
+    put("moeblock_shuffle_train", m, m(xb[:, :, :, :16].contiguous()))
+    save("seemore", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         for name in sys.argv[1:]:
@@ -368,3 +428,4 @@ if __name__ == "__main__":
     gold_color()
     gold_unet()
     gold_model_input_grad()
+    gold_seemore()

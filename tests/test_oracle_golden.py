@@ -291,3 +291,40 @@ def test_attention_head_gradients_are_ill_conditioned_for_bf16_features():
             outside.append((n, cos))
     assert len(outside) >= 5, outside          # measured: 20 of the tensors, worst cosine 0.9977 (layer 1 linear1.weight)
     assert all(c >= 0.99 for _, c in outside), outside
+
+
+def _sm_params(g, tag):
+    pre = tag + ".p."
+    return {k[len(pre):]: t(v) for k, v in g.items() if k.startswith(pre)}
+
+
+def test_seemore_blocks_oracle_vs_reference(golden):
+    """The constructible blocks of conv_sep_kan/seemore.py (:114-155, :188-410), restated in the oracle, against outputs of
+    the reference's own modules (tests/golden/seemore.npz, make_golden.py::gold_seemore): forward |d| <= 1e-5 + 1e-4 |ref|."""
+    g = golden("seemore")
+    x, k, xb = t(g["x"]), t(g["k"]), t(g["xb"])
+
+    def close(got, tag):
+        ref = t(g[tag + ".y"])
+        assert got.shape == ref.shape, (tag, got.shape, ref.shape)
+        err = (got - ref).abs()
+        assert bool((err <= FWD_ATOL + FWD_RTOL * ref.abs()).all()), (tag, float(err.max()))
+
+    for ks in (3, 11):
+        close(orc.sm_striped_conv(x, _sm_params(g, f"striped{ks}"), ""), f"striped{ks}")
+    close(orc.sm_layer_norm_cf(x, _sm_params(g, "ln"), ""), "ln")
+    close(orc.sm_gated_ffn(x, _sm_params(g, "gffn"), ""), "gffn")
+    close(orc.sm_striped_conv_former(x, _sm_params(g, "scf"), ""), "scf")
+    close(orc.sm_sme(x, _sm_params(g, "sme"), ""), "sme")
+    for low in (2, 7, 64):
+        close(orc.sm_expert(x, k, _sm_params(g, f"expert{low}"), ""), f"expert{low}")
+    close(orc.sm_router(x, _sm_params(g, "router"), ""), "router")
+    pl = _sm_params(g, "moelayer_train")
+    close(orc.sm_moe_layer(x, k, pl, "", topk=2), "moelayer_train")
+    close(orc.sm_moe_layer(x[:1], k[:1], pl, "", topk=2), "moelayer_eval")
+    for space in ("linear", "exp", "double"):
+        pb = _sm_params(g, f"moeblock_{space}_train")
+        close(orc.sm_moe_block(xb, pb, "", topk=2, recursive=2), f"moeblock_{space}_train")
+        close(orc.sm_moe_block(xb[1:], pb, "", topk=2, recursive=2), f"moeblock_{space}_eval")
+    close(orc.sm_moe_block(xb[:, :, :, :16].contiguous(), _sm_params(g, "moeblock_shuffle_train"), "", topk=1, recursive=1,
+                           use_shuffle=True), "moeblock_shuffle_train")
