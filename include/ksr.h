@@ -654,6 +654,42 @@ int ksr_unet_att_mix_bwd(const float* gram, const float* dT, int c, int heads, i
                          const float* temp_a, const float* temp_v, const float* wv, const float* wp, float vscale,
                          float* D, float* dparams, ksr_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Blocks of the SeemoRe backbone (conv_sep_kan/seemore.py), forward only, NHWC fp32.  The reference's top class
+ * SeemoRe (:13-77) and its RME / ResGroup (:84-107, :162-181) raise in their constructors (RME passes mlp_ratio= to a
+ * GatedFFN that has no such argument, :176 vs :355-358), so the drop-in surface is the constructible blocks:
+ * StripedConv2d :325-341, GatedFFN :354-382, LayerNorm(channels_first) :386-410, StripedConvFormer :134-155, SME :114-129,
+ * Expert :289-302, Router :305-318, MoELayer :261-285, MoEBlock :188-258 (host side: kan_sr/seemore.py).
+ * Tensors are [B, H, W, ld] with the operand's channels starting at c0 (torch.chunk halves are read in place).
+ * ------------------------------------------------------------------------------------------- */
+
+/* nn.Conv2d (dense or depthwise, any kernel shape / stride / zero padding) with optional exact GELU (nn.GELU()) after it,
+ * optional elementwise factor `mul` on the input (q * v of seemore.py:154, x * gate of :379) and optional residual added
+ * after the activation (seemore.py:127-128).  w: kernel layout, dense [KH*KW][Cin][Cout] / depthwise [KH*KW][Cout].
+ * Cout % 8 == 0, Cin % 4 == 0, row lengths and first channels multiples of 4. */
+int ksr_sm_conv_fwd(const float* in, int in_ld, int in_c0, const float* mul, int mul_ld, int mul_c0, const float* w,
+                    const float* bias, const float* res, int res_ld, int res_c0, float* out, int out_ld, int out_c0,
+                    int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_h, int pad_w,
+                    int depthwise, int act, ksr_stream_t stream);
+/* LayerNorm(data_format="channels_first").forward (seemore.py:402-410) over 64 channels: in / out [npix, 64]. */
+int ksr_sm_layernorm_fwd(const float* in, const float* gain, const float* shift, float* out, int64_t npix, float eps,
+                         ksr_stream_t stream);
+/* MoEBlock.calibrate's tail (seemore.py:243-244): out [B,H,W,64] = res + F.interpolate(src [B,hs,ws,64], size=(H,W),
+ * mode="bilinear", align_corners=False). */
+int ksr_sm_resize_add_fwd(const float* src, int hs, int ws, const float* res, int res_ld, int res_c0, float* out, int B,
+                          int H, int W, ksr_stream_t stream);
+/* Router.forward + the softmax / top-k of MoELayer.forward (seemore.py:317-318, :270-277): weights [B, E] = softmax over the
+ * experts of router_w [E,64] applied to the per-image channel means, all but the topk largest set to 0; logits_out [B, E]
+ * (optional) = Router.forward's output.  E <= 8. */
+int ksr_sm_route_fwd(const float* in, int in_ld, int in_c0, const float* router_w, int E, int topk, int B, int64_t HW,
+                     float* weights, float* logits_out, ksr_stream_t stream);
+/* The sum of MoELayer.forward (seemore.py:273-285) with Expert.forward (:298-302) inside: out [B*HW, 64] = x + sum_e
+ * weights[b, e] * conv_3_e(conv_2_e(k) * conv_1_e(x)).  ptrs: HOST array of 6 device pointers per expert (conv_1.weight
+ * [low,64], conv_1.bias, conv_2.weight [low,64], conv_2.bias, conv_3.weight [64,low], conv_3.bias); low: HOST array. */
+int ksr_sm_experts_fwd(const float* x, int x_ld, int x_c0, const float* k, int k_ld, int k_c0, const float* weights,
+                       const float* const* ptrs, const int* low, int n_experts, float* out, int B, int64_t HW,
+                       ksr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,6 +87,7 @@ def _declare(L: ctypes.CDLL) -> None:
 EXPORTS = [
     "ksr_version", "ksr_last_error", "ksr_set_precision", "ksr_get_precision",
     "ksr_reduce_defer", "ksr_reduce_flush", "ksr_reduce_pending",
+    "ksr_sm_conv_fwd", "ksr_sm_layernorm_fwd", "ksr_sm_resize_add_fwd", "ksr_sm_route_fwd", "ksr_sm_experts_fwd",
     "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",
     "ksr_stem_fwd", "ksr_stem_gate_fwd", "ksr_pointwise_fwd", "ksr_dwrelu_pw_fwd", "ksr_gate_pw_fwd",
     "ksr_batch_tx_layer_fwd", "ksr_batch_attn_fwd", "ksr_batch_qkv_attn_fwd", "ksr_batch_tx_layer_post_fwd",
