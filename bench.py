@@ -13,6 +13,8 @@ One JSON line on stdout (rank 0).  Workloads (synthetic data, random-init weight
           (BASELINE config "x4 SR inference, 1xMI355X, fp32, 1080p->4K"); N>1 = N independent replicas.
   train-unet : the same training step with the reference's UNet as the hyper-encoder (backbone="unet"), exact fp32,
           8 patches of 256x256 per GPU.  Not the headline configuration: a side workload for that backbone.
+  train-attn : BASELINE configs[3]: the same training step with ConvSepKanAttention(64, 64, 336) in place of `feed`
+          (attention=True) and the larger spline grid (G = 16, k = 3), 64 patches of 128x128 per GPU, bf16 storage.
 `value` = whole-job output megapixels per second with inputs resident in HBM.
 """
 import argparse
@@ -149,6 +151,31 @@ def measured_traffic(entry: str):
         return json.load(fh).get(ENTRY_KERNEL[entry])
 
 
+# entry point -> device kernel names (prefix match) of the attention-head workload, for the PMC lookup
+ATTN_ENTRY_KERNELS = {
+    "ksr_feed_kan_fwd_img": ("feed_kan_fwd_kernel",), "ksr_feed_kan_bwd_img": ("feed_kan_bwd_kernel",),
+    "ksr_chan_dw_fwd": ("chan_dw_kernel",), "ksr_chan_dw_bwd": ("chan_dw_kernel",), "ksr_chan_apply": ("chan_apply_kernel",),
+    "ksr_batch_attn_bwd": ("attn_bwd_dma_kernel",), "ksr_batch_tx_layer_bwd_token": ("tx_bwd_token_kernel",),
+    "ksr_batch_qkv_attn_fwd": ("qkv_attn_fwd_dma_kernel",), "ksr_in_proj_bwd_wg": ("inproj_bwd_fused_kernel",),
+    "ksr_batch_tx_layer_post_fwd": ("tx_layer_fwd_kernel",), "ksr_ssim_fwd": ("ssim_fwd_cols_kernel",),
+    "ksr_wgrad": ("wgrad_fast_kernel", "wgrad_kernel"), "ksr_gram_batched": ("wgrad_kernel",), "ksr_gram_batched_kan": ("wgrad_kernel",),
+}
+
+
+def measured_traffic_csv(entry: str, csv_name: str):
+    """HBM bytes per launch of an entry point's kernels (launch-weighted over the matching rows of a committed PMC summary)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", csv_name)
+    if entry not in ATTN_ENTRY_KERNELS or not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        rows = [r for r in csv.DictReader(fh) if r["kernel"].replace("void ", "").replace("(anonymous namespace)::", "").startswith(ATTN_ENTRY_KERNELS[entry])]
+    n = sum(int(r["launches_in_pmc_pass"]) for r in rows)
+    if not n:
+        return None
+    return int(sum(float(r["hbm_bytes_per_launch"]) * int(r["launches_in_pmc_pass"]) for r in rows) / n)
+
+
 def unet_kernel_models(P: int):
     """Algorithmic HBM bytes per LR pixel and training step of the two entry points that carry the UNet backbone
     (every launch reads its inputs and writes its output once, fp32; level l of the pyramid has 4^-l pixels):
@@ -161,6 +188,25 @@ def unet_kernel_models(P: int):
     wgrad = dc + 45 + 30 + att_apply + att_z + 2 * 20.75
     return {"ksr_unet_conv_fwd": ("hbm", 0, conv, PEAK_MFMA_F32_TFLOPS), "ksr_unet_wgrad": ("hbm", 0, wgrad, PEAK_MFMA_F32_TFLOPS),
             "ksr_kan_lin_fwd": ("hbm", 0, 84.0, PEAK_MFMA_F32_TFLOPS), "ksr_kan_lin_bwd": ("hbm", 0, 100.0, PEAK_MFMA_F32_TFLOPS)}
+
+
+def attn_head_kernel_models(P: int, act_bytes: int):
+    """Algorithmic HBM bytes per LR pixel and training step of the channel-attention head's entry points (cfg 4, fused form:
+    the head's last 1x1 map runs inside the feed+KAN kernels with one matrix per image).  a = bytes of one 64-channel
+    activation row in the storage type.  Per-image 64 x 64 algebra (ksr_chan_soft_*) moves no per-pixel bytes."""
+    a = 64 * act_bytes
+    lane = 2 * 16 * ((8 * (P // 16) + 15) // 16) * act_bytes        # gparam row: both lane halves, padded to MFMA blocks
+    pk = PEAK_MFMA_BF16_TFLOPS if act_bytes == 2 else PEAK_MFMA_F32_TFLOPS
+    return {
+        "ksr_chan_dw_fwd": ("hbm", 2 * 9 * 192, 3 * a + 3 * a, pk),                         # pq in, qkv out
+        "ksr_chan_dw_bwd": ("hbm", 2 * 9 * 192, 3 * a + 3 * a, pk),
+        "ksr_gram_batched": ("hbm", 2 * 64 * 64, 2 * a, pk),                               # q, k in
+        "ksr_gram_batched_kan": ("hbm", 2 * P * 64, lane + a, pk),                         # gparam, v in
+        "ksr_chan_apply": ("hbm", 2 * 128 * 128, 2 * a + 2 * a, pk),                       # [q|k] in, d[q|k] out
+        "ksr_feed_kan_fwd_img": ("hbm", 2 * 64 * P + 400, a + 4 + 4 * 16 + 128, pk),        # v in, Y' and (uw, S) out
+        "ksr_feed_kan_bwd_img": ("hbm", 2 * 64 * P + 800, 64 + 4 + 128 + a + lane, pk),    # dY', x, (uw, S) in, dv and gparam out
+        "ksr_pointwise_bwd": ("hbm", 2 * 192 * 64, 3 * a + a, pk),
+    }
 
 
 UNET_ENTRY_KERNELS = {"ksr_unet_conv_fwd": ("unet_conv_kernel", "unet_conv_ksplit_kernel"), "ksr_unet_wgrad": ("unet_wgrad_kernel",)}
@@ -185,11 +231,11 @@ def measured_traffic_unet(entry: str):
     return int(avg)
 
 
-def build_model(upscale=4, G=5, k=3, seed=0, backbone="gazetr"):
+def build_model(upscale=4, G=5, k=3, seed=0, backbone="gazetr", attention=False):
     from kan_sr.module import ConvSepKan
     from kan_sr.init import init_like_training_setup
     torch.manual_seed(seed)
-    m = ConvSepKan([1], [upscale * upscale], [3], G, k, 0.1, [-1, 1], upscale, backbone=backbone)
+    m = ConvSepKan([1], [upscale * upscale], [3], G, k, 0.1, [-1, 1], upscale, backbone=backbone, attention=attention)
     init_like_training_setup(m, seed)
     return m
 
@@ -212,6 +258,17 @@ def cpu_baseline(workload: str, seconds_budget: float = 12.0):
 
         def step():
             y = orc.conv_sep_kan_forward(x, p, backbone="unet", train=True, **kw)
+            y[:, :1].mean().backward()
+    elif workload == "train-attn":
+        from kan_sr.module import ConvSepKan
+        ref = ConvSepKan([1], [16], [3], 16, 3, 0.1, [-1, 1], 4, attention=True)
+        p = {n: v.detach().clone().requires_grad_() for n, v in ref.state_dict().items()}
+        kw = dict(kw, grid_size=16, attention=True)
+        x = torch.rand(4, 3, 128, 128)
+        sample = "4 patches of 128x128 (1/16 of the per-GPU batch), channel-attention head, G = 16, eval-mode graph, fwd+bwd"
+
+        def step():
+            y = orc.conv_sep_kan_forward(x, p, **kw)
             y[:, :1].mean().backward()
     elif workload == "infer":
         x = torch.rand(1, 3, 270, 480)
@@ -247,7 +304,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train", "train-unet"])
+    ap.add_argument("--workload", default=os.environ.get("KSR_BENCH_WORKLOAD", "train"), choices=["infer", "train", "train-unet", "train-attn"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true",
                     help="train: skip the inference and other-precision measurements (profiler passes: every launch in the "
@@ -291,9 +348,13 @@ def main():
     _lib.lib()   # fail loudly if the HIP library is missing
 
     unet = args.workload == "train-unet"
+    attn = args.workload == "train-attn"
     if unet:
         args.workload, args.precision = "train", "fp32"
-    model = build_model(backbone="unet" if unet else "gazetr").to(dev)
+    if attn:
+        args.workload = "train"
+    G = 16 if attn else 5
+    model = build_model(G=G, backbone="unet" if unet else "gazetr", attention=attn).to(dev)
     torch.manual_seed(1234 + rank)
     if args.workload == "infer":
         B, H, W = 1, 540, 960
@@ -347,6 +408,10 @@ def main():
               + "), dropout live" + ("; step replayed from a HIP graph" if graph and not args.no_graph else ""))
         if graph:
             args.warmup = max(args.warmup, 3)     # the graph is recorded on the third step
+        if attn:
+            wl = (f"x4 SR training step with the channel-attention head (ConvSepKanAttention(64, 64, 336) in place of feed) and "
+                  f"spline grid G = 16, k = 3, {mode} (fwd + loss {args.loss} + bwd + RCCL gradient all-reduce + Adam), {B} patches "
+                  "of 128x128 per GPU (BASELINE configs[3]), dropout live")
         if unet:
             wl = (f"x4 SR training step with the UNet hyper-encoder, exact fp32 (fwd + loss {args.loss} + bwd + RCCL gradient "
                   "all-reduce + Adam), 8 patches of 256x256 per GPU, BatchNorm on per-rank batch statistics"
@@ -401,12 +466,14 @@ def main():
         totals = {k: sum(v) / nlaunch for k, v in prof.items()}            # ms per step per entry point
         dom = max(totals, key=totals.get)
         avg_ms = sum(prof[dom]) / len(prof[dom])
-        P = 16 * (5 + 3 + 2)
+        P = 16 * (G + 3 + 2)
         bf16 = args.workload == "train" and args.precision != "fp32"
         models = kernel_models(B, P, bf16, 2 if (args.workload == "train" and args.precision == "bf16s") else 4,
                                train=args.workload != "infer")
         if unet:
             models.update(unet_kernel_models(P))
+        if attn:
+            models.update(attn_head_kernel_models(P, 2 if args.precision == "bf16s" else 4))
         kmodel = models.get(dom)
         npx = B * H * W
         roofline = {"kernel": dom, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
@@ -434,7 +501,11 @@ def main():
         roofline["launches_per_step"] = len(prof[dom]) // nlaunch
         roofline["ms_per_step_by_entry_point"] = {k: round(v, 4) for k, v in sorted(totals.items())}
         roofline["frac_by_entry_point"] = {k: [price(k)["bound"], price(k)["frac"]] for k in sorted(totals) if k in models}
-        if world == 1 and args.workload == "train" and not unet and not args.headline_only:
+        if attn and B == 64 and args.precision == "bf16s":
+            roofline["traffic"] = measured_traffic_csv(dom, "r03_cfg4_b64_bf16s_pmc_hbm.csv")
+            roofline["traffic_source"] = "profiles/r03_cfg4_b64_bf16s_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
+            roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
+        if world == 1 and args.workload == "train" and not unet and not attn and not args.headline_only:
             # second half of the headline metric: 1-GPU x4 inference of one 960x540 -> 3840x2160 frame
             model.eval()
             model.precision = "fp32"
@@ -482,7 +553,7 @@ def main():
                 del ts2, m2
             torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline("train-unet" if unet else args.workload)     # last: its threads stay out of the GPU timings
+            cpu = cpu_baseline("train-unet" if unet else ("train-attn" if attn else args.workload))     # last: its threads stay out of the GPU timings
 
     if args.workload == "train":
         ts.close()                      # every rank: destroys the gradient communicator
@@ -495,7 +566,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "bf16" if (args.workload == "train" and args.precision != "fp32") else "f32",
-            "data": "synthetic", "config": {"workload": wl, "upscale": 4, "grid_size": 5, "spline_order": 3,
+            "data": "synthetic", "config": {"workload": wl, "upscale": 4, "grid_size": G, "spline_order": 3,
                                             "per_gpu_batch": B, "lr_patch": [H, W]},
             "roofline": roofline, "cpu_baseline": cpu, "inference": inference, "ms_per_step_by_precision": by_precision}))
 

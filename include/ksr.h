@@ -297,6 +297,11 @@ int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b, int b_is_p
  * dW [64,1,3,3], db [64]. slab: 512*640 floats. */
 int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0, float* slab,
                      float* dW, float* db, int B, int H, int W, ksr_stream_t stream);
+/* The same for `groups` (1..8) depthwise convs over consecutive blocks of 64 channels of the same two tensors in ONE launch:
+ * the q_dw | k_dw | v_dw of the channel-attention head (conv_sep_kan_attention.py:16-37) under autograd.  dW [groups*64][9],
+ * db [groups*64]; slab: groups * 512 * 640 floats. */
+int ksr_dwconv_wgrad_groups(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0, int groups,
+                            float* slab, float* dW, float* db, int B, int H, int W, ksr_stream_t stream);
 
 /* ffn1's scalar front (pointwise1 1->1, depthwise 3x3 on one channel): out12 = gradients of
  * pointwise1.weight, pointwise1.bias, depthwise.weight (9), depthwise.bias.  slab: 256*12 floats. */

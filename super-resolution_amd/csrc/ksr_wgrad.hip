@@ -547,6 +547,10 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
     __shared__ __attribute__((aligned(16))) float halo[AFF ? HALO_H * HALO_W : HALO_FLOATS];
     __shared__ float red[10][4][64];
     const int tid = threadIdx.x, c = tid & 63, row = tid >> 6;
+    // blockIdx.y = group of 64 channels (several depthwise convs over neighbouring channel blocks of the same tensors)
+    a.in_c0 += 64 * (int)blockIdx.y;
+    a.ds_c0 += 64 * (int)blockIdx.y;
+    a.slab += (long)blockIdx.y * gridDim.x * 640;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
     const long ntiles = (long)a.B * tiles_y * tiles_x;
     const long HW = (long)a.H * a.W;
@@ -998,18 +1002,29 @@ extern "C" int ksr_colreduce(const float* a, int a_ld, int a_c0, const float* b,
 }
 
 // Depthwise 3x3 (64 channels) parameter gradients: dW [64][1][3][3], db [64]. slab: 512*640 floats.
-extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0,
-                                float* slab, float* dW, float* db, int B, int H, int W, hipStream_t stream) {
+// `groups` depthwise convs over consecutive blocks of 64 channels of the same two tensors (the q | k | v branches of the
+// channel-attention head) in one launch: dW [groups*64][9], db [groups*64]; slab: groups * 512 * 640 floats.
+extern "C" int ksr_dwconv_wgrad_groups(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0, int groups,
+                                       float* slab, float* dW, float* db, int B, int H, int W, hipStream_t stream) {
     KSR_CHECK_ARG(in && ds && slab && dW && db && B > 0 && H > 0 && W > 0 && ds_ld >= 64, "dwconv_wgrad: bad argument");
+    KSR_CHECK_ARG(groups >= 1 && groups <= 8 && in_c0 + 64 * groups <= in_ld && ds_c0 + 64 * groups <= ds_ld,
+                  "dwconv_wgrad: the channel groups do not fit the rows");
     DwgArgs d{in, in_ld, in_c0, ds, ds_ld, ds_c0, slab, B, H, W, nullptr, nullptr};
     long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
     const long g = ntiles < 512 ? ntiles : 512;
-    if (ksr_prec() == KSR_BF16S) hipLaunchKernelGGL(dwgrad_kernel<__bf16>, dim3((unsigned)g), dim3(256), 0, stream, d);
-    else hipLaunchKernelGGL(dwgrad_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, d);
+    const dim3 grid((unsigned)g, (unsigned)groups);
+    if (ksr_prec() == KSR_BF16S) hipLaunchKernelGGL(dwgrad_kernel<__bf16>, grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL(dwgrad_kernel<float>, grid, dim3(256), 0, stream, d);
     KSR_LAUNCH_CHECK("dwconv_wgrad");
-    // slab rows: tap t (J = 9) x channel (K = 64) then the bias row handled as a 10th row via two calls
-    if (int rc = launch_reduce(slab, (int)g, 9, 64, 640, dW, 1, 9, nullptr, 0, 0, 0, stream)) return rc;
-    return launch_reduce(slab + 576, (int)g, 1, 64, 640, db, 64, 1, nullptr, 0, 0, 0, stream);
+    // slab rows: tap t (J = 9) x channel (K = 64) then the bias row handled as a 10th row via two calls; one batch entry
+    // per channel group (its partial rows follow the previous group's, its outputs 576 / 64 floats on)
+    if (int rc = launch_reduce(slab, (int)g, 9, 64, 640, dW, 1, 9, nullptr, 0, 0, 0, stream, -1, -1, groups, 576)) return rc;
+    return launch_reduce(slab + 576, (int)g, 1, 64, 640, db, 64, 1, nullptr, 0, 0, 0, stream, -1, -1, groups, 64);
+}
+
+extern "C" int ksr_dwconv_wgrad(const float* in, int in_ld, int in_c0, const float* ds, int ds_ld, int ds_c0,
+                                float* slab, float* dW, float* db, int B, int H, int W, hipStream_t stream) {
+    return ksr_dwconv_wgrad_groups(in, in_ld, in_c0, ds, ds_ld, ds_c0, 1, slab, dW, db, B, H, W, stream);
 }
 
 // The same for the first gated block's depthwise conv, whose input (the gate half of t) is rebuilt from (v, ab).

@@ -74,11 +74,10 @@ class _QkvFn(torch.autograd.Function):
         check(L.ksr_chan_dw_bwd(ptr(dqkv), ptr(dw_w), ptr(dpq), c_int(192), c_int(3), c_int(B), c_int(H), c_int(W),
                                 stream()), "ksr_chan_dw_bwd")
         g_dw_w, g_dw_b = _new(dev, 192, 9), _new(dev, 192)
-        slab = _new(dev, max(512 * 640, int(L.ksr_wgrad_slab_floats(c_int(192), c_int(64)))))
-        for gi in range(3):
-            check(L.ksr_dwconv_wgrad(ptr(pq), c_int(192), c_int(64 * gi), ptr(dqkv), c_int(192), c_int(64 * gi), ptr(slab),
-                                     ptr(g_dw_w[64 * gi:64 * gi + 64]), ptr(g_dw_b[64 * gi:64 * gi + 64]),
-                                     c_int(B), c_int(H), c_int(W), stream()), "ksr_dwconv_wgrad")
+        slab = _new(dev, max(3 * 512 * 640, int(L.ksr_wgrad_slab_floats(c_int(192), c_int(64)))))
+        # the three branches' depthwise weight gradients in one launch (channel groups q | k | v of the same two tensors)
+        check(L.ksr_dwconv_wgrad_groups(ptr(pq), c_int(192), c_int(0), ptr(dqkv), c_int(192), c_int(0), c_int(3), ptr(slab),
+                                        ptr(g_dw_w), ptr(g_dw_b), c_int(B), c_int(H), c_int(W), stream()), "ksr_dwconv_wgrad_groups")
         g_w, g_b = _new(dev, 192, 64), _new(dev, 192)
         check(L.ksr_wgrad(ptr(dpq), c_int(192), c_int(0), c_int(192), ptr(x), c_int(64), c_int(0), c_int(64),
                           ptr(None), c_int(0), c_int(0), c_int64(N), ptr(slab), ptr(g_w), ptr(g_b), c_int(0), c_int(0),
