@@ -65,6 +65,13 @@ inline unsigned ksr_persistent_grid(K kernel, long ntiles, long cap, int block =
     return (unsigned)(ntiles < slots ? ntiles : slots);
 }
 
+// Deferred slab reductions (ksr_reduce_defer / ksr_reduce_flush, ksr_wgrad.hip): whether the calling thread records its
+// reductions, and the UNet weight-gradient kernels' share of the recorded list (ksr_unet_bwd.hip).
+bool ksr_reduce_deferring();
+int ksr_unet_reduce_flush(hipStream_t stream);
+int ksr_unet_reduce_pending();
+void ksr_unet_reduce_clear();
+
 struct KsrKnots {
     float t[KSR_MAX_KNOTS];
     int M;  // number of knots = G + 2k + 1

@@ -192,6 +192,44 @@ __global__ void __launch_bounds__(256) unet_wgrad_reduce_kernel(WgRedArgs a) {
     }
 }
 
+// Several of those reductions in one launch (the deferred form: ksr_reduce_defer / ksr_reduce_flush): workgroup -> (entry,
+// block of 16 outputs) through the prefix table; per output the same sums in the same order as the kernel above.
+constexpr int UNET_RED_BATCH_MAX = 40;
+struct WgRedBatch {
+    WgRedArgs e[UNET_RED_BATCH_MAX];
+    int first[UNET_RED_BATCH_MAX + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256) unet_wgrad_reduce_batch_kernel(WgRedBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.first[i + 1]) ++i;
+    const WgRedArgs a = b.e[i];
+    const int le = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = ((int)blockIdx.x - b.first[i]) * 16 + le;
+    const long K = (long)a.B * a.chunks;
+    __shared__ double red[16][16];
+    double s = 0.0;
+    if (e < a.E) {
+        const float* p = a.partials + e;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        long k = sl;
+        for (; k + 48 < K; k += 64) {
+            s0 += p[k * a.E]; s1 += p[(k + 16) * a.E]; s2 += p[(k + 32) * a.E]; s3 += p[(k + 48) * a.E];
+        }
+        for (; k < K; k += 16) s0 += p[k * a.E];
+        s = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+    }
+    red[sl][le] = s;
+    __syncthreads();
+    if (sl == 0 && e < a.E) {
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tot += red[k][le];
+        a.out[e] = (float)tot;
+    }
+}
+thread_local WgRedBatch g_unet_red;
+
 // ------------------------------------------------------------------------------------------------ BatchNorm + ReLU
 struct BnRedArgs { const float* dout; const float* raw; const float* scale; const float* shift; float* partials; long npix; int C; };
 
@@ -590,6 +628,19 @@ __global__ void __launch_bounds__(256) unet_att_mix_bwd_kernel(MixBwdArgs a) {
 
 }  // namespace
 
+int ksr_unet_reduce_flush(hipStream_t stream) {
+    WgRedBatch& b = g_unet_red;
+    if (b.n == 0) return KSR_OK;
+    const int blocks = b.first[b.n];
+    hipLaunchKernelGGL(unet_wgrad_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
+    b.n = 0;
+    KSR_LAUNCH_CHECK("unet_wgrad_reduce(batch)");
+    return KSR_OK;
+}
+int ksr_unet_reduce_pending() { return g_unet_red.n; }
+void ksr_unet_reduce_clear() { g_unet_red.n = 0; }
+
+
 struct WgPlan { int cols, segs, nwg, E; };
 
 static bool wgrad_plan(int mode, int ks, int stride, int ca, int cg, int B, int Ha, int Wa, int Hg, int Wg, WgPlan& p) {
@@ -646,6 +697,18 @@ extern "C" int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1
                        stream, a);
     KSR_LAUNCH_CHECK("unet_wgrad");
     WgRedArgs r{slab, out, B, p.nwg, p.E, per_image};
+    if (!per_image && ksr_reduce_deferring()) {
+        // recorded, not run: the caller keeps slab and out until ksr_reduce_flush (a full list is flushed here)
+        WgRedBatch& b = g_unet_red;
+        if (b.n == UNET_RED_BATCH_MAX) {
+            if (int rc = ksr_unet_reduce_flush(stream)) return rc;
+        }
+        if (b.n == 0) b.first[0] = 0;
+        b.e[b.n] = r;
+        b.first[b.n + 1] = b.first[b.n] + (p.E + 15) / 16;
+        ++b.n;
+        return KSR_OK;
+    }
     hipLaunchKernelGGL(unet_wgrad_reduce_kernel, dim3((unsigned)((p.E + 15) / 16), (unsigned)(per_image ? B : 1)), dim3(256), 0, stream, r);
     KSR_LAUNCH_CHECK("unet_wgrad_reduce");
     return KSR_OK;

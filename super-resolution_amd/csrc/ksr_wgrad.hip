@@ -852,18 +852,25 @@ extern "C" int ksr_wgrad_slab_floats(int J, int K) { return WG_GRID * (J * K + J
 // ksr_reduce_flush(stream) runs all recorded ones in a single launch: same sums, same order, same bits.  The caller must
 // then give every such call its OWN slab and keep slabs and outputs alive and untouched until the flush, and must order the
 // flush after every producer (same stream, or an event).  ksr_reduce_defer(0) ends the mode (the list must be empty).
+bool ksr_reduce_deferring() { return g_red_defer; }
+
 extern "C" int ksr_reduce_defer(int on) {
     if (on < 0) {                 // abandon: drop what was recorded (error paths of the caller)
         g_red_batch.n = 0;
+        ksr_unet_reduce_clear();
         g_red_defer = false;
         return KSR_OK;
     }
-    KSR_CHECK_ARG(on || g_red_batch.n == 0, "reduce_defer(0): %d recorded reductions were never flushed", g_red_batch.n);
+    const int pending = g_red_batch.n + ksr_unet_reduce_pending();
+    KSR_CHECK_ARG(on || pending == 0, "reduce_defer(0): %d recorded reductions were never flushed", pending);
     g_red_defer = on != 0;
     return KSR_OK;
 }
-extern "C" int ksr_reduce_flush(hipStream_t stream) { return flush_reduce_batch(stream); }
-extern "C" int ksr_reduce_pending(void) { return g_red_batch.n; }
+extern "C" int ksr_reduce_flush(hipStream_t stream) {
+    if (int rc = flush_reduce_batch(stream)) return rc;
+    return ksr_unet_reduce_flush(stream);
+}
+extern "C" int ksr_reduce_pending(void) { return g_red_batch.n + ksr_unet_reduce_pending(); }
 
 // Fixed-order sum of G partial rows [J*K | J] (written by a kernel that accumulated the products itself) to dW, db.
 int ksr_slab_reduce(const float* slab, int G, int J, int K, float* dW, float* db, hipStream_t stream) {

@@ -20,6 +20,11 @@ import torch.nn as nn
 from ._lib import KsrError, check, lib, ptr, stream
 
 
+# One launch for the reductions that finish the plain weight gradients of a backward pass (see UNet._backward)
+DEFER_WGRAD_REDUCTIONS = True
+_DEFERRED_SLABS = None          # while a backward pass records its reductions: the slabs they will read
+
+
 def _new(dev, *shape):
     return torch.empty(*shape, device=dev, dtype=torch.float32)
 
@@ -362,6 +367,8 @@ class UNet(nn.Module):
         nslab = int(L.ksr_unet_wgrad_slab_floats(c_int(mode), c_int(ks), c_int(ca), c_int(cg), c_int(B), c_int(Ha), c_int(Wa),
                                                  c_int(Hg), c_int(Wg)))
         slab = _new(g.device, max(1, nslab))
+        if _DEFERRED_SLABS is not None and not per_image:
+            _DEFERRED_SLABS.append(slab)          # its reduction is recorded, not run: alive until the flush
         if out is None:
             out = _new(g.device, *((B, E) if per_image else (E,)))
         elif out.numel() != (B * E if per_image else E):
@@ -568,10 +575,27 @@ class UNet(nn.Module):
         """dw [B*H*W, P]: gradient of the output (with the head fused: [B*H*W, 4], gradient of reproj's input, reproj's
         own parameter gradients being in self._KG["reproj"] already) -> {parameter name: gradient}; with want_input_grad
         the gradient of the input plane [B,H,W,1] is left in self._input_grad."""
+        global _DEFERRED_SLABS
         self._tape = tape
         B, H, W = tape["reproj"]["dims"]
         self._ensure_prepared()
         self._ensure_emit_plan(B)
+        # The 27 plain weight gradients end in a small fixed-order reduction each, whose results only the parameter-gradient
+        # table below reads: they are recorded and run in ONE launch before it (ksr_reduce_defer / ksr_reduce_flush).
+        defer = DEFER_WGRAD_REDUCTIONS
+        if defer:
+            check(lib().ksr_reduce_defer(c_int(1)), "ksr_reduce_defer")
+            _DEFERRED_SLABS = []
+        try:
+            return self._backward_body(tape, dw, want_input_grad, B, H, W, defer)
+        except BaseException:
+            if defer:
+                lib().ksr_reduce_defer(c_int(-1))
+            raise
+        finally:
+            _DEFERRED_SLABS = None
+
+    def _backward_body(self, tape, dw, want_input_grad, B, H, W, defer):
         P = self.out_channels
         y = tape["reproj"]["y"]
         if tape["reproj"]["fused"]:
@@ -599,6 +623,9 @@ class UNet(nn.Module):
             dpooled, _ = self._double_conv_bwd(key, dc, dout, need_input_grad=lvl > 0 or want_input_grad)
         self._input_grad = dpooled if want_input_grad else None
         self._tape = None
+        if defer:
+            check(lib().ksr_reduce_flush(stream()), "ksr_reduce_flush")
+            check(lib().ksr_reduce_defer(c_int(0)), "ksr_reduce_defer")
         return self._collect_grads()
 
     def forward_nhwc(self, y_plane: torch.Tensor, fuse_head: bool = False) -> torch.Tensor:
