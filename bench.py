@@ -491,7 +491,7 @@ def main():
             roofline.update(price(dom))
         if args.workload == "train" and args.precision == "bf16s" and B == 64:
             roofline["traffic"] = measured_traffic(dom)
-            roofline["traffic_source"] = "profiles/r02_train_b64_bf16s_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
+            roofline["traffic_source"] = "profiles/r03_train_b64_bf16s_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
             roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
         if unet and B == 8:
             roofline["traffic"] = measured_traffic_unet(dom)

@@ -66,7 +66,7 @@ wg = [r for r in rows if r[0].startswith(("wgrad_kernel<", "wgrad_fast_kernel<")
 if wg:
     per_kernel["entry:ksr_wgrad"] = int(sum(r[6] * r[1] for r in wg) / sum(r[1] for r in wg) + next((v for k, v in per_kernel.items() if k.startswith("reduce_kernel")), 0))
 # bench.py reads the default workload's file; other tags keep their own
-with open(os.path.join(OUT, "pmc_hbm_bytes_per_launch.json" if TAG == "r02_train_b64_bf16s" else f"{TAG}_pmc_hbm_bytes_per_launch.json"), "w") as fh:
+with open(os.path.join(OUT, "pmc_hbm_bytes_per_launch.json" if TAG in ("r02_train_b64_bf16s", "r03_train_b64_bf16s") else f"{TAG}_pmc_hbm_bytes_per_launch.json"), "w") as fh:
     json.dump(per_kernel, fh, indent=1)
 total = sum(r[6] * r[1] for r in rows)
 print(f"wrote {len(rows)} kernels to profiles/{TAG}_*; HBM bytes over the PMC pass: {total / 1e9:.2f} GB "
