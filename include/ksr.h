@@ -321,6 +321,24 @@ int64_t ksr_tx_bwd_wg_slab_floats(void);
 int ksr_batch_tx_layer_bwd_out_wg(const float* du1, const float* ctx, const float* out_w, float* dctx, int64_t N,
                                   float p_drop, uint64_t seed, float* wg_slab, float* dW, float* db, ksr_stream_t stream);
 
+/* bf16-storage mode: the per-token backward of the layer (the part of ksr_batch_tx_layer_bwd_token that stops at du1) as two
+ * kernels that each accumulate one of the MLP's weight gradients from operands they hold, replacing that call and the two
+ * ksr_wgrad launches for linear2 / linear1 (TransformerEncoderLayer.forward under autograd, gazetr.py:53-66).
+ * ..._mlp_wg: norm2 <- linear2 <- ReLU / dropout.  dy [N,64]: gradient of the layer's output (for the last layer: of the
+ *   final norm's input, see ksr_feed_kan_bwd_lnf); xhat2, rstd2, hmid: saved by the forward.  Writes du2 [N,64] (gradient
+ *   entering the second residual branch) and dpre [N,32]; ln_grad: norm2's gain gradient at [c], shift gradient at
+ *   [ln_row_stride + c]; dW2 [64,32], db2 [64].  ln_slab: 768 * 128 floats; wg_slab: ksr_tx_bwd_wg_slab_floats().
+ * ..._ln1_wg: du1 [N,64] = LayerNorm-1 backward of du2 + dpre W1; ln_grad: norm1's (gain, shift) gradient pair; dW1 [32,64]
+ *   is the product with xhat1 (map it through norm1 with ksr_wgrad_affine_input), db1 [32].  ln_slab: 768 * 128 floats. */
+int ksr_batch_tx_layer_bwd_mlp_wg(const float* dy, const float* xhat2, const float* rstd2, const float* hmid,
+                                  const float* n2_w, const float* l2_w, float* du2, float* dpre, int64_t N, float p_drop,
+                                  uint64_t seed, float* ln_slab, float* ln_grad, int ln_row_stride, float* wg_slab,
+                                  float* dW2, float* db2, ksr_stream_t stream);
+int ksr_batch_tx_layer_bwd_ln1_wg(const float* du2, const float* dpre, const float* xhat1, const float* rstd1,
+                                  const float* n1_w, const float* l1_w, float* du1, int64_t N, float* ln_slab,
+                                  float* ln_grad, int ln_row_stride, float* wg_slab, float* dW1, float* db1,
+                                  ksr_stream_t stream);
+
 /* Deferred slab reductions (no counterpart in the reference, whose parameter gradients come from autograd:
  * src/ml/pipelines/default.py:75-84).  Every entry point that accumulates a parameter gradient writes per-workgroup
  * partial rows into its slab and ends with a small fixed-order reduction launch.  After ksr_reduce_defer(1) the CALLING
@@ -371,6 +389,16 @@ int ksr_ssim_y_grad_l1(const float* maps, const float* pred, int64_t pred_batch_
                        int64_t tgt_batch_stride, float* grad, int64_t grad_batch_stride, int B, int H, int W, float scale,
                        float l1_grad_scale, float* l1_slab, float* l1_out, const float* ssim_value, float ssim_weight,
                        float* loss_out, ksr_stream_t stream);
+
+/* ksr_feed_kan_bwd with the backward of the LayerNorm that produced feat - the encoder's final norm (gazetr.py:113, under
+ * autograd) - inside (bf16-storage mode only): gfeat receives the gradient of that LayerNorm's INPUT (the last transformer
+ * layer's output), ln_grad the norm's gain gradient at [c] and shift gradient at [ln_row_stride + c].  xhat [N,64], rstd [N]:
+ * as saved by ksr_batch_tx_layer_post_fwd; ln_slab: 768 * 128 floats of workspace. */
+int ksr_feed_kan_bwd_lnf(const float* gout, int64_t gout_batch_stride, const float* x_img, int64_t img_batch_stride,
+                         const float* feed_w, const float* save_us, float* gfeat, float* gparam, int B, int H, int W,
+                         int upscale, int n_coef, const float* knots, int n_knots, int spline_order, const float* xhat,
+                         const float* rstd, const float* ln_w, float* ln_slab, float* ln_grad, int ln_row_stride,
+                         ksr_stream_t stream);
 
 /* The fused feed + KAN kernels with ONE WEIGHT MATRIX PER IMAGE (feed_w_per_image [B][P][64], P = r^2 (n_coef + 2); the
  * bias [P] is shared) and the pixel's 64 features at channels feat_c0 .. feat_c0 + 63 of rows of feat_ld elements.  This

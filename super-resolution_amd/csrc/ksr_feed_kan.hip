@@ -31,6 +31,9 @@ struct FeedArgs {
     long w_bstride, bias_bstride;
     int feat_ld, feat_c0;      // row length and first channel of feat (64, 0 for a dense [N,64] tensor)
     int gfeat_ld, gfeat_c0;    // the same for gfeat
+    // backward, optional: feat is the output of a LayerNorm (the encoder's final norm) whose backward runs here too: gfeat
+    // then receives the gradient of that LayerNorm's INPUT, and lnf_slab [grid][2][64] its gain / shift gradient sums
+    const void* lnf_xhat; const float* lnf_rstd; const float* lnf_w; float* lnf_slab;
 };
 
 // Pixels a workgroup's tiles run over: all N, or the HW pixels of image blockIdx.y (per-image weights)
@@ -334,9 +337,13 @@ template <int NB, bool COAL>
 struct __attribute__((aligned(16))) FeedBwdSmem {
     float frag[2 * (NB * 16) * 64];
     float knots[KSR_MAX_KNOTS];
+    float lnf[64];                                     // gain of the fused final LayerNorm
     // bf16 storage: per-wave tile through which the two outputs leave in lane-linear 16-byte pieces (a lane's own 160
-    // and 64 contiguous bytes, stored directly, make every store instruction touch 64 separate segments)
-    __bf16 tile[COAL ? 4 * 32 * (NB * 16 + 8 > 72 ? NB * 16 + 8 : 72) : 8];
+    // and 64 contiguous bytes, stored directly, make every store instruction touch 64 separate segments); between the
+    // two it serves as the wave's fp32 transposer for the fused final LayerNorm (hence at least KSR_XPOSE_FLOATS floats)
+    static constexpr int OUT_TILE = 32 * (NB * 16 + 8 > 72 ? NB * 16 + 8 : 72);
+    static constexpr int WAVE_TILE = OUT_TILE > 2 * KSR_XPOSE_FLOATS ? OUT_TILE : 2 * KSR_XPOSE_FLOATS;
+    __bf16 tile[COAL ? 4 * WAVE_TILE : 8];
 };
 
 // Backward: dparam[e] per lane (lane order), dfeat = dparam * W_feed, both stored; the feed weight
@@ -348,13 +355,17 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
     using ST = typename KsrStore<PREC>::T;
     constexpr bool COAL = sizeof(ST) == 2;
     constexpr int TLD = KH + 8;                       // tile pitch for the parameter gradients (16 bytes of padding)
-    constexpr int TILE = 32 * (TLD > 72 ? TLD : 72);  // elements per wave (the feature gradients use a pitch of 72)
+    constexpr int TILE = FeedBwdSmem<NB, COAL>::WAVE_TILE;   // elements per wave (the feature gradients use a pitch of 72)
+    static_assert(!COAL || 32 * (TLD > 72 ? TLD : 72) <= TILE, "the output tiles fit");
     __shared__ FeedBwdSmem<NB, COAL> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
     ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.w + (long)blockIdx.y * a.w_bstride, 64, nullptr, MapHL{32},
                                          MapKan{C::O, KC}, tid, 256);
     if (tid < KSR_MAX_KNOTS) sm.knots[tid] = kn.t[tid];
+    const bool lnf = COAL && a.lnf_xhat != nullptr;
+    if (lnf && tid < 64) sm.lnf[tid] = a.lnf_w[tid];
+    float lcs0 = 0.f, lcs1 = 0.f;                    // lane = channel: sums of g * xhat and of g over this wave's tokens
     __syncthreads();
 
     const int HW = a.H * a.W;
@@ -444,6 +455,25 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
 #pragma unroll
         for (int i = 0; i < 16; ++i) { df[i] = acc[0][i]; df[16 + i] = acc[1][i]; }
         if constexpr (COAL) {
+            if (lnf) {
+                // backward of the LayerNorm that produced feat: column sums for its gain / shift, then the gradient of its input
+                float* xbf = reinterpret_cast<float*>(tl);       // the parameter-gradient stores have read the tile (fence inside)
+                const int nv = (N - n0w) < 32 ? (int)(N - n0w > 0 ? N - n0w : 0) : 32;
+                float xh[32];
+                ksr_load32_co<ST>(xbf, a.lnf_xhat, n0w, nv, 64, 0, lane, xh);
+                if (!live) {
+#pragma unroll
+                    for (int i = 0; i < 32; ++i) df[i] = 0.f;
+                }
+                ksr_colsum32(xbf, lane, df, xh, lcs0, lcs1);
+                const float rs = a.lnf_rstd[n];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) { df[i] *= sm.lnf[32 * h + i]; s1 += df[i]; s2 += df[i] * xh[i]; }
+                const float m1 = ksr_pair_sum(s1) * (1.f / 64.f), m2 = ksr_pair_sum(s2) * (1.f / 64.f);
+#pragma unroll
+                for (int i = 0; i < 32; ++i) df[i] = rs * (df[i] - m1 - xh[i] * m2);
+            }
             constexpr int FLD = 72;                       // 64 channels + 16 bytes of padding
             static_assert(32 * FLD <= TILE, "the feature-gradient tile fits");
             ksr_wave_fence();
@@ -461,13 +491,29 @@ __global__ void __launch_bounds__(256, 2) feed_kan_bwd_kernel(FeedArgs a, KsrKno
             if (live) ksr_storen<ST, 32>(a.gfeat, n * a.gfeat_ld + a.gfeat_c0 + 32 * h, df);
         }
     }
+    if constexpr (COAL) {
+        if (lnf) {
+            // the four waves' sums meet in LDS (each wave's own tile first), one row [2][64] per workgroup
+            const float* t0 = reinterpret_cast<const float*>(sm.tile);
+            constexpr int WT = TILE / 2;                  // floats per wave tile
+            float* xbf = reinterpret_cast<float*>(sm.tile + wv * TILE);
+            ksr_wave_fence();
+            xbf[lane] = lcs0; xbf[64 + lane] = lcs1;
+            __syncthreads();
+            for (int i = tid; i < 128; i += 256)
+                a.lnf_slab[((long)blockIdx.y * gridDim.x + blockIdx.x) * 128 + i] = (t0[i] + t0[WT + i]) + (t0[2 * WT + i] + t0[3 * WT + i]);
+        }
+    }
 }
 
 template <int R, int KC, int KORD>
-int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
+int launch_feed_bwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s, int* grid_out = nullptr) {
 #define KSR_CALL(P)                                                                                                      \
     do {                                                                                                                 \
-        const dim3 grid = feed_grid(a, ksr_wg_slots(reinterpret_cast<const void*>(feed_kan_bwd_kernel<P, R, KC, KORD>), 256)); \
+        long cap = ksr_wg_slots(reinterpret_cast<const void*>(feed_kan_bwd_kernel<P, R, KC, KORD>), 256);               \
+        if (a.lnf_xhat && cap > 768) cap = 768;                    /* rows of the LayerNorm slab */                      \
+        const dim3 grid = feed_grid(a, cap);                                                                             \
+        if (grid_out) *grid_out = (int)(grid.x * grid.y);                                                                \
         hipLaunchKernelGGL((feed_kan_bwd_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn);                         \
     } while (0)
     KSR_DISPATCH_PREC(KSR_CALL);
@@ -548,10 +594,15 @@ extern "C" int ksr_feed_kan_lane_len(int upscale, int n_coef) {
     return (nh + 15) / 16 * 16;
 }
 
+// gradient sums of up to three LayerNorms from per-workgroup rows [G][2][64] (ksr_tx_bwd.hip)
+int ksr_ln_reduce(const float* slab, int G, float* out0, float* out1, float* out2, int row_stride, hipStream_t stream);
+
 static int feed_kan_bwd_impl(const float* gout, int64_t gout_batch_stride, const float* x_img, int64_t img_batch_stride,
                              const float* feed_w, int per_image_weights, const float* save_us, float* gfeat, int gfeat_ld,
                              int gfeat_c0, float* gparam, int B, int H, int W, int upscale, int n_coef, const float* knots,
-                             int n_knots, int spline_order, hipStream_t stream) {
+                             int n_knots, int spline_order, hipStream_t stream, const float* lnf_xhat = nullptr,
+                             const float* lnf_rstd = nullptr, const float* lnf_w = nullptr, float* lnf_slab = nullptr,
+                             float* lnf_grad = nullptr, int lnf_row_stride = 0) {
     KSR_CHECK_ARG(gout && x_img && feed_w && save_us && gfeat && gparam && knots, "feed_kan_bwd: null pointer");
     KSR_CHECK_ARG(gfeat_ld >= 64 && gfeat_c0 >= 0 && gfeat_c0 + 64 <= gfeat_ld && gfeat_ld % 8 == 0 && gfeat_c0 % 8 == 0,
                   "feed_kan_bwd: bad feature-gradient row layout (ld %d, first channel %d)", gfeat_ld, gfeat_c0);
@@ -565,13 +616,21 @@ static int feed_kan_bwd_impl(const float* gout, int64_t gout_batch_stride, const
     a.w = feed_w; a.save_us = const_cast<float*>(save_us); a.gfeat = gfeat; a.gparam = gparam; a.B = B; a.H = H; a.W = W;
     a.gfeat_ld = gfeat_ld; a.gfeat_c0 = gfeat_c0; a.feat_ld = 64;
     a.w_bstride = per_image_weights ? (long)ksr_feed_kan_P(upscale, n_coef) * 64 : 0;
+    if (lnf_xhat) {
+        KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "feed_kan_bwd: the fused LayerNorm backward exists in the bf16 storage mode only");
+        KSR_CHECK_ARG(lnf_rstd && lnf_w && lnf_slab && lnf_grad && lnf_row_stride >= 64 && gfeat_ld == 64 && gfeat_c0 == 0,
+                      "feed_kan_bwd: the fused LayerNorm backward needs rstd, gain, a slab, its gradient pair and a dense gfeat");
+        a.lnf_xhat = lnf_xhat; a.lnf_rstd = lnf_rstd; a.lnf_w = lnf_w; a.lnf_slab = lnf_slab;
+    }
     KsrKnots kn;
     for (int i = 0; i < KSR_MAX_KNOTS; ++i) kn.t[i] = knots[i < n_knots ? i : n_knots - 1];
     kn.M = n_knots; kn.k = spline_order;
-#define KSR_X(R, KC, KO) if (upscale == R && n_coef == KC && spline_order == KO) return launch_feed_bwd<R, KC, KO>(a, kn, stream);
+    int grid = 0, rc = KSR_ERR_UNSUPPORTED;
+#define KSR_X(R, KC, KO) if (upscale == R && n_coef == KC && spline_order == KO) rc = launch_feed_bwd<R, KC, KO>(a, kn, stream, &grid);
     KSR_FEED_CONFIGS(KSR_X)
 #undef KSR_X
-    return KSR_ERR_UNSUPPORTED;
+    if (rc != KSR_OK || !lnf_xhat) return rc;
+    return ksr_ln_reduce(lnf_slab, grid, lnf_grad, nullptr, nullptr, lnf_row_stride, stream);
 }
 
 extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, const float* x_img,
@@ -580,6 +639,19 @@ extern "C" int ksr_feed_kan_bwd(const float* gout, int64_t gout_batch_stride, co
                                 int n_knots, int spline_order, hipStream_t stream) {
     return feed_kan_bwd_impl(gout, gout_batch_stride, x_img, img_batch_stride, feed_w, 0, save_us, gfeat, 64, 0, gparam, B, H, W,
                              upscale, n_coef, knots, n_knots, spline_order, stream);
+}
+
+// ksr_feed_kan_bwd with the backward of the LayerNorm that produced feat (the encoder's final norm, gazetr.py:113) inside
+// (bf16 storage mode): gfeat receives the gradient of that LayerNorm's INPUT, ln_grad its gain gradient at [c] and its shift
+// gradient at [ln_row_stride + c].  xhat [N,64], rstd [N]: saved by the forward; ln_slab: 768 * 128 floats.
+extern "C" int ksr_feed_kan_bwd_lnf(const float* gout, int64_t gout_batch_stride, const float* x_img, int64_t img_batch_stride,
+                                    const float* feed_w, const float* save_us, float* gfeat, float* gparam, int B, int H, int W,
+                                    int upscale, int n_coef, const float* knots, int n_knots, int spline_order, const float* xhat,
+                                    const float* rstd, const float* ln_w, float* ln_slab, float* ln_grad, int ln_row_stride,
+                                    hipStream_t stream) {
+    KSR_CHECK_ARG(xhat != nullptr, "feed_kan_bwd_lnf: null xhat");
+    return feed_kan_bwd_impl(gout, gout_batch_stride, x_img, img_batch_stride, feed_w, 0, save_us, gfeat, 64, 0, gparam, B, H, W,
+                             upscale, n_coef, knots, n_knots, spline_order, stream, xhat, rstd, ln_w, ln_slab, ln_grad, ln_row_stride);
 }
 
 // Backward of ksr_feed_kan_fwd_img: per-image weights; the feature gradient goes to channels gfeat_c0 .. + 63 of rows of

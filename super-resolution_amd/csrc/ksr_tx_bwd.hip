@@ -47,6 +47,20 @@ __device__ __forceinline__ void ln_bwd(const float (&dy)[32], const float* __res
     for (int i = 0; i < 32; ++i) dx[i] = rstd * (dxh[i] - m1 - xhat[i] * m2);
 }
 
+// the same in place: g (gradient of the LayerNorm's output) becomes the gradient of its input
+__device__ __forceinline__ void ln_bwd_inplace(float (&g)[32], const float* __restrict__ gain, int h, const float (&xhat)[32], float rstd) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        g[i] *= gain[32 * h + i];
+        s1 += g[i];
+        s2 += g[i] * xhat[i];
+    }
+    const float m1 = ksr_pair_sum(s1) * (1.f / 64.f), m2 = ksr_pair_sum(s2) * (1.f / 64.f);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) g[i] = rstd * (g[i] - m1 - xhat[i] * m2);
+}
+
 template <int PREC>
 __global__ void __launch_bounds__(256, 2) tx_bwd_token_kernel(TxBwdTokArgs a) {
     KSR_MIX_SEED(a);
@@ -276,6 +290,162 @@ __global__ void __launch_bounds__(256, 2) tx_bwd_out_wg_kernel(TxBwdOutArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16 storage: the token backward in two kernels that each accumulate one of the MLP's weight gradients, so that the tensors
+// which only fed those products are read where they are made:
+//   tx_bwd_mlp_wg_kernel : LayerNorm 2 <- linear2 <- ReLU / dropout: writes du2 (the residual branch's
+//                          gradient) and dpre, accumulates dW2 = dm^T hmid, db2 (dm = du2 under linear2's dropout mask is
+//                          never written);
+//   tx_bwd_ln1_wg_kernel : ds1 = du2 + dpre W1, LayerNorm 1 backward: writes du1, accumulates dW1 = dpre^T xhat1, db1.
+// Against tx_bwd_token_kernel + two ksr_wgrad launches: 200 bytes per token and layer less (dm and dpre are not re-read,
+// hmid and xhat1 are read once), and each kernel holds 32 accumulator registers where the one-kernel form would have
+// needed 64 beside its 215 (it spilled in every arrangement).
+struct TxBwdMlpArgs {
+    const void* dy;
+    const void* xhat2; const float *rstd2, *n2_w;
+    const void* hmid;                                   // [N,32]
+    const float* l2_w;                                  // [64,32]
+    void *du2, *dpre;                                   // [N,64], [N,32]
+    float* ln_slab;                                     // [gridDim.x][2][64]: norm2
+    float* wg_slab;                                     // [gridDim.x][64*32 + 64]
+    long N; float p_drop; unsigned long long seed; const unsigned long long* seed_dev;
+};
+struct __attribute__((aligned(16))) TxBwdMlpSmem {
+    float f_l2t[1 * 32 * 64 / 2];
+    float ln[64];
+    float xpose[4 * KSR_XPOSE_FLOATS];
+};
+
+__global__ void __launch_bounds__(256, 2) tx_bwd_mlp_wg_kernel(TxBwdMlpArgs a) {
+    // (A variant with the encoder's final LayerNorm backward in front spilled 61 registers in every arrangement - 0.36 ms per
+    // launch against 0.125: that backward runs inside the feed + KAN backward instead, ksr_feed_kan_bwd_lnf.)
+    KSR_MIX_SEED(a);
+    using ST = __bf16;
+    constexpr int PREC = KSR_BF16S;
+    __shared__ TxBwdMlpSmem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<PREC, 32, 1, true>(sm.f_l2t, nullptr, a.l2_w, 32, nullptr, MapSplit{16}, MapHL{32}, tid, 256);
+    if (tid < 64) sm.ln[tid] = a.n2_w[tid];
+    __syncthreads();
+    const float keep = 1.f - a.p_drop, inv_keep = 1.f / keep;
+    const bool drop = a.p_drop > 0.f;
+    const long ntiles = (a.N + 127) / 128;
+    float cs0 = 0.f, cs1 = 0.f;
+    KsrWgFusedT<2, 1> wgf;
+    ksr_wgft_init(wgf);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n0 = tile * 128 + wv * 32 + tok;
+        const long n = n0 < a.N ? n0 : 0;
+        const long n0w = tile * 128 + wv * 32;
+        const int nvalid = (a.N - n0w) < 32 ? (int)(a.N - n0w > 0 ? a.N - n0w : 0) : 32;
+        float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+        KsrTile<ST> t_dy, t_x2;
+        KsrTile16<ST> t_hm;
+        ksr_co_fetch<ST>(a.dy, n0w, nvalid, 64, 0, lane, t_dy);
+        ksr_co_fetch<ST>(a.xhat2, n0w, nvalid, 64, 0, lane, t_x2);
+        const float rs_2 = a.rstd2[n];
+        float g[32], xh[32];
+        ksr_co_finish<ST>(xb, lane, t_dy, g);
+        ksr_co16_fetch<ST>(a.hmid, n0w, nvalid, lane, t_hm);
+        ksr_co_finish<ST>(xb, lane, t_x2, xh);
+        ksr_colsum32(xb, lane, g, xh, cs0, cs1);
+        ln_bwd_inplace(g, sm.ln, h, xh, rs_2);                     // g = du2
+        ksr_store32_co<ST>(xb, a.du2, n0w, nvalid, 64, 0, lane, g);
+        float dm[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i)
+            dm[i] = drop ? (ksr_keep(a.seed, 3u, (unsigned long long)n * 64 + 32 * h, i, keep) ? g[i] * inv_keep : 0.f) : g[i];
+        float hm[16], dpre[16];
+        ksr_co16_finish<ST>(xb, lane, t_hm, hm);
+        {
+            f32x16 acc[1];
+            ksr_wave_gemm<PREC, 32, 1>(sm.f_l2t, nullptr, dm, acc, lane);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dpre[i] = hm[i] > 0.f ? (drop ? acc[0][i] * inv_keep : acc[0][i]) : 0.f;
+        }
+        ksr_store16_co<ST>(xb, a.dpre, n0w, nvalid, lane, dpre);
+        ksr_wgft_accumulate<2, 1>(xb, lane, dm, hm, wgf);      // rows past the end of the tensor hold zeros in dm
+    }
+    {
+        // LayerNorm gain / shift sums: the four waves' sums meet in LDS (each wave's own transposer first)
+        float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+        ksr_wave_fence();
+        xb[lane] = cs0; xb[64 + lane] = cs1;
+        __syncthreads();
+        for (int i = tid; i < 128; i += 256)
+            a.ln_slab[(long)blockIdx.x * 128 + i] =
+                (sm.xpose[i] + sm.xpose[KSR_XPOSE_FLOATS + i]) + (sm.xpose[2 * KSR_XPOSE_FLOATS + i] + sm.xpose[3 * KSR_XPOSE_FLOATS + i]);
+    }
+    ksr_wgft_finish<2, 1>(sm.xpose, a.wg_slab + (long)blockIdx.x * (64 * 32 + 64), tid, wgf);
+}
+
+struct TxBwdLn1Args {
+    const void *du2, *dpre, *xhat1; const float *rstd1, *n1_w;
+    const float* l1_w;                                  // [32,64]
+    void* du1;
+    float* ln_slab;                                     // [gridDim.x][2][64]: norm1
+    float* wg_slab;                                     // [gridDim.x][32*64 + 32]
+    long N;
+};
+struct __attribute__((aligned(16))) TxBwdLn1Smem {
+    float f_l1t[2 * 16 * 64 / 2];
+    float ln[64];
+    float xpose[4 * KSR_XPOSE_FLOATS];
+};
+
+__global__ void __launch_bounds__(256, 2) tx_bwd_ln1_wg_kernel(TxBwdLn1Args a) {
+    using ST = __bf16;
+    constexpr int PREC = KSR_BF16S;
+    __shared__ TxBwdLn1Smem sm;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<PREC, 16, 2, true>(sm.f_l1t, nullptr, a.l1_w, 64, nullptr, MapHL{32}, MapSplit{16}, tid, 256);
+    if (tid < 64) sm.ln[tid] = a.n1_w[tid];
+    __syncthreads();
+    const long ntiles = (a.N + 127) / 128;
+    float cs0 = 0.f, cs1 = 0.f;
+    KsrWgFusedT<1, 2> wgf;
+    ksr_wgft_init(wgf);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n0 = tile * 128 + wv * 32 + tok;
+        const long n = n0 < a.N ? n0 : 0;
+        const long n0w = tile * 128 + wv * 32;
+        const int nvalid = (a.N - n0w) < 32 ? (int)(a.N - n0w > 0 ? a.N - n0w : 0) : 32;
+        float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+        KsrTile<ST> t_du, t_x1;
+        KsrTile16<ST> t_dp;
+        ksr_co_fetch<ST>(a.du2, n0w, nvalid, 64, 0, lane, t_du);
+        ksr_co16_fetch<ST>(a.dpre, n0w, nvalid, lane, t_dp);
+        ksr_co_fetch<ST>(a.xhat1, n0w, nvalid, 64, 0, lane, t_x1);
+        const float rs_1 = a.rstd1[n];
+        float du2[32], dpre[16], xh[32];
+        ksr_co_finish<ST>(xb, lane, t_du, du2);
+        ksr_co16_finish<ST>(xb, lane, t_dp, dpre);
+        float ds1[32];
+        {
+            f32x16 acc[2];
+            ksr_wave_gemm<PREC, 16, 2>(sm.f_l1t, nullptr, dpre, acc, lane);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ds1[i] = du2[i] + acc[0][i]; ds1[16 + i] = du2[16 + i] + acc[1][i]; }
+        }
+        ksr_co_finish<ST>(xb, lane, t_x1, xh);
+        ksr_wgft_accumulate<1, 2>(xb, lane, dpre, xh, wgf);     // rows past the end of the tensor hold zeros in dpre
+        ksr_colsum32(xb, lane, ds1, xh, cs0, cs1);
+        ln_bwd_inplace(ds1, sm.ln, h, xh, rs_1);                   // ds1 = du1
+        ksr_store32_co<ST>(xb, a.du1, n0w, nvalid, 64, 0, lane, ds1);
+    }
+    {
+        float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+        ksr_wave_fence();
+        xb[lane] = cs0; xb[64 + lane] = cs1;
+        __syncthreads();
+        for (int i = tid; i < 2 * 64; i += 256)
+            a.ln_slab[(long)blockIdx.x * 128 + i] = (sm.xpose[i] + sm.xpose[KSR_XPOSE_FLOATS + i]) + (sm.xpose[2 * KSR_XPOSE_FLOATS + i] + sm.xpose[3 * KSR_XPOSE_FLOATS + i]);
+    }
+    ksr_wgft_finish<1, 2>(sm.xpose, a.wg_slab + (long)blockIdx.x * (32 * 64 + 32), tid, wgf);
+}
+
+// ---------------------------------------------------------------------------------------------
 struct TxBwdAttnArgs {
     const float* qkv;    // [N,192] saved by the forward (q not scaled)
     const float* ctx;    // [N,64]
@@ -479,6 +649,56 @@ extern "C" int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, c
     else hipLaunchKernelGGL(tx_bwd_attn_kernel<float>, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_attn");
     return KSR_OK;
+}
+
+int ksr_ln_reduce(const float* slab, int G, float* out0, float* out1, float* out2, int row_stride, hipStream_t stream) {
+    LnRedArgs r{slab, G, {out0, out1, out2}, row_stride};
+    const int n = out2 ? 3 : (out1 ? 2 : 1);
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3(n, 4), dim3(1024), 0, stream, r);
+    KSR_LAUNCH_CHECK("ln_reduce");
+    return KSR_OK;
+}
+
+// bf16 storage: the first half of the token backward with linear2's weight gradient inside (see tx_bwd_mlp_wg_kernel).
+// dy [N,64]: gradient of the layer's output; xhat2 [N,64], rstd2 [N], hmid [N,32]: saved by the forward.  Outputs du2 [N,64],
+// dpre [N,32]; ln_grad: norm2's gain gradient at [c], shift gradient at [ln_row_stride + c]; dW2 [64,32], db2 [64].
+// ln_slab: 768 * 128 floats, wg_slab: ksr_tx_bwd_wg_slab_floats() floats.
+extern "C" int ksr_batch_tx_layer_bwd_mlp_wg(const float* dy, const float* xhat2, const float* rstd2, const float* hmid,
+                                             const float* n2_w, const float* l2_w, float* du2, float* dpre, int64_t N,
+                                             float p_drop, uint64_t seed, float* ln_slab, float* ln_grad, int ln_row_stride,
+                                             float* wg_slab, float* dW2, float* db2, hipStream_t stream) {
+    KSR_CHECK_ARG(dy && xhat2 && rstd2 && hmid && n2_w && l2_w && du2 && dpre && ln_slab && ln_grad && wg_slab && dW2 && db2 &&
+                  N > 0 && ln_row_stride >= 64, "batch_tx_layer_bwd_mlp_wg: bad argument");
+    KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "batch_tx_layer_bwd_mlp_wg: bf16 storage mode only");
+    TxBwdMlpArgs a{dy, xhat2, rstd2, n2_w, hmid, l2_w, du2, dpre, ln_slab, wg_slab, (long)N, p_drop, seed, ksr_seed_dev()};
+    const long ntiles = (N + 127) / 128;
+    const unsigned grid = ksr_persistent_grid(tx_bwd_mlp_wg_kernel, ntiles, KSR_WGF_MAX_GRID);
+    hipLaunchKernelGGL(tx_bwd_mlp_wg_kernel, dim3(grid), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("batch_tx_layer_bwd_mlp_wg");
+    const int rc = ksr_ln_reduce(ln_slab, (int)grid, ln_grad, nullptr, nullptr, ln_row_stride, stream);
+    if (rc != KSR_OK) return rc;
+    return ksr_slab_reduce(wg_slab, (int)grid, 64, 32, dW2, db2, stream);
+}
+
+// ... and the second half with linear1's weight gradient inside (tx_bwd_ln1_wg_kernel): du1 [N,64] from du2, dpre, xhat1,
+// rstd1; ln_grad: norm1's pair; dW1 [32,64] is the product with xhat1 (the caller maps it through norm1's gain / shift:
+// ksr_wgrad_affine_input), db1 [32].  ln_slab: 768 * 128 floats.
+extern "C" int ksr_batch_tx_layer_bwd_ln1_wg(const float* du2, const float* dpre, const float* xhat1, const float* rstd1,
+                                             const float* n1_w, const float* l1_w, float* du1, int64_t N, float* ln_slab,
+                                             float* ln_grad, int ln_row_stride, float* wg_slab, float* dW1, float* db1,
+                                             hipStream_t stream) {
+    KSR_CHECK_ARG(du2 && dpre && xhat1 && rstd1 && n1_w && l1_w && du1 && ln_slab && ln_grad && wg_slab && dW1 && db1 && N > 0 && ln_row_stride >= 64,
+                  "batch_tx_layer_bwd_ln1_wg: bad argument");
+    KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "batch_tx_layer_bwd_ln1_wg: bf16 storage mode only");
+    TxBwdLn1Args a{du2, dpre, xhat1, rstd1, n1_w, l1_w, du1, ln_slab, wg_slab, (long)N};
+    const long ntiles = (N + 127) / 128;
+    const unsigned grid = ksr_persistent_grid(tx_bwd_ln1_wg_kernel, ntiles, KSR_WGF_MAX_GRID);
+    hipLaunchKernelGGL(tx_bwd_ln1_wg_kernel, dim3(grid), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("batch_tx_layer_bwd_ln1_wg");
+    LnRedArgs r{ln_slab, (int)grid, {ln_grad, nullptr, nullptr}, ln_row_stride};
+    hipLaunchKernelGGL(ln_reduce_kernel, dim3(1, 4), dim3(1024), 0, stream, r);
+    KSR_LAUNCH_CHECK("batch_tx_layer_bwd_ln1_wg(ln reduce)");
+    return ksr_slab_reduce(wg_slab, (int)grid, 32, 64, dW1, db1, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

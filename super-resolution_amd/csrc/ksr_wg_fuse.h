@@ -109,4 +109,106 @@ __device__ __forceinline__ void ksr_wgf_finish(float* __restrict__ area, float* 
     for (int i = tid; i < KSR_WGF_ROW; i += 256) slab_row[i] = area[i];
 }
 
+// The same scheme for products with a 32-channel operand (the transformer's linear1: 32 x 64, linear2: 64 x 32): JB / KB =
+// number of 32-channel blocks of dz (rows of dW) / of av (columns).  A 32-channel tensor sits in the half layout of its own:
+// lane half h holds channels 16 h .. 16 h + 15 of token lane & 31 (16 values per lane), and fills chunks 0..3 of its tile rows.
+template <int JB, int KB>
+struct KsrWgFusedT {
+    f32x16 acc[JB][KB];     // rows j = 32 jb + (q&3) + 8 (q>>2) + 4 (lane>>5), column k = 32 kb + (lane&31)
+    float bsum;             // lane c < 32 JB: sum over tokens of dz[tok][c]
+};
+
+template <int JB, int KB>
+__device__ __forceinline__ void ksr_wgft_init(KsrWgFusedT<JB, KB>& w) {
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) w.acc[jb][kb][q] = 0.f;
+    w.bsum = 0.f;
+}
+
+// one operand (NB blocks of 32 channels, 16 NB values per lane) -> the wave's bf16 tile
+template <int NB>
+__device__ __forceinline__ void ksr_wgft_put(__bf16* __restrict__ tile, int lane, const float (&v)[16 * NB]) {
+    const int tok = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 2 * NB; ++q) *reinterpret_cast<uint4*>(tile + ksr_wgf_off(tok, 2 * NB * h + q)) = ksr_pack8(v + 8 * q);
+}
+
+template <int JB, int KB>
+__device__ __forceinline__ void ksr_wgft_accumulate(float* __restrict__ xb, int lane, const float (&dz)[16 * JB],
+                                                    const float (&av)[16 * KB], KsrWgFusedT<JB, KB>& w) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    __bf16* tz = reinterpret_cast<__bf16*>(xb);
+    __bf16* ta = tz + 32 * 64;
+    ksr_wave_fence();
+    ksr_wgft_put<JB>(tz, lane, dz);
+    ksr_wgft_put<KB>(ta, lane, av);
+    ksr_wave_fence();
+    const int g = lane >> 5, db = (lane >> 4) & 1, qq = (lane & 15) >> 2, p = lane & 3;
+    auto tr = [&](const __bf16* tile, int row, int chunk) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(tile + ksr_wgf_off(row, chunk) + 4 * (p & 1)));
+    };
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int r0 = 16 * s + 4 * g + qq;
+        union { s16x4 hv[2]; bf16x8 v; } A[JB], Bv[KB];
+#pragma unroll
+        for (int blk = 0; blk < JB; ++blk) {
+            const int chunk = 4 * blk + 2 * db + (p >> 1);
+            A[blk].hv[0] = tr(tz, r0, chunk); A[blk].hv[1] = tr(tz, r0 + 8, chunk);
+        }
+#pragma unroll
+        for (int blk = 0; blk < KB; ++blk) {
+            const int chunk = 4 * blk + 2 * db + (p >> 1);
+            Bv[blk].hv[0] = tr(ta, r0, chunk); Bv[blk].hv[1] = tr(ta, r0 + 8, chunk);
+        }
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+                w.acc[jb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[jb].v, Bv[kb].v, w.acc[jb][kb], 0, 0, 0);
+    }
+    // bias gradient: lane c adds up column c of the dz tile (the values the products saw)
+    if (lane < 32 * JB) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; r += 2) {
+            s0 += (float)tz[ksr_wgf_off(r, lane >> 3) + (lane & 7)];
+            s1 += (float)tz[ksr_wgf_off(r + 1, lane >> 3) + (lane & 7)];
+        }
+        w.bsum += s0 + s1;
+    }
+    ksr_wave_fence();
+}
+
+// Called by all 256 threads after the tile loop.  area: (32 JB) * (32 KB) + 32 JB floats of LDS that every wave may
+// overwrite now; slab_row receives dW [32 JB][32 KB] | db [32 JB].
+template <int JB, int KB>
+__device__ __forceinline__ void ksr_wgft_finish(float* __restrict__ area, float* __restrict__ slab_row, int tid,
+                                                const KsrWgFusedT<JB, KB>& w) {
+    constexpr int J = 32 * JB, K = 32 * KB;
+    const int lane = tid & 63, wv = tid >> 6, col = lane & 31, g = lane >> 5;
+    for (int turn = 0; turn < 4; ++turn) {
+        __syncthreads();
+        if (wv == turn) {
+#pragma unroll
+            for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+                for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int idx = (32 * jb + (q & 3) + 8 * (q >> 2) + 4 * g) * K + 32 * kb + col;
+                        area[idx] = (turn == 0 ? 0.f : area[idx]) + w.acc[jb][kb][q];
+                    }
+            if (lane < J) area[J * K + lane] = (turn == 0 ? 0.f : area[J * K + lane]) + w.bsum;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < J * K + J; i += 256) slab_row[i] = area[i];
+}
+
 #endif

@@ -36,7 +36,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad", "_finalize", "_mix", "_merge", "_dgrad", "_batch", "_wg", "_v", "_l1", "_input", "_img", "_kan", "_flush", "_groups")):
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad", "_finalize", "_mix", "_merge", "_dgrad", "_batch", "_wg", "_v", "_l1", "_input", "_img", "_kan", "_flush", "_groups", "_lnf")):
             return fn
 
         def timed(*args):
@@ -87,6 +87,7 @@ def _declare(L: ctypes.CDLL) -> None:
 EXPORTS = [
     "ksr_version", "ksr_last_error", "ksr_set_precision", "ksr_get_precision",
     "ksr_reduce_defer", "ksr_reduce_flush", "ksr_reduce_pending", "ksr_dwconv_wgrad_groups",
+    "ksr_batch_tx_layer_bwd_mlp_wg", "ksr_batch_tx_layer_bwd_ln1_wg", "ksr_feed_kan_bwd_lnf",
     "ksr_sm_conv_fwd", "ksr_sm_layernorm_fwd", "ksr_sm_resize_add_fwd", "ksr_sm_route_fwd", "ksr_sm_experts_fwd",
     "ksr_kan_cell_fwd", "ksr_kan_cell_bwd", "ksr_bilinear_up",
     "ksr_stem_fwd", "ksr_stem_gate_fwd", "ksr_pointwise_fwd", "ksr_dwrelu_pw_fwd", "ksr_gate_pw_fwd",

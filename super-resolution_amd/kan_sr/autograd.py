@@ -37,6 +37,9 @@ SIDE_STREAM_MIN_TOKENS = 1 << 19          # LR pixels per backward pass from whi
 # pixels the immediate reduction reads its slab while it is still in the caches and the deferred one re-reads all slabs
 # (170 MB) from memory (64 patches: 4.48 -> 4.65 ms), so it is used below DEFER_BELOW_TOKENS pixels per pass.
 # KSR_DEFER_REDUCTIONS=0 / 1 forces it off / on.
+# bf16 storage: the per-token backward of a transformer layer as two kernels that accumulate linear2's / linear1's weight
+# gradients themselves (ksr_batch_tx_layer_bwd_mlp_wg, ..._ln1_wg) instead of one kernel + two ksr_wgrad launches
+SPLIT_TOKEN_BACKWARD = os.environ.get("KSR_SPLIT_TOKEN_BWD", "1") != "0"
 DEFER_REDUCTIONS = os.environ.get("KSR_DEFER_REDUCTIONS", "auto")
 DEFER_BELOW_TOKENS = 1 << 19
 
@@ -205,9 +208,11 @@ def _dwconv_wgrad(ws: _Ws, inp, in_ld, in_c0, ds, g: Geometry, name_w, name_b):
     return dW, db
 
 
-def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, seed, grads, y_in_sigmoid):
-    """Backward of transformer layer li.  dy: gradient of its output [N,64].  Returns the gradient of
-    its input (times sigmoid' of that input when y_in_sigmoid is given)."""
+def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, seed, grads, y_in_sigmoid,
+                       final_norm_done: bool = False):
+    """Backward of transformer layer li.  dy: gradient of its output [N,64] - for the last layer, of the final norm's
+    output, or with final_norm_done of the final norm's input.  Returns the gradient of its input (times sigmoid' of
+    that input when y_in_sigmoid is given)."""
     L = lib()
     N = g.N
     q = f"{pre}encoder.layers.{li}."
@@ -217,6 +222,9 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
               p[q + "self_attn.out_proj.weight"]]
     saved = [sv["xhatf"], sv["rstdf"], sv["xhat2"], sv["rstd2"], sv["hmid"], sv["xhat1"], sv["rstd1"]]
     fused = ws.fused_wgrad()
+    assert not final_norm_done or (fused and SPLIT_TOKEN_BACKWARD and last)
+    if fused and SPLIT_TOKEN_BACKWARD and (not last or final_norm_done):
+        return _tx_layer_backward_split(ws, dy, li, p, pre, g, sv, p_drop, seed, grads, y_in_sigmoid)
     dm, dpre, du1, dctx = ws.act(N, 64), ws.act(N, 32), ws.act(N, 64), ws.act(N, 64)
     # bf16 storage: the token kernel stops at du1; the out-projection's backward (with out_proj's weight gradient) follows
     da = ws.act(N, 64) if (p_drop > 0 and not fused) else None
@@ -282,6 +290,56 @@ def _tx_layer_backward(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, se
     _wgrad(ws, dqkv, 192, 0, 192, sv["in"], 64, 0, 64, N, gw, gb)
     check(L.ksr_in_proj_bwd(ptr(dqkv), ptr(p[q + "self_attn.in_proj_weight"]), ptr(du1), ptr(y_in_sigmoid), ptr(dsin),
                             *_dims(g), stream()), "ksr_in_proj_bwd")
+    return dsin
+
+
+def _tx_layer_backward_split(ws: _Ws, dy, li: int, p, pre, g: Geometry, sv, p_drop, seed, grads, y_in_sigmoid):
+    """bf16 storage: the layer's backward with every weight gradient accumulated by the kernel that holds its operands:
+    norm2 + linear2 (ksr_batch_tx_layer_bwd_mlp_wg), linear1 + norm1 (..._ln1_wg), out-projection (..._out_wg),
+    attention, in-projection (ksr_in_proj_bwd_wg).  No ksr_wgrad launch, and dm is never written.  dy is the gradient of
+    the layer's own output (for the last layer the final norm's backward has run already)."""
+    L = lib()
+    N = g.N
+    q = f"{pre}encoder.layers.{li}."
+    lseed = (seed * 4 + li) & 0xFFFFFFFFFFFFFFFF
+    gn2 = ws.grad_pair(q + "norm2.weight", q + "norm2.bias", 64)
+    gn1 = ws.grad_pair(q + "norm1.weight", q + "norm1.bias", 64)
+    du2, dpre, du1, dctx = ws.act(N, 64), ws.act(N, 32), ws.act(N, 64), ws.act(N, 64)
+    gw2, gb2 = ws.grad(q + "linear2.weight", 64, 32), ws.grad(q + "linear2.bias", 64)
+    check(L.ksr_batch_tx_layer_bwd_mlp_wg(ptr(dy), ptr(sv["xhat2"]), ptr(sv["rstd2"]), ptr(sv["hmid"]), ptr(p[q + "norm2.weight"]),
+                                          ptr(p[q + "linear2.weight"]), ptr(du2), ptr(dpre), c_int64(N), c_float(p_drop),
+                                          c_uint64(lseed), ptr(ws.ln_slab()), ptr(gn2), c_int(64), ptr(ws.fused_slab()),
+                                          ptr(gw2), ptr(gb2), stream()), "ksr_batch_tx_layer_bwd_mlp_wg")
+    grads[q + "linear2.weight"], grads[q + "linear2.bias"] = gw2, gb2
+    grads[q + "norm2.weight"], grads[q + "norm2.bias"] = gn2[0], gn2[1]
+    gw1, gb1 = ws.grad(q + "linear1.weight", 32, 64), ws.grad(q + "linear1.bias", 32)
+    check(L.ksr_batch_tx_layer_bwd_ln1_wg(ptr(du2), ptr(dpre), ptr(sv["xhat1"]), ptr(sv["rstd1"]), ptr(p[q + "norm1.weight"]),
+                                          ptr(p[q + "linear1.weight"]), ptr(du1), c_int64(N), ptr(ws.ln_slab()), ptr(gn1), c_int(64),
+                                          ptr(ws.fused_slab()), ptr(gw1), ptr(gb1), stream()), "ksr_batch_tx_layer_bwd_ln1_wg")
+    grads[q + "norm1.weight"], grads[q + "norm1.bias"] = gn1[0], gn1[1]
+
+    # the forward did not keep LayerNorm 1's output s1 = xhat1 * gain + shift: the product was taken with xhat1
+    def fold(gw=gw1, gb=gb1, n1w=p[q + "norm1.weight"], n1b=p[q + "norm1.bias"]):
+        check(L.ksr_wgrad_affine_input(ptr(gw), ptr(gb), ptr(n1w), ptr(n1b), c_int(32), c_int(64), stream()),
+              "ksr_wgrad_affine_input")
+    ws.after_reduction(fold)
+    grads[q + "linear1.weight"], grads[q + "linear1.bias"] = gw1, gb1
+    gw, gb = ws.grad(q + "self_attn.out_proj.weight", 64, 64), ws.grad(q + "self_attn.out_proj.bias", 64)
+    check(L.ksr_batch_tx_layer_bwd_out_wg(ptr(du1), ptr(sv["ctx"]), ptr(p[q + "self_attn.out_proj.weight"]), ptr(dctx),
+                                          c_int64(N), c_float(p_drop), c_uint64(lseed), ptr(ws.fused_slab()), ptr(gw), ptr(gb),
+                                          stream()), "ksr_batch_tx_layer_bwd_out_wg")
+    grads[q + "self_attn.out_proj.weight"], grads[q + "self_attn.out_proj.bias"] = gw, gb
+    dqkv = ws.act(N, 192)
+    attn_bwd = L.ksr_batch_attn_bwd if engine.split_attention(g.B) else L.ksr_batch_tx_layer_bwd_attn
+    check(attn_bwd(ptr(sv["qkv"]), ptr(sv["ctx"]), ptr(dctx), ptr(dqkv), c_int(g.B), c_int(g.H * g.W), c_float(p_drop),
+                   c_uint64(lseed), stream()), "attention backward")
+    gw, gb = ws.grad(q + "self_attn.in_proj_weight", 192, 64), ws.grad(q + "self_attn.in_proj_bias", 192)
+    grads[q + "self_attn.in_proj_weight"], grads[q + "self_attn.in_proj_bias"] = gw, gb
+    dsin = ws.act(N, 64)
+    assert y_in_sigmoid is None or y_in_sigmoid.data_ptr() == sv["in"].data_ptr()
+    check(L.ksr_in_proj_bwd_wg(ptr(dqkv), ptr(p[q + "self_attn.in_proj_weight"]), ptr(du1), ptr(sv["in"]),
+                               c_int(0 if y_in_sigmoid is None else 1), ptr(dsin), ptr(ws.fused_slab()), ptr(gw), ptr(gb),
+                               c_int64(N), stream()), "ksr_in_proj_bwd_wg")
     return dsin
 
 
@@ -417,15 +475,27 @@ def backward_all(gout: torch.Tensor, gout_batch_stride: int, x: torch.Tensor, p:
         lane_len = int(L.ksr_feed_kan_lane_len(c_int(g.r), c_int(g.n_coef)))
         gfeat = ws.act(N, 64)
         gparam = ws.act(N, 2 * lane_len)
-        check(L.ksr_feed_kan_bwd(ptr(gout), c_int64(gout_batch_stride), ptr(x),
-                                 c_int64(3 * g.H * g.W), ptr(p[pre + "feed.weight"]), ptr(save_us), ptr(gfeat), ptr(gparam),
-                                 *_dims(g), c_int(g.r), c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k),
-                                 stream()), "ksr_feed_kan_bwd")
+        # bf16 storage: the final norm's backward runs inside the feed + KAN backward (gfeat = gradient of the norm's INPUT)
+        final_norm_done = ws.fused_wgrad() and SPLIT_TOKEN_BACKWARD
+        if final_norm_done:
+            tx1 = sv["tx1"]
+            gnf = ws.grad_pair(pre + "encoder.norm.weight", pre + "encoder.norm.bias", 64)
+            check(L.ksr_feed_kan_bwd_lnf(ptr(gout), c_int64(gout_batch_stride), ptr(x), c_int64(3 * g.H * g.W),
+                                         ptr(p[pre + "feed.weight"]), ptr(save_us), ptr(gfeat), ptr(gparam), *_dims(g),
+                                         c_int(g.r), c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k),
+                                         ptr(tx1["xhatf"]), ptr(tx1["rstdf"]), ptr(p[pre + "encoder.norm.weight"]),
+                                         ptr(ws.ln_slab()), ptr(gnf), c_int(64), stream()), "ksr_feed_kan_bwd_lnf")
+            grads[pre + "encoder.norm.weight"], grads[pre + "encoder.norm.bias"] = gnf[0], gnf[1]
+        else:
+            check(L.ksr_feed_kan_bwd(ptr(gout), c_int64(gout_batch_stride), ptr(x),
+                                     c_int64(3 * g.H * g.W), ptr(p[pre + "feed.weight"]), ptr(save_us), ptr(gfeat), ptr(gparam),
+                                     *_dims(g), c_int(g.r), c_int(g.n_coef), g.knots_c, c_int(len(g.knots)), c_int(g.k),
+                                     stream()), "ksr_feed_kan_bwd")
         P = g.r * g.r * (g.n_coef + 2)
         gw, gb = ws.grad(pre + "feed.weight", P, 64, 1, 1), ws.grad(pre + "feed.bias", P)
         _wgrad(ws, gparam, 2 * lane_len, 0, 2 * lane_len, sv["feat"], 64, 0, 64, N, gw, gb, kan=(g.r, g.n_coef))
         grads[pre + "feed.weight"], grads[pre + "feed.bias"] = gw, gb
-        trunk_backward(ws, gfeat, x, p, pre, g, sv, p_drop, seed, grads, on_tail_done)
+        trunk_backward(ws, gfeat, x, p, pre, g, sv, p_drop, seed, grads, on_tail_done, final_norm_done)
         ws.close()                # joins the second stream and runs the recorded reductions
         if want_input_grad:
             grads["__input__"] = _input_gradient(ws, gout, gout_batch_stride, gout_chroma, x, p, pre, g, sv)
@@ -457,13 +527,15 @@ def _input_gradient(ws: _Ws, gout, gout_batch_stride, gout_full, x, p, pre, g: G
 
 
 def trunk_backward(ws: _Ws, gfeat: torch.Tensor, x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Geometry,
-                   sv: dict, p_drop: float, seed: int, grads: Dict[str, torch.Tensor], on_tail_done=None) -> None:
-    """Backward of engine.encoder_forward from gfeat [N,64] (gradient of the final-LayerNormed features):
+                   sv: dict, p_drop: float, seed: int, grads: Dict[str, torch.Tensor], on_tail_done=None,
+                   final_norm_done: bool = False) -> None:
+    """Backward of engine.encoder_forward from gfeat [N,64] (gradient of the final-LayerNormed features, or with
+    final_norm_done - the caller ran that norm's backward and filled its two gradients - of the norm's input):
     fills `grads` for every encoder parameter except `feed`."""
     L = lib()
     N = g.N
     # ---- transformer layers ----
-    d = _tx_layer_backward(ws, gfeat, 1, p, pre, g, sv["tx1"], p_drop, seed, grads, None)
+    d = _tx_layer_backward(ws, gfeat, 1, p, pre, g, sv["tx1"], p_drop, seed, grads, None, final_norm_done)
     dz6 = _tx_layer_backward(ws, d, 0, p, pre, g, sv["tx0"], p_drop, seed, grads, sv["x6"])
     if on_tail_done is not None:
         ws.flush()                # the first bucket's gradients include second-stream and recorded reductions
