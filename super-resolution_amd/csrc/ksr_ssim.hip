@@ -47,13 +47,19 @@ constexpr int SS_RUN = 8, SS_RUNS = SS_T / SS_RUN, SS_SPAN = SS_RUN + SS_K - 1; 
 // pixels are requested before the horizontal pass.  Against the tile version (32 x 32 windows from 42 x 42 pixels,
 // filter passes that keep 3 and 2 of 4 waves busy): no rows are filtered twice, 6 % of the columns are, every thread
 // works in both passes.
+// The kernel is bound by the vector ALUs' throughput, not by latency: with taps removed from one part at a time (64 x 3 x
+// 512 x 512, 266 us) the vertical filter accounts for 76 us, the horizontal one for 90, the evaluation of S for 47 and
+// loads / LDS / barriers for the rest, the parts adding up; a variant with three waves per SIMD instead of two (runs of 5
+// windows, 6-row sub-batches: 168 registers, 17 KB of LDS) ran in the same time.  About 5 cycles per vector instruction and
+// SIMD (two thirds of them packed) is what this chip sustains on such a stream.
 constexpr int SV_T = 128;                       // two waves: four workgroups give every SIMD of a CU its two waves (three-wave
-                                                // workgroups left two of the four SIMDs with one, and the kernel is bound by
-                                                // vector-instruction issue)
+                                                // workgroups left two of the four SIMDs with one)
 constexpr int SV_WO = SV_T - (SS_K - 1);        // window columns per strip at most
 constexpr int SV_R = SS_K;                      // input rows per batch
 constexpr int SV_RUN = 11, SV_SPAN = SV_RUN + SS_K - 1;
-constexpr int SV_V1_LD = SV_T + 16;             // pitch of the e12 rows: the 4 batch rows of a wave fall on different banks
+constexpr int SV_V1_LD = SV_T + 25;             // row pitch 153: the horizontal pass's reads (lane = batch row x run of 11 columns: 11 columns
+                                                // apart inside a row, six rows per wave) are free of bank conflicts for both the 16-byte and
+                                                // the 4-byte rows (144 made them three- and two-way; no measurable difference)
 static_assert(((SV_WO + SV_RUN - 1) / SV_RUN - 1) * SV_RUN + SV_SPAN <= SV_V1_LD, "the last run's columns stay inside a padded row");
 constexpr int SV_GRID = 256 * 4;                // persistent workgroups: four fit a CU (registers)
 
@@ -72,7 +78,9 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
     const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
     float sum = 0.f;
     for (int t = t_begin; t < t_end; ++t) {
-        const int strip = t % ns, band = (t / ns) % nb, c = (t / (ns * nb)) % a.C, b = t / (ns * nb * a.C);
+        // channel fastest: a workgroup's chunk of tasks holds the planes of one (strip, band, image) - the luma plane, which
+        // also writes the derivative maps, costs 1.4 x a chroma plane, and every workgroup is resident from the start
+        const int c = t % a.C, strip = (t / a.C) % ns, band = (t / (a.C * ns)) % nb, b = t / (a.C * ns * nb);
         const int x0 = strip * wo, y0 = band * bh;
         const int xo_end = min(Wi, x0 + wo), yo_end = min(Hi, y0 + bh);      // windows [y0, yo_end) x [x0, xo_end)
         const int y_in_end = yo_end + SS_K - 1;                                  // input rows [y0, y_in_end)
@@ -118,53 +126,75 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
             if (m + 1 < nbatch) fetch(m + 1);
             __syncthreads();
             // ---- horizontal: thread = (batch row rr, run j of 11 windows), j fastest
-            if (tid < SV_R * nruns) {
-                const int rr = tid / nruns, j = tid - rr * nruns, q0 = j * SV_RUN;
-                const int uy = y0 + SV_R * m + rr - (SS_K - 1);
-                if (uy >= y0 && uy < yo_end) {
-                    f32x2 ha[SV_RUN], hb[SV_RUN];
-                    float hc[SV_RUN];
+            const bool want_maps = a.maps && c == 0;        // uniform over the workgroup
+            const int hrr = tid / nruns, hj = tid - hrr * nruns, q0 = hj * SV_RUN;
+            const int uy = y0 + SV_R * m + hrr - (SS_K - 1);
+            const bool hrow = tid < SV_R * nruns && uy >= y0 && uy < yo_end;
+            float dmap[SV_RUN][3];
+            if (hrow) {
+                const int rr = hrr;
+                f32x2 ha[SV_RUN], hb[SV_RUN];
+                float hc[SV_RUN];
 #pragma unroll
-                    for (int o = 0; o < SV_RUN; ++o) { ha[o] = f32x2{0.f, 0.f}; hb[o] = f32x2{0.f, 0.f}; hc[o] = 0.f; }
+                for (int o = 0; o < SV_RUN; ++o) { ha[o] = f32x2{0.f, 0.f}; hb[o] = f32x2{0.f, 0.f}; hc[o] = 0.f; }
 #pragma unroll
-                    for (int i = 0; i < SV_SPAN; ++i) {
-                        // at most four columns' reads ahead of their use: hoisting all 21 costs 100 registers
-                        if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-                        const int q = q0 + i;        // < SV_T + 16; columns past the strip only feed windows past it
-                        const float4 v = v4[rr][q];
-                        const float vc = v1[rr][q];
-                        const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
-#pragma unroll
-                        for (int o = 0; o < SV_RUN; ++o) {
-                            if (i - o < 0 || i - o >= SS_K) continue;
-                            const float g = w.g[i - o < 6 ? i - o : 10 - (i - o)];
-                            ha[o] += g * va; hb[o] += g * vb; hc[o] += g * vc;
-                        }
-                    }
+                for (int i = 0; i < SV_SPAN; ++i) {
+                    // at most four columns' reads ahead of their use: hoisting all 21 costs 100 registers
+                    if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);
+                    const int q = q0 + i;        // < SV_V1_LD; columns past the strip only feed windows past it
+                    const float4 v = v4[rr][q];
+                    const float vc = v1[rr][q];
+                    const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
 #pragma unroll
                     for (int o = 0; o < SV_RUN; ++o) {
-                        const int ux = x0 + q0 + o;
-                        if (ux >= xo_end) continue;
-                        const float m1 = ha[o][0], m2 = ha[o][1], e11 = hb[o][0], e22 = hb[o][1], e12 = hc[o];
-                        const float vp_raw = e11 - m1 * m1, vt_raw = e22 - m2 * m2;
-                        const float vp = fmaxf(vp_raw, 0.f), vt = fmaxf(vt_raw, 0.f);
-                        const float cov = e12 - m1 * m2;
-                        const float N1 = 2.f * m1 * m2 + c1, D1 = m1 * m1 + m2 * m2 + c1;
-                        const float N2 = 2.f * cov + c2, D2 = vp + vt + c2;
-                        const float i1 = __builtin_amdgcn_rcpf(D1), i2 = __builtin_amdgcn_rcpf(D2);
-                        const float inv = i1 * i2;
-                        const float S = N1 * N2 * inv;
-                        sum += S;
-                        if (a.maps && c == 0) {
-                            const float vp_on = vp_raw > 0.f ? 1.f : 0.f;
-                            const float dC = 2.f * N1 * inv;
-                            const float dB = -S * i2 * vp_on;
-                            const float dA = 2.f * m2 * (N2 - N1) * inv - 2.f * m1 * S * (i1 - i2 * vp_on);
-                            const long mi = ((long)b * Hi + uy) * Wi + ux;
-                            const long ms = (long)a.B * Hi * Wi;
-                            a.maps[mi] = dA; a.maps[ms + mi] = dB; a.maps[2 * ms + mi] = dC;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);      // one window's temporaries at a time
+                        if (i - o < 0 || i - o >= SS_K) continue;
+                        const float g = w.g[i - o < 6 ? i - o : 10 - (i - o)];
+                        ha[o] += g * va; hb[o] += g * vb; hc[o] += g * vc;
+                    }
+                }
+#pragma unroll
+                for (int o = 0; o < SV_RUN; ++o) {
+                    const int ux = x0 + q0 + o;
+                    dmap[o][0] = dmap[o][1] = dmap[o][2] = 0.f;
+                    if (ux >= xo_end) continue;
+                    const float m1 = ha[o][0], m2 = ha[o][1], e11 = hb[o][0], e22 = hb[o][1], e12 = hc[o];
+                    const float vp_raw = e11 - m1 * m1, vt_raw = e22 - m2 * m2;
+                    const float vp = fmaxf(vp_raw, 0.f), vt = fmaxf(vt_raw, 0.f);
+                    const float cov = e12 - m1 * m2;
+                    const float N1 = 2.f * m1 * m2 + c1, D1 = m1 * m1 + m2 * m2 + c1;
+                    const float N2 = 2.f * cov + c2, D2 = vp + vt + c2;
+                    const float i1 = __builtin_amdgcn_rcpf(D1), i2 = __builtin_amdgcn_rcpf(D2);
+                    const float inv = i1 * i2;
+                    const float S = N1 * N2 * inv;
+                    sum += S;
+                    if (want_maps) {
+                        const float vp_on = vp_raw > 0.f ? 1.f : 0.f;
+                        dmap[o][2] = 2.f * N1 * inv;
+                        dmap[o][1] = -S * i2 * vp_on;
+                        dmap[o][0] = 2.f * m2 * (N2 - N1) * inv - 2.f * m1 * S * (i1 - i2 * vp_on);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);      // one window's temporaries at a time
+                }
+            }
+            if (want_maps) {
+                // The derivative maps leave through the (now free) column-sum rows: a thread's 11 windows are 11 columns
+                // of one row, so storing them directly puts 64 lanes on 64 separate 44-byte strides per instruction (that
+                // cost a third of the kernel's time); from LDS thread = column stores whole rows.
+                __syncthreads();           // every thread has read its columns of v4
+                if (hrow) {
+#pragma unroll
+                    for (int o = 0; o < SV_RUN; ++o) v4[hrr][q0 + o] = make_float4(dmap[o][0], dmap[o][1], dmap[o][2], 0.f);
+                }
+                __syncthreads();
+                const long ms = (long)a.B * Hi * Wi;
+                if (x0 + tid < xo_end) {
+#pragma unroll
+                    for (int rr = 0; rr < SV_R; ++rr) {
+                        const int vy = y0 + SV_R * m + rr - (SS_K - 1);
+                        if (vy < y0 || vy >= yo_end) continue;
+                        const float4 d = v4[rr][tid];
+                        float* mp = a.maps + ((long)b * Hi + vy) * Wi + x0;
+                        mp[tid] = d.x; (mp + ms)[tid] = d.y; (mp + 2 * ms)[tid] = d.z;
                     }
                 }
             }
@@ -374,10 +404,10 @@ extern "C" int ksr_ssim_fwd(const float* pred, int64_t pred_batch_stride, const 
     // (a band re-filters the 10 rows above it), at least 23 window rows (three batches of input rows) each
     const int ns = (Wi + SV_WO - 1) / SV_WO, wo = (Wi + ns - 1) / ns;
     int nb = 1;
-    while ((long)ns * nb * C * B < SV_GRID * 9 / 10 && Hi / (nb + 1) >= 2 * SS_K + 1) ++nb;
+    while ((long)ns * nb * B < SV_GRID * 9 / 10 && Hi / (nb + 1) >= 2 * SS_K + 1) ++nb;
     const int bh = (Hi + nb - 1) / nb;
     KSR_CHECK_ARG((long)ns * nb * C * B < (1L << 31), "ssim_fwd: too many strips for one launch");
-    const unsigned grid = (unsigned)std::min<long>((long)ns * nb * C * B, SV_GRID);
+    const unsigned grid = (unsigned)std::min<long>((long)ns * nb * B, SV_GRID);      // a workgroup takes all planes of its (strip, band, image)s
     hipLaunchKernelGGL(ssim_fwd_cols_kernel, dim3(grid), dim3(SV_T), 0, stream, a, w, ns, wo, nb, bh);
     KSR_LAUNCH_CHECK("ssim_fwd");
     hipLaunchKernelGGL(ssim_finish_kernel, dim3(1), dim3(1024), 0, stream, slab, (long)grid,

@@ -13,9 +13,11 @@ for dp, _, fs in os.walk(out):
     for f in fs:
         if f.endswith("kernel_stats.csv"):
             rows = list(csv.DictReader(open(os.path.join(dp, f))))
+            steps = 12        # 5 timed + 2 warm-up + the 5 of the per-entry-point pass
+            print(f"all kernels: {sum(float(r['TotalDurationNs']) for r in rows) / steps / 1e6:.3f} ms per step (if {steps} steps ran)")
             for r in rows:
                 name = re.sub(r"\(anonymous namespace\)::", "", r["Name"])
                 name = re.sub(r"\(.*", "", name).replace("void ", "")
                 if pat in name and float(r["Percentage"]) > 0.2:
-                    print(f"{name[:70]:70s} calls {int(r['Calls']):4d} avg {float(r['AverageNs'])/1e3:8.1f} us  {float(r['Percentage']):5.2f} %")
+                    print(f"{name[:70]:70s} calls {int(r['Calls']):4d} avg {float(r['AverageNs'])/1e3:8.1f} us  per step {float(r['TotalDurationNs'])/steps/1e3:7.1f} us  {float(r['Percentage']):5.2f} %")
 PY
