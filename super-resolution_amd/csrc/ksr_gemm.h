@@ -512,6 +512,60 @@ __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __r
     ksr_co16_from_lds<T, TWO_PATH, NT, FULLTILE>(xb, base, n0, nvalid, 32, 0, lane);
 }
 
+// Deferred form of ksr_store32_co: a tile's output is transposed right away but stays in registers (the store layout:
+// lane-linear 16-byte pieces) and is stored one loop iteration later, after the next tile's loads have been waited for.
+// The vector-memory counter completes in issue order, so a kernel that stores at the end of an iteration and waits for
+// its prefetched input at the top of the next one waits for those stores as well; stored an iteration late, both the
+// loads and the stores that a wait covers were issued a whole tile's arithmetic earlier.
+template <class T> struct KsrPend { ksr_f32x4_t v[8]; long n0; int nvalid; };       // native vectors: the struct must live in registers
+template <> struct KsrPend<__bf16> { ksr_u32x4_t v[4]; long n0; int nvalid; };
+
+template <class T>
+__device__ __forceinline__ void ksr_pend32_co(float* __restrict__ xb, long n0, int nvalid, int lane, const float (&x)[32],
+                                              KsrPend<T>& p) {
+    float* wp = xb + (lane & 31) * KSR_XPOSE_LD + 32 * (lane >> 5);
+    ksr_wave_fence();
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+    ksr_wave_fence();
+    if constexpr (sizeof(T) == 4) {
+        const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.v[i] = *reinterpret_cast<const ksr_f32x4_t*>(xb + (4 * i + r4) * KSR_XPOSE_LD + c4);
+    } else {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* sp = xb + (8 * i + r8) * KSR_XPOSE_LD + c8;
+            const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
+            const float xs[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            const uint4 u = ksr_pack8(xs);
+            p.v[i] = ksr_u32x4_t{u.x, u.y, u.z, u.w};
+        }
+    }
+    p.n0 = n0; p.nvalid = nvalid;
+    ksr_wave_fence();
+}
+template <class T>
+__device__ __forceinline__ void ksr_pend_store(void* __restrict__ base, int ld, int c0, int lane, KsrPend<T>& p) {
+    if constexpr (sizeof(T) == 4) {
+        const int r4 = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = 4 * i + r4;
+            if (row < p.nvalid) *reinterpret_cast<ksr_f32x4_t*>(reinterpret_cast<float*>(base) + (p.n0 + row) * ld + c0 + c4) = p.v[i];
+        }
+    } else {
+        const int r8 = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + r8;
+            if (row < p.nvalid) *reinterpret_cast<ksr_u32x4_t*>(reinterpret_cast<__bf16*>(base) + (p.n0 + row) * ld + c0 + c8) = p.v[i];
+        }
+    }
+    p.nvalid = 0;
+}
+
 // Sum of v over the two lanes that share a token (lanes l and l^32).
 __device__ __forceinline__ float ksr_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 

@@ -146,6 +146,10 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
         if (MODE == 1) ksr_co_fetch<ST, true>(a.ctx_in, r0, nv, 64, 0, lane, nx_ctx);
     };
     if (AHEAD && (int)blockIdx.x < ntiles) fetch_next(blockIdx.x);
+    // single-image mode: a tile's output is stored during the next tile (ksr_pend32_co)
+    constexpr bool DEFER = MODE == 2;
+    KsrPend<ST> pend;
+    pend.nvalid = 0; pend.n0 = 0;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // POST: no cross-token step is left, tiles are 128 consecutive rows of [S*HW, 64]
@@ -257,6 +261,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
 
         }
         if (AHEAD && tile + (int)gridDim.x < ntiles) fetch_next(tile + gridDim.x);
+        if (DEFER) ksr_pend_store<ST>(a.out, 64, 0, lane, pend);
         // ---- out projection + residual + LayerNorm 1 -------------------------------------
         float s1[32];
         {
@@ -327,11 +332,12 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
                 if (a.sv_xhatf) sv32(a.sv_xhatf, xhat);
                 if (live && a.sv_rstdf && h == 0) a.sv_rstdf[n] = rstd;
             }
-            st32(a.out, y);
+            if (DEFER) ksr_pend32_co<ST>(xb, n0w, nvalid, lane, y, pend); else st32(a.out, y);
         } else {
-            st32(a.out, s2);
+            if (DEFER) ksr_pend32_co<ST>(xb, n0w, nvalid, lane, s2, pend); else st32(a.out, s2);
         }
     }
+    if (DEFER) ksr_pend_store<ST>(a.out, 64, 0, lane, pend);
 }
 
 }  // namespace
@@ -361,8 +367,8 @@ extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* 
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     const bool train = saves || p_drop > 0.f;
     if (S == 1 && !train) {      // inference on one image: no attention step is left (see TxSmem)
-        const unsigned g1 = (unsigned)(ntiles < 1024 ? ntiles : 1024);
-#define KSR_CALL(P) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, 2>), dim3(g1), dim3(256), 0, stream, a)
+        // one resident round: every workgroup stages the weights (and forms W_out W_v) once
+#define KSR_CALL(P) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, 2>), dim3(ksr_persistent_grid(tx_layer_fwd_kernel<P, false, 2>, ntiles, 1024)), dim3(256), 0, stream, a)
         KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
         KSR_LAUNCH_CHECK("batch_tx_layer_fwd(single image)");
@@ -400,12 +406,11 @@ extern "C" int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, fl
     }
     a.S = 1; a.HW = (int)N; a.eps = eps; a.p_drop = p_drop; a.seed = seed; a.seed_dev = ksr_seed_dev();
     const long ntiles = (N + 127) / 128;
-    const unsigned grid = (unsigned)(ntiles < 1024 ? ntiles : 1024);
     const bool train = saves || p_drop > 0.f;
 #define KSR_CALL(P)                                                                                                   \
     do {                                                                                                              \
-        if (train) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, true, 1>), dim3(grid), dim3(256), 0, stream, a);     \
-        else hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, 1>), dim3(grid), dim3(256), 0, stream, a);          \
+        if (train) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, true, 1>), dim3(ksr_persistent_grid(tx_layer_fwd_kernel<P, true, 1>, ntiles, 1024)), dim3(256), 0, stream, a);     \
+        else hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, 1>), dim3(ksr_persistent_grid(tx_layer_fwd_kernel<P, false, 1>, ntiles, 1024)), dim3(256), 0, stream, a);          \
     } while (0)
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
