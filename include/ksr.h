@@ -347,6 +347,9 @@ int ksr_batch_tx_layer_bwd_ln1_wg(const float* du2, const float* dpre, const flo
  * bits as the immediate form.  While the mode is on the caller gives every such call its OWN slab, keeps slabs and
  * outputs alive and untouched until the flush, and orders the flush after every producer (same stream, or an event).
  * Reductions over at most 32 partial rows and the batched (per-image) ones are never deferred.
+ * Recorded reductions are kept in one list per stream of the recording calls (at most 4 streams per thread).
+ * ksr_reduce_defer(k), k >= 2: as 1, and a stream's list is run on that stream as soon as it holds k entries (fewer
+ * launches while the slabs are still in the caches; the per-call slabs are needed all the same).
  * ksr_reduce_defer(0) ends the mode (error if reductions are still recorded), ksr_reduce_defer(-1) ends it and drops what
  * was recorded (a caller's error path); ksr_reduce_pending() = recorded count. */
 int ksr_reduce_defer(int on);

@@ -8,6 +8,9 @@
 #include "ksr_gemm.h"
 #include "ksr_wg_fuse.h"
 
+// gradient sums of up to three LayerNorms from per-workgroup rows (defined below)
+int ksr_ln_reduce(const float* slab, int G, float* out0, float* out1, float* out2, int row_stride, hipStream_t stream);
+
 namespace {
 
 struct TxBwdTokArgs {
@@ -630,11 +633,7 @@ extern "C" int ksr_batch_tx_layer_bwd_token(const float* dy, const float* const*
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token");
-    if (ln_slab) {
-        LnRedArgs r{ln_slab, (int)grid, {a.nf_w ? ln_grads[0] : nullptr, ln_grads[1], ln_grads[2]}, ln_row_stride};
-        hipLaunchKernelGGL(ln_reduce_kernel, dim3(3, 4), dim3(1024), 0, stream, r);
-        KSR_LAUNCH_CHECK("batch_tx_layer_bwd_token(ln reduce)");
-    }
+    if (ln_slab) return ksr_ln_reduce(ln_slab, (int)grid, a.nf_w ? ln_grads[0] : nullptr, ln_grads[1], ln_grads[2], ln_row_stride, stream);
     return KSR_OK;
 }
 
@@ -651,7 +650,17 @@ extern "C" int ksr_batch_tx_layer_bwd_attn(const float* qkv, const float* ctx, c
     return KSR_OK;
 }
 
+// slab: [3][G][2][64] (block l belongs to out_l; a null out_l is skipped).  While the calling thread records its slab
+// reductions (ksr_reduce_defer) these sums are recorded with them - ln_reduce_kernel and the recorded form add the rows in the
+// same order, so the bits do not depend on the mode - and the slab must then stay untouched until the flush.
 int ksr_ln_reduce(const float* slab, int G, float* out0, float* out1, float* out2, int row_stride, hipStream_t stream) {
+    float* outs[3] = {out0, out1, out2};
+    if (ksr_reduce_deferring() && G > 32) {
+        for (int l = 0; l < 3; ++l)
+            if (outs[l])
+                if (int rc = ksr_slab_reduce_rows(slab + (long)l * G * 128, G, 2, 64, 128, outs[l], row_stride, stream)) return rc;
+        return KSR_OK;
+    }
     LnRedArgs r{slab, G, {out0, out1, out2}, row_stride};
     const int n = out2 ? 3 : (out1 ? 2 : 1);
     hipLaunchKernelGGL(ln_reduce_kernel, dim3(n, 4), dim3(1024), 0, stream, r);
@@ -695,9 +704,7 @@ extern "C" int ksr_batch_tx_layer_bwd_ln1_wg(const float* du2, const float* dpre
     const unsigned grid = ksr_persistent_grid(tx_bwd_ln1_wg_kernel, ntiles, KSR_WGF_MAX_GRID);
     hipLaunchKernelGGL(tx_bwd_ln1_wg_kernel, dim3(grid), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("batch_tx_layer_bwd_ln1_wg");
-    LnRedArgs r{ln_slab, (int)grid, {ln_grad, nullptr, nullptr}, ln_row_stride};
-    hipLaunchKernelGGL(ln_reduce_kernel, dim3(1, 4), dim3(1024), 0, stream, r);
-    KSR_LAUNCH_CHECK("batch_tx_layer_bwd_ln1_wg(ln reduce)");
+    if (int rc = ksr_ln_reduce(ln_slab, (int)grid, ln_grad, nullptr, nullptr, ln_row_stride, stream)) return rc;
     return ksr_slab_reduce(wg_slab, (int)grid, 32, 64, dW1, db1, stream);
 }
 

@@ -18,6 +18,8 @@ constexpr int KSR_WGF_MAX_GRID = 768;            // most workgroups a data-gradi
 int ksr_slab_reduce(const float* slab, int G, int J, int K, float* dW, float* db, hipStream_t stream);
 // The same for partial rows of `stride` floats that hold [J*K | J] at their start (several gradients per row).
 int ksr_slab_reduce_strided(const float* slab, int G, int J, int K, long stride, float* dW, float* db, hipStream_t stream);
+// out[j * out_row_stride + k] = the same sum of a [J][K] block at the start of every partial row (no bias part).
+int ksr_slab_reduce_rows(const float* slab, int G, int J, int K, long stride, float* out, int out_row_stride, hipStream_t stream);
 
 // 16-byte chunk c (8 bf16) of row r sits at chunk position c ^ sw(r): row writes (a lane writes 4 chunks of its own row),
 // the transposing reads (4 rows x 16 channels per 16-lane group) and the column reads are then free of bank conflicts.

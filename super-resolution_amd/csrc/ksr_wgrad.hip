@@ -743,17 +743,42 @@ __global__ void __launch_bounds__(256) outer2_kernel(float* out, const float* r,
 }
 
 // Deferred reductions of the calling thread (ksr_reduce_defer): collected here instead of launched, until ksr_reduce_flush.
+// One list per stream that recorded (at most RED_STREAMS streams per thread: the backward's chain and its second stream):
+// a list that fills its window is run on its own stream without regard to the others.
+constexpr int RED_STREAMS = 4;
+struct RedList { hipStream_t stream; RedBatch b; };
 thread_local bool g_red_defer = false;
-thread_local RedBatch g_red_batch;           // g_red_batch.n entries collected so far
+thread_local int g_red_window = 0;           // > 0: a stream's list is run as soon as it holds that many entries
+thread_local RedList g_red[RED_STREAMS];     // entries with b.n == 0 are free
 
-int flush_reduce_batch(hipStream_t s) {
-    RedBatch& b = g_red_batch;
+int red_pending() {
+    int n = 0;
+    for (int i = 0; i < RED_STREAMS; ++i) n += g_red[i].b.n;
+    return n;
+}
+
+int flush_one(RedBatch& b, hipStream_t s) {
     if (b.n == 0) return KSR_OK;
     const int blocks = b.first[b.n];
     hipLaunchKernelGGL(reduce_batch_kernel, dim3((unsigned)blocks), dim3(32 * RED_GROUPS), 0, s, b);
     b.n = 0;
     KSR_LAUNCH_CHECK("reduce(batch)");
     return KSR_OK;
+}
+
+// every list, in the order of the streams' first use, on stream s (the caller has ordered s after the producers)
+int flush_reduce_batch(hipStream_t s) {
+    for (int i = 0; i < RED_STREAMS; ++i)
+        if (int rc = flush_one(g_red[i].b, s)) return rc;
+    return KSR_OK;
+}
+
+RedBatch* red_list_of(hipStream_t s) {
+    for (int i = 0; i < RED_STREAMS; ++i)
+        if (g_red[i].b.n > 0 && g_red[i].stream == s) return &g_red[i].b;
+    for (int i = 0; i < RED_STREAMS; ++i)
+        if (g_red[i].b.n == 0) { g_red[i].stream = s; return &g_red[i].b; }
+    return nullptr;
 }
 
 int launch_reduce(const float* slab, int G, int J, int K, long stride, float* out, int sj, int sk, float* bias,
@@ -764,14 +789,17 @@ int launch_reduce(const float* slab, int G, int J, int K, long stride, float* ou
     const int total = J * K + (bias ? tail_len : 0);
     if (g_red_defer && nb == 1 && G > 4 * RED_GROUPS_FEW) {
         // (the few-row form sums in another grouping and batched entries keep their own launch: results stay bit-equal)
-        RedBatch& b = g_red_batch;
+        RedBatch* bp = red_list_of(s);
+        KSR_UNSUPPORTED(bp == nullptr, "reduce: more than %d streams with recorded reductions", RED_STREAMS);
+        RedBatch& b = *bp;
         if (b.n == RED_BATCH_MAX) {
-            if (int rc = flush_reduce_batch(s)) return rc;
+            if (int rc = flush_one(b, s)) return rc;
         }
         if (b.n == 0) b.first[0] = 0;
         b.e[b.n] = r;
         b.first[b.n + 1] = b.first[b.n] + (total + 31) / 32;
         ++b.n;
+        if (g_red_window > 0 && b.n >= g_red_window) return flush_one(b, s);
         return KSR_OK;
     }
     // few partial rows (G <= 32: the per-image Gram products): 8 groups keep every thread of a workgroup at work
@@ -852,25 +880,29 @@ extern "C" int ksr_wgrad_slab_floats(int J, int K) { return WG_GRID * (J * K + J
 // ksr_reduce_flush(stream) runs all recorded ones in a single launch: same sums, same order, same bits.  The caller must
 // then give every such call its OWN slab and keep slabs and outputs alive and untouched until the flush, and must order the
 // flush after every producer (same stream, or an event).  ksr_reduce_defer(0) ends the mode (the list must be empty).
+// ksr_reduce_defer(k), k >= 2: as 1, and the reductions recorded by calls on one stream are run ON THAT STREAM as soon as
+// there are k of them (lists are kept per stream): fewer launches while the slabs are still in the caches.
 bool ksr_reduce_deferring() { return g_red_defer; }
 
 extern "C" int ksr_reduce_defer(int on) {
     if (on < 0) {                 // abandon: drop what was recorded (error paths of the caller)
-        g_red_batch.n = 0;
+        for (int i = 0; i < RED_STREAMS; ++i) g_red[i].b.n = 0;
         ksr_unet_reduce_clear();
         g_red_defer = false;
+        g_red_window = 0;
         return KSR_OK;
     }
-    const int pending = g_red_batch.n + ksr_unet_reduce_pending();
+    const int pending = red_pending() + ksr_unet_reduce_pending();
     KSR_CHECK_ARG(on || pending == 0, "reduce_defer(0): %d recorded reductions were never flushed", pending);
     g_red_defer = on != 0;
+    g_red_window = on >= 2 ? on : 0;
     return KSR_OK;
 }
 extern "C" int ksr_reduce_flush(hipStream_t stream) {
     if (int rc = flush_reduce_batch(stream)) return rc;
     return ksr_unet_reduce_flush(stream);
 }
-extern "C" int ksr_reduce_pending(void) { return g_red_batch.n + ksr_unet_reduce_pending(); }
+extern "C" int ksr_reduce_pending(void) { return red_pending() + ksr_unet_reduce_pending(); }
 
 // Fixed-order sum of G partial rows [J*K | J] (written by a kernel that accumulated the products itself) to dW, db.
 int ksr_slab_reduce(const float* slab, int G, int J, int K, float* dW, float* db, hipStream_t stream) {
@@ -880,6 +912,11 @@ int ksr_slab_reduce(const float* slab, int G, int J, int K, float* dW, float* db
 // The same for partial rows that hold [J*K | J] at the start of `stride` floats each (several gradients per row).
 int ksr_slab_reduce_strided(const float* slab, int G, int J, int K, long stride, float* dW, float* db, hipStream_t stream) {
     return launch_reduce(slab, G, J, K, stride, dW, K, 1, db, 0, 0, 0, stream);
+}
+
+// out[j * out_row_stride + k] = sum over G partial rows of `stride` floats that hold [J][K] at their start (no bias part).
+int ksr_slab_reduce_rows(const float* slab, int G, int J, int K, long stride, float* out, int out_row_stride, hipStream_t stream) {
+    return launch_reduce(slab, G, J, K, stride, out, out_row_stride, 1, nullptr, 0, 0, 0, stream);
 }
 
 // dW [J][K] (row-major, or scattered through the KAN channel map when kan_upscale > 0) and db [J].

@@ -35,13 +35,17 @@ SIDE_STREAM_MIN_TOKENS = 1 << 19          # LR pixels per backward pass from whi
 # One launch for all slab reductions of a gradient bucket (ksr_reduce_defer / ksr_reduce_flush) instead of one per weight
 # gradient.  Pays where the step is bound by its launch count (8 patches of 128 x 128 per GPU: 0.913 -> 0.884 ms); with many
 # pixels the immediate reduction reads its slab while it is still in the caches and the deferred one re-reads all slabs
-# (170 MB) from memory (64 patches: 4.48 -> 4.65 ms), so it is used below DEFER_BELOW_TOKENS pixels per pass.
-# KSR_DEFER_REDUCTIONS=0 / 1 forces it off / on.
+# (170 MB) from memory (64 patches: 4.48 -> 4.65 ms), so it is used below DEFER_BELOW_TOKENS pixels per pass.  Running a
+# stream's recorded sums in groups of k (ksr_reduce_defer(k), KSR_DEFER_WINDOW=k) is slower there as well (4.34 ms immediate,
+# 4.37 / 4.39 / 4.41 ms with k = 4 / 3 / 8): what the immediate form has is ONE slab that every producer rewrites and that
+# therefore never leaves the caches, where every recorded sum needs a slab of its own.
+# KSR_DEFER_REDUCTIONS=0 / 1 / k forces none / one launch per bucket / groups of k.
 # bf16 storage: the per-token backward of a transformer layer as two kernels that accumulate linear2's / linear1's weight
 # gradients themselves (ksr_batch_tx_layer_bwd_mlp_wg, ..._ln1_wg) instead of one kernel + two ksr_wgrad launches
 SPLIT_TOKEN_BACKWARD = os.environ.get("KSR_SPLIT_TOKEN_BWD", "1") != "0"
 DEFER_REDUCTIONS = os.environ.get("KSR_DEFER_REDUCTIONS", "auto")
 DEFER_BELOW_TOKENS = 1 << 19
+DEFER_WINDOW = int(os.environ.get("KSR_DEFER_WINDOW", "0"))
 
 
 def _side_stream(dev):
@@ -64,11 +68,17 @@ class _Ws:
         # Deferred reductions: every weight-gradient kernel leaves per-workgroup partial rows in a slab of its own and only
         # RECORDS the fixed-order sum that finishes it; flush() runs all recorded sums in one launch (21 launches of ~5 us
         # per step otherwise: a tenth of the step at 8 patches per GPU).  Same sums, same order, same bits.
-        self.defer = dev.type == "cuda" and (DEFER_REDUCTIONS == "1" or (DEFER_REDUCTIONS != "0" and 0 < n_tokens < DEFER_BELOW_TOKENS))
+        mode = 0
+        if dev.type == "cuda" and DEFER_REDUCTIONS != "0":
+            if DEFER_REDUCTIONS == "auto":
+                mode = 1 if 0 < n_tokens < DEFER_BELOW_TOKENS else (DEFER_WINDOW if DEFER_WINDOW >= 2 else 0)
+            else:
+                mode = max(int(DEFER_REDUCTIONS), 0)
+        self.defer = mode > 0
         self._held = []           # slabs of recorded reductions: alive until the flush
         self._after_flush = []    # launches that continue from a reduced gradient (the affine map of linear1's)
         if self.defer:
-            check(lib().ksr_reduce_defer(c_int(1)), "ksr_reduce_defer")
+            check(lib().ksr_reduce_defer(c_int(mode)), "ksr_reduce_defer")
         self._slab = None
         self._ln_slab = None
         self._sums_slab = None
@@ -167,8 +177,11 @@ class _Ws:
         return self._sums_slab
 
     def ln_slab(self):
-        if self._ln_slab is None:
+        """Workspace of the LayerNorm gain / shift sums; their closing sums are recorded with the others while deferring."""
+        if self._ln_slab is None or self.defer:
             self._ln_slab = torch.empty(3 * 768 * 128, device=self.dev, dtype=torch.float32)
+            if self.defer:
+                self._held.append(self._ln_slab)
         return self._ln_slab
 
     def slab(self, nfloats):

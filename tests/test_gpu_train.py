@@ -551,13 +551,13 @@ def test_lightning_strategy_reports_missing_package():
 
 
 def test_deferred_slab_reductions_are_bit_equal(monkeypatch):
-    """The slab reductions of a backward pass recorded and run in one launch per bucket (ksr_reduce_defer / ksr_reduce_flush)
-    give the bits of the immediate form: whole step in bf16 storage and in the exact mode, flat gradient buffers compared."""
+    """The slab reductions of a backward pass recorded and run in one launch per bucket, or in groups of three per stream
+    (ksr_reduce_defer / ksr_reduce_flush), give the bits of the immediate form: whole step in bf16 storage and in the exact mode, flat gradient buffers compared."""
     from kan_sr import autograd, engine
     from kan_sr.train import TrainStep
     for precision in ("bf16s", "fp32"):
         flats = []
-        for mode in ("0", "1", "0"):
+        for mode in ("0", "1", "3", "0"):
             monkeypatch.setattr(autograd, "DEFER_REDUCTIONS", mode)
             m, _ = _model(4, seed=6)
             m = m.cuda().eval()
@@ -571,8 +571,8 @@ def test_deferred_slab_reductions_are_bit_equal(monkeypatch):
             ts.close()
             assert int(_lib_pending()) == 0
         engine.set_precision("fp32")
-        assert flats[0][0] == flats[1][0] == flats[2][0]
-        assert torch.equal(flats[0][1], flats[1][1]) and torch.equal(flats[0][1], flats[2][1]), precision
+        assert flats[0][0] == flats[1][0] == flats[2][0] == flats[3][0]
+        assert all(torch.equal(flats[0][1], f[1]) for f in flats[1:]), precision
         assert float(flats[0][1].abs().max()) > 0
 
 
