@@ -24,6 +24,13 @@ extern "C" int ksr_version(void) { return 100; }
 static thread_local int g_prec = 0;
 int ksr_prec() { return g_prec; }
 
+// fp32 products of the forward kernels on the bf16 matrix cores (three-term split of both operands, fp32-accurate): the
+// calling thread's choice, read by the fp32 entry points that have such an instance.
+static thread_local bool g_f32_split = false;
+bool ksr_f32_split() { return g_f32_split; }
+extern "C" int ksr_set_f32_split(int on) { g_f32_split = on != 0; return KSR_OK; }
+extern "C" int ksr_get_f32_split(void) { return g_f32_split ? 1 : 0; }
+
 extern "C" int ksr_set_precision(int prec) {
     KSR_CHECK_ARG(prec >= 0 && prec <= 2, "set_precision: 0 (fp32), 1 (bf16 MFMA operands) or 2 (bf16 operands and activation storage)");
     g_prec = prec;

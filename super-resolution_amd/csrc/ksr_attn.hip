@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(AttnArgs a) {
                     sc[X][kb][r] = ok ? sc[X][kb][r] : -INFINITY;
                     m = fmaxf(m, sc[X][kb][r]);
                 }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = ksr_pair_max(m);
             float l = 0.f;
 #pragma unroll
             for (int kb = 0; kb < NW; ++kb)
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_kernel(AttnBwdArgs a) {
                         m = fmaxf(m, st[kb][r]);
                     }
                 }
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                m = ksr_pair_max(m);
                 float l = 0.f;
 #pragma unroll
                 for (int kb = 0; kb < NW; ++kb)

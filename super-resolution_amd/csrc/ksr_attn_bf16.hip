@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_bf16_kernel(AttnArgs a) {
                     m = fmaxf(m, sc[kb][r]);
                 }
             }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = ksr_pair_max(m);
             float l = 0.f;
             const float m2 = m * LOG2E;
 #pragma unroll
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_bf16_kernel(AttnBwdArgs a) {
                         m = fmaxf(m, st[kb][r]);
                     }
                 }
-                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                m = ksr_pair_max(m);
                 float l = 0.f;
                 const float m2 = m * LOG2E;
 #pragma unroll

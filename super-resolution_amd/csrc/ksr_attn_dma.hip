@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_dma_kernel(AttnArgs a) {
                 m = fmaxf(m, sc[kb][r]);
             }
         }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = ksr_pair_max(m);
         float l = 0.f;
         const float m2 = m * cexp;
 #pragma unroll
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(256, 2) qkv_attn_fwd_dma_kernel(QkvAttnArgs a)
                 m = fmaxf(m, sc[kb][r]);
             }
         }
-        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        m = ksr_pair_max(m);
         float l = 0.f;
         const float m2 = m * cexp;
 #pragma unroll
@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dma_kernel(AttnBwdArgs a) {
                     m = fmaxf(m, st[kb][r]);
                 }
             }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = ksr_pair_max(m);
             float l = 0.f, dsum = 0.f;
             const float m2 = m * cexp;
             unsigned kw = 0u;                  // keep bits of this lane's keys: bit r + 16 kb

@@ -24,7 +24,13 @@
 
 // MFMA operand precision of ksr_wave_gemm: exact fp32 (v_mfma_f32_32x32x2_f32) or bf16 operands with fp32
 // accumulation (v_mfma_f32_32x32x16_bf16, 16x the rate).  Storage in HBM and all other arithmetic stay fp32.
-enum { KSR_F32 = 0, KSR_BF16 = 1, KSR_BF16S = 2 };   // KSR_BF16S: bf16 MFMA operands AND bf16 activation storage
+enum { KSR_F32 = 0, KSR_BF16 = 1, KSR_BF16S = 2,      // KSR_BF16S: bf16 MFMA operands AND bf16 activation storage
+       // fp32 products on the bf16 matrix cores: both operands are split exactly into three bf16 terms (8 + 8 + 8 = 24
+       // significand bits), six of the nine partial products are formed (those below 2^-24 of the product are dropped), each
+       // exact in the fp32 accumulator.  v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate and its time adds to the vector
+       // instructions' of a kernel; the six bf16 instructions take 3/8 of its time on a pipe of their own.  A template
+       // argument of the forward kernels that have an instance for it, never a value of ksr_prec() (ksr_f32_split()).
+       KSR_F32X3 = 3 };
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 int ksr_prec();   // the calling thread's mode (ksr_set_precision; thread-local, a new thread starts in KSR_F32)
 // Runs CALL(PREC) for the current mode; CALL is a macro taking the mode constant.
@@ -68,6 +74,20 @@ struct MapKan {
 
 // Number of floats of LDS a staged GEMM needs: NB blocks x KH steps x 64 lanes (+ NB*32 bias).
 __host__ __device__ constexpr int ksr_frag_floats(int KH, int NB) { return NB * KH * 64; }
+// ... for a given mode: fp32 fragments, one bf16 plane, or the three planes of the split form
+template <int PREC> __host__ __device__ constexpr int ksr_frag_floats_p(int KH, int NB) {
+    return PREC == KSR_F32 ? NB * KH * 64 : (PREC == KSR_F32X3 ? NB * KH * 96 : NB * KH * 32);
+}
+bool ksr_f32_split();   // the calling thread's choice for fp32 forward kernels that have a split instance (ksr_set_f32_split)
+
+// x = t[0] + t[1] + t[2] with three bf16 terms (exact to 24 significand bits)
+__device__ __forceinline__ void ksr_split3(float x, __bf16 (&t)[3]) {
+    t[0] = (__bf16)x;
+    float r = x - (float)t[0];
+    t[1] = (__bf16)r;
+    r -= (float)t[1];
+    t[2] = (__bf16)r;
+}
 __host__ __device__ constexpr int ksr_bias_floats(int NB) { return NB * 32; }
 
 // Stage W (row-major [rows][ldw]; element (o, i) at W[o*ldw+i], or W[i*ldw+o] when TRANS) into
@@ -95,7 +115,11 @@ __device__ __forceinline__ void ksr_stage_weights(float* __restrict__ frag, floa
         const int i = im(hh, s);
         float v = 0.f;
         if (o >= 0 && i >= 0) v = TRANS ? W[(long)i * ldw + o] : W[(long)o * ldw + i];
-        if (PREC != KSR_F32) frag16[idx] = (__bf16)v;
+        if (PREC == KSR_F32X3) {
+            __bf16 t[3];
+            ksr_split3(v, t);
+            frag16[idx] = t[0]; frag16[total + idx] = t[1]; frag16[2 * total + idx] = t[2];
+        } else if (PREC != KSR_F32) frag16[idx] = (__bf16)v;
         else frag[idx] = v;
     }
     if (biasfrag) {
@@ -126,6 +150,37 @@ __device__ __forceinline__ void ksr_wave_gemm(const float* __restrict__ frag, co
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[blk][q] = 0.f;
         }
+    }
+    if (PREC == KSR_F32X3) {
+        // three bf16 planes of the weights (fragment order of the bf16 modes, NB * KH * 64 elements apart); the activations
+        // are split once; per 8 k-steps six products, the small ones first
+        bf16x8 x1[KH / 8], x2[KH / 8], x3[KH / 8];
+#pragma unroll
+        for (int s8 = 0; s8 < KH / 8; ++s8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                __bf16 t[3];
+                ksr_split3(x[8 * s8 + j], t);
+                x1[s8][j] = t[0]; x2[s8][j] = t[1]; x3[s8][j] = t[2];
+            }
+        constexpr int PLANE = NB * (KH / 8) * 64;          // in 16-byte pieces
+        const bf16x8* w8 = reinterpret_cast<const bf16x8*>(frag) + lane;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+            for (int s8 = 0; s8 < KH / 8; ++s8) {
+                const int cur = (blk * (KH / 8) + s8) * 64;
+                const bf16x8 w1 = w8[cur], w2 = w8[PLANE + cur], w3 = w8[2 * PLANE + cur];
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1[s8], acc[blk], 0, 0, 0);
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3[s8], acc[blk], 0, 0, 0);
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2[s8], acc[blk], 0, 0, 0);
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1[s8], acc[blk], 0, 0, 0);
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2[s8], acc[blk], 0, 0, 0);
+                acc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1[s8], acc[blk], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        return;
     }
     if (PREC != KSR_F32) {
         // activations -> bf16 once; one 16-byte LDS read (8 bf16 of weights) per MFMA
@@ -567,7 +622,19 @@ __device__ __forceinline__ void ksr_pend_store(void* __restrict__ base, int ld, 
 }
 
 // Sum of v over the two lanes that share a token (lanes l and l^32).
-__device__ __forceinline__ float ksr_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// (v_permlane32_swap exchanges the upper half of one register with the lower half of another: after swapping a register
+// with a copy of itself the two results hold v[l] and v[l ^ 32] in some order - one vector instruction instead of a
+// ds_bpermute round trip through the LDS crossbar.)
+__device__ __forceinline__ float ksr_pair_sum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float ksr_pair_max(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
 
 // LayerNorm over the 64 channels of a token held as x[32] on each of the two half-lanes.
 // Writes xhat (normalised, before gain/shift) and returns rstd.

@@ -44,17 +44,20 @@ constexpr int KV_LD = 132;        // floats per slot: [h0: k32 v32][h1: k32 v32]
 // neither Q, K nor the exchange buffer exist; the out-projection then acts on a linear function of the token, and the
 // kernel applies the product matrix W_out W_v (bias W_out b_v + b_out), which every workgroup forms once in LDS.
 // Tiles are consecutive rows as in MODE 1.
-template <int MODE>
+// NW: waves per workgroup (4; 8 for the split-fp32 instance of MODE 2, whose weight planes leave room for one workgroup
+// per CU).  X3: the weight arrays hold three bf16 planes (1.5 x the fp32 size).
+template <int MODE, int NW = 4, bool X3 = false>
 struct __attribute__((aligned(16))) TxSmem {
     static constexpr bool POST = MODE != 0;
+    static constexpr int FS = X3 ? 3 : 2;         // weight bytes per element / 2
     float f_in[MODE == 0 ? 6 * 32 * 64 : 4];      // 64 -> 192
-    float f_out[2 * 32 * 64];     // 64 -> 64
-    float f_l1[1 * 32 * 64];      // 64 -> 32
-    float f_l2[2 * 16 * 64];      // 32 -> 64
+    float f_out[2 * 32 * 64 * FS / 2];     // 64 -> 64
+    float f_l1[1 * 32 * 64 * FS / 2];      // 64 -> 32
+    float f_l2[2 * 16 * 64 * FS / 2];      // 32 -> 64
     float b_in[6 * 32], b_out[2 * 32], b_l1[32], b_l2[2 * 32];
     float ln[6][64];              // n1_w, n1_b, n2_w, n2_b, nf_w, nf_b
     float kv[POST ? 4 : 128 * KV_LD];
-    float xpose[POST ? 4 * KSR_XPOSE_FLOATS : 4];   // POST: per-wave transposers of the coalesced loads / stores
+    float xpose[POST ? NW * KSR_XPOSE_FLOATS : 4];   // POST: per-wave transposers of the coalesced loads / stores
 };
 
 __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* __restrict__ g,
@@ -71,29 +74,33 @@ __device__ __forceinline__ void ln_affine(const float (&xhat)[32], const float* 
 // MODE 1 (post): the QKV projection and the attention ran in separate kernels (ksr_pointwise_fwd,
 // ksr_batch_attn_fwd); this kernel starts from ctx and needs neither the QKV weights nor the K/V
 // exchange buffer in LDS (4x the occupancy).  MODE 2: see TxSmem.
-template <int PREC, bool TRAIN, int MODE>
-__global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(TxArgs a) {
+template <int PREC, bool TRAIN, int MODE, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, MODE != 0 ? (NW + 3) / 4 * (NW > 4 ? 1 : 2) : 1) tx_layer_fwd_kernel(TxArgs a) {
     KSR_MIX_SEED(a);
     using ST = typename KsrStore<PREC>::T;
     constexpr bool POST = MODE != 0;          // row tiles, coalesced loads / stores, no cross-token step
-    __shared__ TxSmem<MODE> sm;
+    constexpr int NT = 64 * NW, TILE = 32 * NW;   // threads per workgroup, tokens per tile (row-tiled modes)
+    static_assert(NW == 4 || MODE == 2, "only the single-image mode has a wider workgroup");
+    __shared__ TxSmem<MODE, NW, PREC == KSR_F32X3> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
 
-    if (MODE == 0) ksr_stage_weights<PREC, 32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, 256);
+    if (MODE == 0) ksr_stage_weights<PREC, 32, 6, false>(sm.f_in, sm.b_in, a.in_w, 64, a.in_b, MapHL{96}, MapHL{32}, tid, NT);
     if (MODE == 2) {
         // W_out and W_v (rows 128..191 of in_proj) -> the transposer area; their product -> the (not yet staged)
         // MLP fragment area, row-major; then staged like any weight matrix
         float* wo = sm.xpose;
         float* wvv = sm.xpose + 4096;
         float* prod = sm.f_l1;                       // f_l1 | f_l2 are adjacent: 4096 floats
-        static_assert(offsetof(TxSmem<MODE>, f_l2) == offsetof(TxSmem<MODE>, f_l1) + sizeof(float) * 2048, "f_l1 and f_l2 must be adjacent");
-        for (int i = tid; i < 1024; i += 256) {
+        using SM = TxSmem<MODE, NW, PREC == KSR_F32X3>;
+        static_assert(offsetof(SM, f_l2) == offsetof(SM, f_l1) + sizeof(sm.f_l1) && sizeof(sm.f_l1) + sizeof(sm.f_l2) >= 4096 * sizeof(float),
+                      "f_l1 and f_l2 must be adjacent and hold the 64 x 64 product");
+        for (int i = tid; i < 1024; i += NT) {
             reinterpret_cast<float4*>(wo)[i] = reinterpret_cast<const float4*>(a.out_w)[i];
             reinterpret_cast<float4*>(wvv)[i] = reinterpret_cast<const float4*>(a.in_w + 128 * 64)[i];
         }
         __syncthreads();
-        {
+        if (tid < 256) {
             const int i = tid >> 2, j0 = (tid & 3) * 16;
             float acc[16], bsum = 0.f;
 #pragma unroll
@@ -113,13 +120,13 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
             if ((tid & 3) == 0) sm.b_in[i] = bsum + a.out_b[i];
         }
         __syncthreads();
-        ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, prod, 64, sm.b_in, MapHL{32}, MapHL{32}, tid, 256);
+        ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, prod, 64, sm.b_in, MapHL{32}, MapHL{32}, tid, NT);
         __syncthreads();
     } else {
-        ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, 256);
+        ksr_stage_weights<PREC, 32, 2, false>(sm.f_out, sm.b_out, a.out_w, 64, a.out_b, MapHL{32}, MapHL{32}, tid, NT);
     }
-    ksr_stage_weights<PREC, 32, 1, false>(sm.f_l1, sm.b_l1, a.l1_w, 64, a.l1_b, MapSplit{16}, MapHL{32}, tid, 256);
-    ksr_stage_weights<PREC, 16, 2, false>(sm.f_l2, sm.b_l2, a.l2_w, 32, a.l2_b, MapHL{32}, MapSplit{16}, tid, 256);
+    ksr_stage_weights<PREC, 32, 1, false>(sm.f_l1, sm.b_l1, a.l1_w, 64, a.l1_b, MapSplit{16}, MapHL{32}, tid, NT);
+    ksr_stage_weights<PREC, 16, 2, false>(sm.f_l2, sm.b_l2, a.l2_w, 32, a.l2_b, MapHL{32}, MapSplit{16}, tid, NT);
     if (tid < 64) {
         sm.ln[0][tid] = a.n1_w[tid]; sm.ln[1][tid] = a.n1_b[tid];
         sm.ln[2][tid] = a.n2_w[tid]; sm.ln[3][tid] = a.n2_b[tid];
@@ -128,8 +135,8 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
     __syncthreads();
 
     const int S = a.S, HW = a.HW;
-    const int PPW = POST ? 128 : 128 / S;             // pixels per workgroup tile (S <= 128)
-    const int ntiles = POST ? (int)(((long)S * HW + 127) / 128) : (HW + PPW - 1) / PPW;
+    const int PPW = POST ? TILE : 128 / S;            // pixels per workgroup tile (S <= 128)
+    const int ntiles = POST ? (int)(((long)S * HW + TILE - 1) / TILE) : (HW + PPW - 1) / PPW;
     const int slot = wv * 32 + tok;
     const int b = slot / PPW, pl = slot - b * PPW;
     const float scale = 0.17677669529663687f;         // 1/sqrt(32)
@@ -140,7 +147,7 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
     constexpr bool AHEAD = (MODE == 2) || (MODE == 1 && sizeof(ST) == 2);
     KsrTile<ST> nx_in, nx_ctx;
     auto fetch_next = [&](int t) {
-        const long r0 = (long)t * 128 + wv * 32, left = (long)S * HW - r0;
+        const long r0 = (long)t * TILE + wv * 32, left = (long)S * HW - r0;
         const int nv = left < 32 ? (int)(left > 0 ? left : 0) : 32;
         if (!a.in32) ksr_co_fetch<ST, true>(a.in, r0, nv, 64, 0, lane, nx_in);
         if (MODE == 1) ksr_co_fetch<ST, true>(a.ctx_in, r0, nv, 64, 0, lane, nx_ctx);
@@ -154,12 +161,12 @@ __global__ void __launch_bounds__(256, MODE != 0 ? 2 : 1) tx_layer_fwd_kernel(Tx
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         // POST: no cross-token step is left, tiles are 128 consecutive rows of [S*HW, 64]
         const int p = tile * PPW + pl;
-        const long nrow = (long)tile * 128 + slot;
+        const long nrow = (long)tile * TILE + slot;
         const bool live = POST ? (nrow < (long)S * HW) : ((b < S) && (p < HW));
         const long n = live ? (POST ? nrow : ((long)b * HW + p)) : 0;
 
         // POST: a wave's 32 rows are consecutive, loads and stores go through the LDS transposer (coalesced)
-        const long n0w = (long)tile * 128 + wv * 32;
+        const long n0w = (long)tile * TILE + wv * 32;
         const int nvalid = POST ? (((long)S * HW - n0w) < 32 ? (int)((long)S * HW - n0w > 0 ? (long)S * HW - n0w : 0) : 32) : 0;
         float* xb = sm.xpose + (POST ? wv * KSR_XPOSE_FLOATS : 0);
         auto st32 = [&](float* base, const float (&v)[32]) {
@@ -368,6 +375,15 @@ extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* 
     const bool train = saves || p_drop > 0.f;
     if (S == 1 && !train) {      // inference on one image: no attention step is left (see TxSmem)
         // one resident round: every workgroup stages the weights (and forms W_out W_v) once
+        if (ksr_prec() == KSR_F32 && ksr_f32_split()) {
+            // fp32 products as six bf16 matrix instructions: eight waves share one copy of the three weight planes
+            constexpr int XW = 8;
+            const long nt8 = ((long)HW + 32 * XW - 1) / (32 * XW);
+            hipLaunchKernelGGL((tx_layer_fwd_kernel<KSR_F32X3, false, 2, XW>), dim3(ksr_persistent_grid(tx_layer_fwd_kernel<KSR_F32X3, false, 2, XW>, nt8, 1024, 64 * XW)),
+                               dim3(64 * XW), 0, stream, a);
+            KSR_LAUNCH_CHECK("batch_tx_layer_fwd(single image, split fp32)");
+            return KSR_OK;
+        }
 #define KSR_CALL(P) hipLaunchKernelGGL((tx_layer_fwd_kernel<P, false, 2>), dim3(ksr_persistent_grid(tx_layer_fwd_kernel<P, false, 2>, ntiles, 1024)), dim3(256), 0, stream, a)
         KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
