@@ -53,6 +53,17 @@ const char* ksr_last_error(void);
 int ksr_set_precision(int prec);
 int ksr_get_precision(void);
 
+/* Mode 0 only, forward kernels that have such an instance (the single-image transformer layer of inference,
+ * ksr_batch_tx_layer_fwd with S = 1): form the fp32 products on the bf16 matrix cores.  Both operands are split exactly
+ * into three bf16 terms (24 significand bits), six of the nine partial products are accumulated in fp32 (the dropped ones
+ * are below 2^-24 of a product): against a float64 evaluation the results are as close as those of the fp32 matrix
+ * instruction (measured: max error 2.4e-7 against 2.8e-7 on outputs of magnitude 1), but not bit-equal to them.
+ * v_mfma_f32_32x32x2_f32 runs at the fp32 vector rate and adds its time to a kernel's vector instructions.
+ * on = 1 / 0 for the calling thread, -1 = back to the process default (on, unless the environment has KSR_F32_SPLIT=0).
+ * No counterpart in the reference, whose precision is whatever its torch build computes fp32 convolutions in. */
+int ksr_set_f32_split(int on);
+int ksr_get_f32_split(void);
+
 /* KAN cell with the per-pixel parameter tensor materialised.
  * Replaces ConvSepKanCell.forward (conv_sep_kan/conv_sep_kan_cells.py:136-156), KANLayer.__call__
  * (conv_sep_kan/kan_layer.py:153-162), compute_bspline (conv_sep_kan/bspline.py:4-28) and, when

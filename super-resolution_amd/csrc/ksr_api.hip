@@ -1,5 +1,7 @@
 // Error channel and version for libksr.
 #include "ksr_common.h"
+
+#include <cstdlib>
 #include <stdarg.h>
 #include <map>
 #include <mutex>
@@ -24,12 +26,17 @@ extern "C" int ksr_version(void) { return 100; }
 static thread_local int g_prec = 0;
 int ksr_prec() { return g_prec; }
 
-// fp32 products of the forward kernels on the bf16 matrix cores (three-term split of both operands, fp32-accurate): the
-// calling thread's choice, read by the fp32 entry points that have such an instance.
-static thread_local bool g_f32_split = false;
-bool ksr_f32_split() { return g_f32_split; }
-extern "C" int ksr_set_f32_split(int on) { g_f32_split = on != 0; return KSR_OK; }
-extern "C" int ksr_get_f32_split(void) { return g_f32_split ? 1 : 0; }
+// fp32 products of the forward kernels on the bf16 matrix cores (three-term split of both operands, as accurate against a
+// float64 evaluation as the fp32 matrix instruction): on unless the environment holds KSR_F32_SPLIT=0; a thread can override
+// the process default for itself.  Read by the fp32 entry points that have such an instance.
+static thread_local int g_f32_split = -1;      // -1: the process default
+static bool f32_split_default() {
+    static const bool on = [] { const char* e = getenv("KSR_F32_SPLIT"); return !(e && e[0] == '0'); }();
+    return on;
+}
+bool ksr_f32_split() { return g_f32_split < 0 ? f32_split_default() : g_f32_split != 0; }
+extern "C" int ksr_set_f32_split(int on) { g_f32_split = on < 0 ? -1 : (on != 0); return KSR_OK; }
+extern "C" int ksr_get_f32_split(void) { return ksr_f32_split() ? 1 : 0; }
 
 extern "C" int ksr_set_precision(int prec) {
     KSR_CHECK_ARG(prec >= 0 && prec <= 2, "set_precision: 0 (fp32), 1 (bf16 MFMA operands) or 2 (bf16 operands and activation storage)");

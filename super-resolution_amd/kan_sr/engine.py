@@ -83,6 +83,13 @@ def set_precision(name: str) -> None:
     _tls.precision = name
 
 
+def set_f32_split(on) -> None:
+    """fp32 mode, forward kernels with such an instance: products as six bf16 matrix instructions on three-term splits of
+    both operands (fp32-accurate, not bit-equal to the fp32 matrix instruction).  True / False for this thread, None = the
+    process default (on unless KSR_F32_SPLIT=0)."""
+    check(lib().ksr_set_f32_split(c_int(-1 if on is None else int(bool(on)))), "ksr_set_f32_split")
+
+
 def act_dtype() -> torch.dtype:
     """Storage type of the activation tensors in the current precision mode."""
     return torch.bfloat16 if getattr(_tls, "precision", "fp32") == "bf16s" else torch.float32

@@ -80,6 +80,41 @@ def test_batch_tx_layer_vs_oracle(S):
     assert_fwd(out.permute(1, 0, 2), ref, atol=2e-5)
 
 
+@pytest.mark.parametrize("HW", [50, 256, 1000, 4133])
+def test_single_image_layer_split_fp32_vs_exact_and_float64(HW):
+    """The single-image transformer layer with its fp32 products split over bf16 matrix instructions (ksr_set_f32_split, the
+    default) against the fp32 matrix instruction and against the oracle in float64: both forms within the fp32 tolerance of
+    the oracle, the split form no further from float64 than 1.5 x the exact form (+ 1e-7), ragged tile counts of the
+    eight-wave workgroups included."""
+    from kan_sr import engine
+    from kan_sr._lib import lib, ptr, stream, check
+    torch.manual_seed(HW)
+    p = orc.random_params(16, 5, 3, seed=4, scale=2.0)
+    pre = "layers.0.encoder.encoder.encoder.layers.1."
+    s = torch.randn(HW, 1, 64)
+    ref32 = orc.batch_tx_layer(s, p, pre)
+    ref64 = orc.batch_tx_layer(s.double(), {k: v.double() for k, v in p.items()}, pre)
+    pc = cuda_params(p)
+    sin = s.permute(1, 0, 2).contiguous().cuda()
+    plist = [pc[pre + n] for n in engine.TX_PARAM_NAMES] + [None, None]
+    outs = {}
+    try:
+        for split in (False, True):
+            engine.set_f32_split(split)
+            assert int(lib().ksr_get_f32_split()) == int(split)
+            out = torch.full_like(sin, float("nan"))
+            check(lib().ksr_batch_tx_layer_fwd(ptr(sin), ptr(out), engine._ptr_array(plist), None, c_int(1), c_int(HW),
+                                               c_float(1e-5), c_float(0.0), c_uint64(0), None, stream()), "tx")
+            outs[split] = out.permute(1, 0, 2).cpu()
+            assert_fwd(outs[split], ref32, atol=2e-5)
+    finally:
+        engine.set_f32_split(None)
+    e_exact = float((outs[False].double() - ref64).abs().max())
+    e_split = float((outs[True].double() - ref64).abs().max())
+    assert e_split <= 1.5 * e_exact + 1e-7, (e_split, e_exact)
+    assert not torch.equal(outs[False], outs[True]) or HW < 64      # two different instruction sequences
+
+
 @pytest.mark.parametrize("B", [1, 2, 4])
 def test_gazetr_golden_features_through_feed(B):
     """GazeTR golden (P=40, i.e. upscale 2): encoder + fused feed/KAN output equals the oracle's KAN
