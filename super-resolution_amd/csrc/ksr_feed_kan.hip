@@ -72,9 +72,9 @@ struct FeedCfg {
     static constexpr int NB = (NH + 15) / 16;
 };
 
-template <int NB, bool COAL>
+template <int NB, bool COAL, int FRAG_FLOATS = NB * 32 * 64 / (COAL ? 2 : 1)>
 struct __attribute__((aligned(16))) FeedSmem {
-    float frag[NB * 32 * 64 / (COAL ? 2 : 1)];        // bf16 storage implies bf16 fragments: half the bytes
+    float frag[FRAG_FLOATS];                          // bf16 storage implies bf16 fragments: half the bytes; split fp32: 1.5 x
     float biasfrag[NB * 32];
     float knots[KSR_MAX_KNOTS];
     float xpose[COAL ? 4 * 32 * KSR_XPOSE16_LD : 4];  // per-wave transposers of the coalesced (uw, S) stores
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256, 2) feed_kan_fwd_kernel(FeedArgs a, KsrKno
     // (the kernel is bound by memory latency there).  fp32 storage (the exact mode is bound by the fp32 matrix pipe and
     // runs three waves per SIMD): every lane loads its own 128 bytes, which needs neither the LDS nor the registers.
     constexpr bool COAL = sizeof(ST) == 2;
-    __shared__ FeedSmem<NB, COAL> sm;
+    __shared__ FeedSmem<NB, COAL, (PREC == KSR_F32X3 ? ksr_frag_floats_p<KSR_F32X3>(32, NB) : NB * 32 * 64 / (COAL ? 2 : 1))> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
     ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.w + (long)blockIdx.y * a.w_bstride, 64,
@@ -248,7 +248,10 @@ int launch_feed_fwd(const FeedArgs& a, const KsrKnots& kn, hipStream_t s) {
         const dim3 grid = feed_grid(a, ksr_wg_slots(reinterpret_cast<const void*>(feed_kan_fwd_kernel<P, R, KC, KORD>), 256)); \
         hipLaunchKernelGGL((feed_kan_fwd_kernel<P, R, KC, KORD>), grid, dim3(256), 0, s, a, kn);                         \
     } while (0)
-    KSR_DISPATCH_PREC(KSR_CALL);
+    // fp32 mode: the contraction as six bf16 matrix instructions on three-term splits where the three weight planes fit
+    // the LDS (P <= 336: 132 KB), unless the caller turned that off
+    if (ksr_prec() == KSR_F32 && ksr_f32_split() && ksr_frag_floats_p<KSR_F32X3>(32, FeedCfg<R, KC>::NB) * 4 <= 140 * 1024) KSR_CALL(KSR_F32X3);
+    else KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("feed_kan_fwd");
     return KSR_OK;
