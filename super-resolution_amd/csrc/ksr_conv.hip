@@ -37,7 +37,7 @@ struct ConvArgs {
 
 template <int PREC, int PRO, int NB>
 struct __attribute__((aligned(16))) ConvSmem {
-    float frag[NB * 32 * 64 / (PREC != KSR_F32 ? 2 : 1)];
+    float frag[ksr_frag_floats_p<PREC>(32, NB)];
     float biasfrag[NB * 32];
     float dww[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? 9 * 64 : 16];
     float dwb[64];
@@ -46,7 +46,7 @@ struct __attribute__((aligned(16))) ConvSmem {
     float halo[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? HALO_H * HALO_W * HALO_LD : 4];
     // one LDS transposer per wave for the coalesced loads / stores; the stencil kernels reuse the halo tile
     // for it once every wave has finished reading the tile
-    float xpose[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? 4 : 4 * KSR_XPOSE_FLOATS];
+    float xpose[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? 4 : 4 * ksr_xpose_floats_p<PREC>()];
 };
 static_assert(4 * KSR_XPOSE_FLOATS <= HALO_H * HALO_W * HALO_LD, "transposers must fit in the halo tile");
 
@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             y = hw / a.W; x = hw % a.W;
         }
 
-        float* xb = (spatial ? sm.halo : sm.xpose) + wv * KSR_XPOSE_FLOATS;
+        static_assert(PREC != KSR_F32X3 || (PRO == PRO_PLAIN && AHEAD), "the split-fp32 instance exists for the plain 1x1 conv with prefetched tiles");
+        float* xb = (spatial ? sm.halo : sm.xpose) + wv * ksr_xpose_floats_p<PREC>();
         // first row and number of real rows of this wave's 32-pixel run (consecutive pixel indices)
         const long n0w = spatial ? (long)b * HW + (long)y * a.W + (x - tok) : tile * 128 + wv * 32;
         int nvalid;
@@ -136,7 +137,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
         float op[32];
         if (PRO == PRO_PLAIN) {
             if (AHEAD) {
-                ksr_co_finish<ST>(xb, lane, ahead, op);
+                if constexpr (PREC == KSR_F32X3) ksr_co_finish_half(xb, lane, ahead, op);
+                else ksr_co_finish<ST>(xb, lane, ahead, op);
                 if (tile + gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
             } else {
                 ksr_load32_co<ST>(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, op);
@@ -189,8 +191,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
                 o[q] = apply_act<ACT>(acc[2 * grp][q]);
                 o[16 + q] = apply_act<ACT>(acc[2 * grp + 1][q]);
             }
-            ksr_store32_co<ST, !AHEAD>(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
-            if (a.out32) ksr_store32_co<float, !AHEAD, true>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            ksr_store32_co_p<PREC, ST, !AHEAD>(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            if (a.out32) ksr_store32_co_p<PREC, float, !AHEAD, true>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
         }
     }
 }
@@ -219,14 +221,14 @@ constexpr int SG_YH = 8, SG_YW = 36, SG_VH = 6, SG_VW = 34;
 
 template <int PREC>
 struct __attribute__((aligned(16))) StemGateSmem {
-    float frag1[2 * 32 * 64 / (PREC != KSR_F32 ? 2 : 1)];
-    float frag2[2 * 32 * 64 / (PREC != KSR_F32 ? 2 : 1)];
+    float frag1[ksr_frag_floats_p<PREC>(32, 2)];
+    float frag2[ksr_frag_floats_p<PREC>(32, 2)];
     float bias1[64], bias2[64];
     float dww[9 * 64], dwb[64];
     float A[128], Bc[128];
     float u[SG_YH * SG_YW];            // pw1(Y) inside the image, 0 outside
     float v[SG_VH * SG_VW];            // relu(dw3x3(u)) inside the image, -1 outside (v >= 0 inside)
-    float xpose[4 * KSR_XPOSE_FLOATS];
+    float xpose[4 * ksr_xpose_floats_p<PREC>()];
 };
 
 template <int PREC>
@@ -270,7 +272,7 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
     const int HW = a.H * a.W;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
     const long ntiles = (long)a.B * tiles_y * tiles_x;
-    float* xb = sm.xpose + wv * KSR_XPOSE_FLOATS;
+    float* xb = sm.xpose + wv * ksr_xpose_floats_p<PREC>();
 
     // the Y window of a tile (8 x 36 values, at most two per thread) is requested one tile ahead: the only global
     // reads of the kernel would otherwise expose their full latency once per tile
@@ -370,10 +372,10 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
         if (a.sv_v) {
             if (live && h == 0) a.sv_v[n] = vc;
             if (a.sv_t) {
-                ksr_store32_co<ST, true, true>(xb, a.sv_t, n0w, nvalid, 128, 0, lane, val);
-                ksr_store32_co<ST, true, true>(xb, a.sv_t, n0w, nvalid, 128, 64, lane, tg);
+                ksr_store32_co_p<PREC, ST, true, true>(xb, a.sv_t, n0w, nvalid, 128, 0, lane, val);
+                ksr_store32_co_p<PREC, ST, true, true>(xb, a.sv_t, n0w, nvalid, 128, 64, lane, tg);
             }
-            ksr_store32_co<ST, true, true>(xb, a.sv_g, n0w, nvalid, 64, 0, lane, g);
+            ksr_store32_co_p<PREC, ST, true, true>(xb, a.sv_g, n0w, nvalid, 64, 0, lane, g);
         }
         f32x16 acc[2];
         ksr_wave_gemm<PREC, 32, 2>(sm.frag1, sm.bias1, op, acc, lane);
@@ -381,7 +383,7 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) { x3[q] = ksr_sigmoid(acc[0][q]); x3[16 + q] = ksr_sigmoid(acc[1][q]); }
         if (a.sv_x3) {
-            ksr_store32_co<ST, true, true>(xb, a.sv_x3, n0w, nvalid, 64, 0, lane, x3);
+            ksr_store32_co_p<PREC, ST, true, true>(xb, a.sv_x3, n0w, nvalid, 64, 0, lane, x3);
             if (sizeof(ST) == 2) {
                 // the backward and the next layer read x3 as stored: continue from the rounded values
 #pragma unroll
@@ -392,7 +394,7 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
         float o[32];
 #pragma unroll
         for (int q = 0; q < 16; ++q) { o[q] = acc[0][q]; o[16 + q] = acc[1][q]; }
-        ksr_store32_co<ST>(xb, a.t3, n0w, nvalid, 64, 0, lane, o);
+        ksr_store32_co_p<PREC, ST>(xb, a.t3, n0w, nvalid, 64, 0, lane, o);
     }
 }
 
@@ -421,6 +423,9 @@ int launch_conv_p(const ConvArgs& a, hipStream_t s) {
 template <int PRO, int NOUT, int ACT>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
 #define KSR_CALL(P) return launch_conv_p<P, PRO, NOUT, ACT>(a, s)
+    if constexpr (PRO == PRO_PLAIN && NOUT <= 128) {      // (192 outputs: the three weight planes would leave one workgroup per CU)
+        if (ksr_prec() == KSR_F32 && ksr_f32_split()) KSR_CALL(KSR_F32X3);      // fp32 products on the bf16 matrix cores
+    }
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     return KSR_OK;
@@ -499,6 +504,7 @@ extern "C" int ksr_stem_gate_fwd(const float* x_img, int64_t img_batch_stride, c
     a.t3 = t3_out; a.sv_v = save_v; a.sv_t = save_t; a.sv_g = save_gate; a.sv_x3 = save_x3; a.sv_ab = save_ab;
     a.B = B; a.H = H; a.W = W;
 #define KSR_CALL(P) return launch_stem_gate_p<P>(a, stream)
+    if (ksr_prec() == KSR_F32 && ksr_f32_split()) KSR_CALL(KSR_F32X3);      // fp32 products on the bf16 matrix cores
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     return KSR_OK;

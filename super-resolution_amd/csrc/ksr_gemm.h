@@ -567,6 +567,66 @@ __device__ __forceinline__ void ksr_store16_co(float* __restrict__ xb, void* __r
     ksr_co16_from_lds<T, TWO_PATH, NT, FULLTILE>(xb, base, n0, nvalid, 32, 0, lane);
 }
 
+// Half-width forms for the kernels whose LDS is taken by the three weight planes of the split-fp32 products: the same
+// coalesced fp32 tile loads / stores, one 32-channel half at a time through a [32][36] buffer (4.6 KB per wave instead of
+// 8.7 KB; a row's 128 bytes are covered by 8 lanes).
+constexpr int KSR_XPOSE_HALF_LD = 36;
+constexpr int KSR_XPOSE_HALF_FLOATS = 32 * KSR_XPOSE_HALF_LD;
+template <int PREC> __host__ __device__ constexpr int ksr_xpose_floats_p() { return PREC == KSR_F32X3 ? KSR_XPOSE_HALF_FLOATS : KSR_XPOSE_FLOATS; }
+
+// tile fetched by ksr_co_fetch<float> -> half layout
+__device__ __forceinline__ void ksr_co_finish_half(float* __restrict__ xb, int lane, const KsrTile<float>& t, float (&x)[32]) {
+    const int r4 = lane >> 4, c16 = lane & 15, h = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        ksr_wave_fence();
+        if ((c16 >> 3) == p) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(xb + (4 * i + r4) * KSR_XPOSE_HALF_LD + 4 * (c16 & 7)) = t.v[i];
+        }
+        ksr_wave_fence();
+        if (h == p) {
+            const float* rp = xb + (lane & 31) * KSR_XPOSE_HALF_LD;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(rp + 4 * q);
+                x[4 * q + 0] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+            }
+        }
+    }
+    ksr_wave_fence();
+}
+// x (half layout) -> rows [n0, n0 + nvalid), channels [c0, c0 + 64) of an fp32 tensor
+template <bool NT = false>
+__device__ __forceinline__ void ksr_store32_co_half(float* __restrict__ xb, float* __restrict__ base, long n0, int nvalid, int ld,
+                                                    int c0, int lane, const float (&x)[32]) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        ksr_wave_fence();
+        if (h == p) {
+            float* wp = xb + (lane & 31) * KSR_XPOSE_HALF_LD;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+        }
+        ksr_wave_fence();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            const float4 v = *reinterpret_cast<const float4*>(xb + row * KSR_XPOSE_HALF_LD + c4);
+            if (row < nvalid) ksr_st16<NT>(reinterpret_cast<float4*>(base + (n0 + row) * ld + c0 + 32 * p + c4), v);
+        }
+    }
+    ksr_wave_fence();
+}
+// the form a kernel instance's mode asks for (split fp32: half width; tensors are fp32 there)
+template <int PREC, class T, bool TWO_PATH = true, bool NT = false>
+__device__ __forceinline__ void ksr_store32_co_p(float* __restrict__ xb, void* __restrict__ base, long n0, int nvalid, int ld,
+                                                 int c0, int lane, const float (&x)[32]) {
+    if constexpr (PREC == KSR_F32X3) ksr_store32_co_half<NT>(xb, reinterpret_cast<float*>(base), n0, nvalid, ld, c0, lane, x);
+    else ksr_store32_co<T, TWO_PATH, NT>(xb, base, n0, nvalid, ld, c0, lane, x);
+}
+
 // Deferred form of ksr_store32_co: a tile's output is transposed right away but stays in registers (the store layout:
 // lane-linear 16-byte pieces) and is stored one loop iteration later, after the next tile's loads have been waited for.
 // The vector-memory counter completes in issue order, so a kernel that stores at the end of an iteration and waits for
