@@ -39,10 +39,11 @@ template <int PREC, int PRO, int NB>
 struct __attribute__((aligned(16))) ConvSmem {
     float frag[ksr_frag_floats_p<PREC>(32, NB)];
     float biasfrag[NB * 32];
-    float dww[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? 9 * 64 : 16];
+    // (split fp32, stencil kernels: the depthwise table lives in the halo tile's padding, ksr_stage_dw_pad)
+    float dww[((PRO == PRO_DWRELU || PRO == PRO_GATE) && PREC != KSR_F32X3) ? 9 * 64 : 16];
     float dwb[64];
-    float p2w[64];
-    float p2b[64];
+    float p2w[PRO == PRO_STEM ? 64 : 4];
+    float p2b[PRO == PRO_STEM ? 64 : 4];
     float halo[(PRO == PRO_DWRELU || PRO == PRO_GATE) ? HALO_H * HALO_W * HALO_LD : 4];
     // one LDS transposer per wave for the coalesced loads / stores; the stencil kernels reuse the halo tile
     // for it once every wave has finished reading the tile
@@ -67,7 +68,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
 
     ksr_stage_weights<PREC, 32, NB, false>(sm.frag, sm.biasfrag, a.wt, 64, a.bias, MapHL{NOUT / 2}, MapHL{32}, tid, 256);
     if (PRO == PRO_DWRELU || PRO == PRO_GATE) {
-        ksr_stage_dw<false>(sm.dww, a.dw_w, tid);
+        if constexpr (PREC == KSR_F32X3) ksr_stage_dw_pad<false>(sm.halo, a.dw_w, tid);
+        else ksr_stage_dw<false>(sm.dww, a.dw_w, tid);
         if (tid < 64) sm.dwb[tid] = a.dw_b[tid];
     }
     if (PRO == PRO_STEM) {
@@ -127,8 +129,10 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             y = hw / a.W; x = hw % a.W;
         }
 
-        static_assert(PREC != KSR_F32X3 || (PRO == PRO_PLAIN && AHEAD), "the split-fp32 instance exists for the plain 1x1 conv with prefetched tiles");
-        float* xb = (spatial ? sm.halo : sm.xpose) + wv * ksr_xpose_floats_p<PREC>();
+        static_assert(PREC != KSR_F32X3 || spatial || (PRO == PRO_PLAIN && AHEAD), "split fp32: stencil kernels, or the plain 1x1 conv with prefetched tiles");
+        // split fp32: the plain kernel's transposers are half width; the stencil kernels' are the (full-size) halo tile
+        constexpr int OUTP = spatial ? (int)KSR_F32 : PREC;
+        float* xb = spatial ? sm.halo + wv * KSR_XPOSE_FLOATS : sm.xpose + wv * ksr_xpose_floats_p<PREC>();
         // first row and number of real rows of this wave's 32-pixel run (consecutive pixel indices)
         const long n0w = spatial ? (long)b * HW + (long)y * a.W + (x - tok) : tile * 128 + wv * 32;
         int nvalid;
@@ -165,7 +169,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             float g[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = sm.dwb[32 * h + i];
-            ksr_dwconv_lane(sm.halo, sm.dww, wv, tok, h, g);
+            if constexpr (PREC == KSR_F32X3) ksr_dwconv_lane_pad(sm.halo, wv, tok, h, g);
+            else ksr_dwconv_lane(sm.halo, sm.dww, wv, tok, h, g);
             __syncthreads();       // every wave is done with the halo tile: it now serves as the transposers
             if (PRO == PRO_DWRELU) {
 #pragma unroll
@@ -191,8 +196,8 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
                 o[q] = apply_act<ACT>(acc[2 * grp][q]);
                 o[16 + q] = apply_act<ACT>(acc[2 * grp + 1][q]);
             }
-            ksr_store32_co_p<PREC, ST, !AHEAD>(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
-            if (a.out32) ksr_store32_co_p<PREC, float, !AHEAD, true>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            ksr_store32_co_p<OUTP, ST, !AHEAD>(xb, a.out, n0w, nvalid, NOUT, 64 * grp, lane, o);
+            if (a.out32) ksr_store32_co_p<OUTP, float, !AHEAD, true>(xb, a.out32, n0w, nvalid, NOUT, 64 * grp, lane, o);
         }
     }
 }
@@ -423,7 +428,7 @@ int launch_conv_p(const ConvArgs& a, hipStream_t s) {
 template <int PRO, int NOUT, int ACT>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
 #define KSR_CALL(P) return launch_conv_p<P, PRO, NOUT, ACT>(a, s)
-    if constexpr (PRO == PRO_PLAIN && NOUT <= 128) {      // (192 outputs: the three weight planes would leave one workgroup per CU)
+    if constexpr ((PRO == PRO_PLAIN && NOUT <= 128) || ((PRO == PRO_DWRELU || PRO == PRO_GATE) && NOUT == 64)) {      // (192 outputs: the three weight planes would leave one workgroup per CU)
         if (ksr_prec() == KSR_F32 && ksr_f32_split()) KSR_CALL(KSR_F32X3);      // fp32 products on the bf16 matrix cores
     }
     KSR_DISPATCH_PREC(KSR_CALL);

@@ -101,4 +101,36 @@ __device__ __forceinline__ void ksr_dwconv_lane(const float* __restrict__ halo, 
         }
 }
 
+// The same with the depthwise weights kept in the PADDING of the halo tile (4 floats behind each pixel's 64 channels: element
+// k of the [tap][channel] table sits at halo[(k >> 2) * HALO_LD + 64 + (k & 3)]; 816 slots for 576 weights).  Nothing that
+// writes pixels or uses the tile as transposers touches the padding, so the table is staged once per workgroup.  For the
+// split-fp32 instances, whose three weight planes leave no room for a table of its own.
+template <bool FLIP>
+__device__ __forceinline__ void ksr_stage_dw_pad(float* __restrict__ halo, const float* __restrict__ w, int tid) {
+    static_assert(HALO_H * HALO_W * 4 >= 9 * 64, "the padding holds the table");
+    for (int i = tid; i < 9 * 64; i += 256) {
+        const int c = i & 63, tap = i >> 6;
+        halo[(i >> 2) * HALO_LD + 64 + (i & 3)] = w[c * 9 + (FLIP ? 8 - tap : tap)];
+    }
+}
+__device__ __forceinline__ void ksr_dwconv_lane_pad(const float* __restrict__ halo, int row, int col, int h, float (&g)[32]) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const float* hp = &halo[((row + dy) * HALO_W + (col + dx)) * HALO_LD + 32 * h];
+            const float* wp = &halo[(((dy * 3 + dx) * 64 + 32 * h) >> 2) * HALO_LD + 64];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 tv = *reinterpret_cast<const f32x4*>(hp + 4 * q);
+                const f32x4 wq = *reinterpret_cast<const f32x4*>(wp + q * HALO_LD);
+                g[4 * q + 0] += wq[0] * tv[0]; g[4 * q + 1] += wq[1] * tv[1];
+                g[4 * q + 2] += wq[2] * tv[2]; g[4 * q + 3] += wq[3] * tv[3];
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(g[i]));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 #endif
