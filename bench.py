@@ -67,6 +67,10 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4, train: bool = 
         # one image (inference): softmax over a single key is 1, the context is the value projection, and the out-projection of
         # a linear function of the token is one 64 x 64 matrix (W_out W_v): lin_post alone
         "ksr_batch_tx_layer_fwd": ("mfma", 2 * ((0 if S == 1 else 2 * 64 * 192 + 256 * S) + lin_post), 2 * 512, pk),
+        # one image, fp32: both layers + the final norm in one launch (the tensor between the layers is never written).  Priced
+        # by its fp32-equivalent flops against the fp32 matrix peak; with the split form (the default) the instructions are
+        # six bf16 matrix instructions per product block, and what is left of the time is vector work
+        "ksr_tx2_single_fwd": ("mfma", 2 * lin_post, 512, pk),
         # attention: the bf16-operand kernels are bound by memory and vector arithmetic (masks, exp, dropout hash), the
         # matrix pipe is < 10 % busy: priced against HBM; the exact fp32 kernels against the fp32 MFMA peak
         "ksr_batch_attn_fwd": ("hbm" if bf16 else "mfma", 2 * 256 * S, 2 * (768 + 256), f32),
@@ -360,7 +364,9 @@ def main():
         B, H, W = 1, 540, 960
         model.eval()
         x = torch.rand(B, 3, H, W, device=dev)
-        wl = "x4 SR inference fp32, 960x540 -> 3840x2160 frame (BASELINE configs[1]); N>1 = replicas"
+        wl = ("x4 SR inference fp32 (products as six bf16 matrix instructions on three-term operand splits, as close to float64 as "
+              "the fp32 matrix instruction; KSR_F32_SPLIT=0 selects that one), 960x540 -> 3840x2160 frame (BASELINE configs[1]); "
+              "N>1 = replicas")
 
         def step():
             with torch.no_grad():
@@ -531,7 +537,7 @@ def main():
             tr = (time.perf_counter() - tr) / 20
             inference = {"value": round(3840 * 2160 / 1e6 / ti, 1), "unit": "MP/s", "ms_per_frame": round(ti * 1e3, 4),
                          "ms_per_frame_rgb_in_rgb_out": round(tr * 1e3, 4),
-                         "workload": "x4 SR inference fp32 eval, 960x540 -> 3840x2160, 1 GPU (BASELINE configs[1])"}
+                         "workload": "x4 SR inference fp32 eval (split-fp32 products), 960x540 -> 3840x2160, 1 GPU (BASELINE configs[1])"}
             # the same step in the other precision modes (fresh model and step each; 3 warm-up + 10 timed steps), so that
             # the run that reports the bf16-storage headline also records the fp32-storage and exact-fp32 times
             by_precision = {args.precision: round(dt / args.steps * 1e3, 4)}

@@ -152,6 +152,14 @@ int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* const* para
                            int HW, float eps, float p_drop, uint64_t seed, const float* in_f32_copy,
                            ksr_stream_t stream);
 
+/* Both encoder layers and the final LayerNorm of ONE image in one launch (GazeTR.forward in eval mode, gazetr.py:110-117, on a
+ * batch of one: the attention over a single key is the V projection, so each layer applies W_out W_v as one matrix).  The
+ * [N,64] tensor between the layers is never written.  params0 / params1: the 12 per-layer tensors in the order of
+ * ksr_batch_tx_layer_fwd's params; in, out [N,64] fp32.  Mode 0 only (KSR_ERR_UNSUPPORTED otherwise); follows
+ * ksr_set_f32_split. */
+int ksr_tx2_single_fwd(const float* in, float* out, const float* const* params0, const float* const* params1,
+                       const float* nf_w, const float* nf_b, int64_t N, float eps, ksr_stream_t stream);
+
 /* The same layer as three kernels, used for large local batches: ksr_pointwise_fwd(n_out = 192) computes
  * qkv [N,192] = in_proj(x); ksr_batch_attn_fwd runs the 2-head softmax attention over the S images of every
  * pixel on the matrix cores (ctx [N,64]); ksr_batch_tx_layer_post_fwd does out_proj, norm1, the MLP, norm2

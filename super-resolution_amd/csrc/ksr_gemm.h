@@ -681,6 +681,41 @@ __device__ __forceinline__ void ksr_pend_store(void* __restrict__ base, int ld, 
     p.nvalid = 0;
 }
 
+// ksr_pend32_co through the half-width buffer (fp32 tensors): piece i of half p = row (i * 64 + lane) >> 3, floats
+// 32 p + 4 ((i * 64 + lane) & 7) .. + 3.
+struct KsrPendHalf { ksr_f32x4_t v[8]; long n0; int nvalid; };
+__device__ __forceinline__ void ksr_pend32_co_half(float* __restrict__ xb, long n0, int nvalid, int lane, const float (&x)[32],
+                                                   KsrPendHalf& pd) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        ksr_wave_fence();
+        if (h == p) {
+            float* wp = xb + (lane & 31) * KSR_XPOSE_HALF_LD;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<float4*>(wp + 4 * q) = make_float4(x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]);
+        }
+        ksr_wave_fence();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane;
+            pd.v[4 * p + i] = *reinterpret_cast<const ksr_f32x4_t*>(xb + (idx >> 3) * KSR_XPOSE_HALF_LD + (idx & 7) * 4);
+        }
+    }
+    pd.n0 = n0; pd.nvalid = nvalid;
+    ksr_wave_fence();
+}
+__device__ __forceinline__ void ksr_pend_store_half(float* __restrict__ base, int ld, int c0, int lane, KsrPendHalf& pd) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 3, c4 = (idx & 7) * 4;
+            if (row < pd.nvalid) *reinterpret_cast<ksr_f32x4_t*>(base + (pd.n0 + row) * ld + c0 + 32 * p + c4) = pd.v[4 * p + i];
+        }
+    pd.nvalid = 0;
+}
+
 // Sum of v over the two lanes that share a token (lanes l and l^32).
 // (v_permlane32_swap exchanges the upper half of one register with the lower half of another: after swapping a register
 // with a copy of itself the two results hold v[l] and v[l ^ 32] in some order - one vector instruction instead of a

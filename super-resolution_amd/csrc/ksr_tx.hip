@@ -347,6 +347,128 @@ __global__ void __launch_bounds__(64 * NW, MODE != 0 ? (NW + 3) / 4 * (NW > 4 ? 
     if (DEFER) ksr_pend_store<ST>(a.out, 64, 0, lane, pend);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Inference on one image: BOTH encoder layers and the final LayerNorm in one pass over the tokens (each layer as in MODE 2
+// of tx_layer_fwd_kernel: W_out W_v applied as one matrix).  The [N,64] tensor between the layers (a 133-MB write and read
+// per 540 x 960 frame) and one pair of transposes never exist.  Eight waves share one copy of both layers' weights
+// (fp32: 64 KB; split fp32: three bf16 planes, 96 KB) beside half-width transposers: one workgroup per CU.
+struct Tx2Args {
+    const float* in; float* out;
+    const float* p[2][12];        // per layer: the 12 tensors of ksr_batch_tx_layer_fwd's params
+    const float *nf_w, *nf_b;
+    long N; float eps;
+};
+template <int PREC>
+struct __attribute__((aligned(16))) Tx2Smem {
+    float f_out[2][ksr_frag_floats_p<PREC>(32, 2)];
+    float f_l1[2][ksr_frag_floats_p<PREC>(32, 1)];      // f_l1[l] | f_l2[l] are not adjacent across layers: the product
+    float f_l2[2][ksr_frag_floats_p<PREC>(16, 2)];      // matrix of layer l is formed in scratch below
+    float b_out[2][64], b_l1[2][32], b_l2[2][64], b_v[64];
+    float ln[2][4][64], lnf[2][64];
+    float xpose[8 * KSR_XPOSE_HALF_FLOATS];             // 36 KB; the prologue uses 32 KB of it for W_out and W_v
+    float prod[64 * 64];
+};
+
+template <int PREC>
+__global__ void __launch_bounds__(512, 2) tx2_single_fwd_kernel(Tx2Args a) {
+    __shared__ Tx2Smem<PREC> sm;
+    static_assert(sizeof(sm.xpose) >= 2 * 4096 * sizeof(float), "the transposers hold W_out and W_v in the prologue");
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int h = lane >> 5;
+    for (int l = 0; l < 2; ++l) {
+        const float *in_w = a.p[l][0], *in_b = a.p[l][1], *out_w = a.p[l][2], *out_b = a.p[l][3];
+        float* wo = sm.xpose;
+        float* wvv = sm.xpose + 4096;
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 512) {
+            reinterpret_cast<float4*>(wo)[i] = reinterpret_cast<const float4*>(out_w)[i];
+            reinterpret_cast<float4*>(wvv)[i] = reinterpret_cast<const float4*>(in_w + 128 * 64)[i];
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int i = tid >> 2, j0 = (tid & 3) * 16;
+            float acc[16], bsum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+            for (int k = 0; k < 64; ++k) {
+                const float w = wo[i * 64 + k];
+                bsum = fmaf(w, in_b[128 + k], bsum);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(wvv + k * 64 + j0 + 4 * q);
+                    acc[4 * q] = fmaf(w, v.x, acc[4 * q]); acc[4 * q + 1] = fmaf(w, v.y, acc[4 * q + 1]);
+                    acc[4 * q + 2] = fmaf(w, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(w, v.w, acc[4 * q + 3]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sm.prod[i * 64 + j0 + j] = acc[j];
+            if ((tid & 3) == 0) sm.b_v[i] = bsum + out_b[i];
+        }
+        __syncthreads();
+        ksr_stage_weights<PREC, 32, 2, false>(sm.f_out[l], sm.b_out[l], sm.prod, 64, sm.b_v, MapHL{32}, MapHL{32}, tid, 512);
+        ksr_stage_weights<PREC, 32, 1, false>(sm.f_l1[l], sm.b_l1[l], a.p[l][4], 64, a.p[l][5], MapSplit{16}, MapHL{32}, tid, 512);
+        ksr_stage_weights<PREC, 16, 2, false>(sm.f_l2[l], sm.b_l2[l], a.p[l][6], 32, a.p[l][7], MapHL{32}, MapSplit{16}, tid, 512);
+        if (tid < 64) {
+            sm.ln[l][0][tid] = a.p[l][8][tid]; sm.ln[l][1][tid] = a.p[l][9][tid];
+            sm.ln[l][2][tid] = a.p[l][10][tid]; sm.ln[l][3][tid] = a.p[l][11][tid];
+            if (l == 1) { sm.lnf[0][tid] = a.nf_w[tid]; sm.lnf[1][tid] = a.nf_b[tid]; }
+        }
+    }
+    __syncthreads();
+
+    const long ntiles = (a.N + 255) / 256;
+    float* xb = sm.xpose + wv * KSR_XPOSE_HALF_FLOATS;
+    KsrTile<float> nx;
+    auto fetch_next = [&](long t) {
+        const long r0 = t * 256 + wv * 32, left = a.N - r0;
+        const int nv = left < 32 ? (int)(left > 0 ? left : 0) : 32;
+        ksr_co_fetch<float, true>(a.in, r0, nv, 64, 0, lane, nx);
+    };
+    if ((long)blockIdx.x < ntiles) fetch_next(blockIdx.x);
+    KsrPendHalf pend;
+    pend.nvalid = 0; pend.n0 = 0;
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long n0w = tile * 256 + wv * 32;
+        const int nvalid = (a.N - n0w) < 32 ? (int)(a.N - n0w > 0 ? a.N - n0w : 0) : 32;
+        float s0[32];
+        ksr_co_finish_half(xb, lane, nx, s0);
+        if (tile + gridDim.x < ntiles) fetch_next(tile + gridDim.x);
+        ksr_pend_store_half(a.out, 64, 0, lane, pend);          // the previous tile's output
+#pragma unroll
+        for (int l = 0; l < 2; ++l) {
+            float s1[32];
+            {
+                f32x16 acc[2];
+                ksr_wave_gemm<PREC, 32, 2>(sm.f_out[l], sm.b_out[l], s0, acc, lane);
+                float u[32], xhat[32];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { u[i] = acc[0][i] + s0[i]; u[16 + i] = acc[1][i] + s0[16 + i]; }
+                ksr_layernorm64(u, xhat, a.eps);
+                ln_affine(xhat, sm.ln[l][0], sm.ln[l][1], h, s1);
+            }
+            {
+                f32x16 acc1[1];
+                ksr_wave_gemm<PREC, 32, 1>(sm.f_l1[l], sm.b_l1[l], s1, acc1, lane);
+                float hm[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) hm[i] = acc1[0][i] > 0.f ? acc1[0][i] : 0.f;
+                f32x16 acc2[2];
+                ksr_wave_gemm<PREC, 16, 2>(sm.f_l2[l], sm.b_l2[l], hm, acc2, lane);
+                float u[32], xhat[32];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { u[i] = acc2[0][i] + s1[i]; u[16 + i] = acc2[1][i] + s1[16 + i]; }
+                ksr_layernorm64(u, xhat, a.eps);
+                ln_affine(xhat, sm.ln[l][2], sm.ln[l][3], h, s0);      // the next layer's input
+            }
+        }
+        float xhat[32], y[32];
+        ksr_layernorm64(s0, xhat, a.eps);
+        ln_affine(xhat, sm.lnf[0], sm.lnf[1], h, y);
+        ksr_pend32_co_half(xb, n0w, nvalid, lane, y, pend);
+    }
+    ksr_pend_store_half(a.out, 64, 0, lane, pend);
+}
+
 }  // namespace
 
 extern "C" int ksr_batch_tx_layer_fwd(const float* in, float* out, const float* const* params, float* const* saves,
@@ -431,5 +553,27 @@ extern "C" int ksr_batch_tx_layer_post_fwd(const float* in, const float* ctx, fl
     KSR_DISPATCH_PREC(KSR_CALL);
 #undef KSR_CALL
     KSR_LAUNCH_CHECK("batch_tx_layer_post_fwd");
+    return KSR_OK;
+}
+
+// Both encoder layers and the final LayerNorm of a single image in one launch (GazeTR.forward in eval mode on one image,
+// gazetr.py:110-117: over a batch of one the attention is the V projection).  params0 / params1: the 12 tensors of
+// ksr_batch_tx_layer_fwd per layer; in, out [N,64] fp32.  fp32 mode only (other modes: KSR_ERR_UNSUPPORTED).
+extern "C" int ksr_tx2_single_fwd(const float* in, float* out, const float* const* params0, const float* const* params1,
+                                  const float* nf_w, const float* nf_b, int64_t N, float eps, hipStream_t stream) {
+    KSR_CHECK_ARG(in && out && params0 && params1 && nf_w && nf_b && N > 0, "tx2_single_fwd: bad argument");
+    KSR_UNSUPPORTED(ksr_prec() != KSR_F32, "tx2_single_fwd: fp32 mode only");
+    Tx2Args a{};
+    a.in = in; a.out = out; a.nf_w = nf_w; a.nf_b = nf_b; a.N = (long)N; a.eps = eps;
+    for (int i = 0; i < 12; ++i) {
+        KSR_CHECK_ARG(params0[i] && params1[i], "tx2_single_fwd: params[%d] is null", i);
+        a.p[0][i] = params0[i]; a.p[1][i] = params1[i];
+    }
+    const long ntiles = ((long)N + 255) / 256;
+    if (ksr_f32_split())
+        hipLaunchKernelGGL(tx2_single_fwd_kernel<KSR_F32X3>, dim3(ksr_persistent_grid(tx2_single_fwd_kernel<KSR_F32X3>, ntiles, 1024, 512)), dim3(512), 0, stream, a);
+    else
+        hipLaunchKernelGGL(tx2_single_fwd_kernel<KSR_F32>, dim3(ksr_persistent_grid(tx2_single_fwd_kernel<KSR_F32>, ntiles, 1024, 512)), dim3(512), 0, stream, a);
+    KSR_LAUNCH_CHECK("tx2_single_fwd");
     return KSR_OK;
 }

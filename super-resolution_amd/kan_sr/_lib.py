@@ -85,7 +85,7 @@ def _declare(L: ctypes.CDLL) -> None:
 
 # every symbol include/ksr.h declares (tests/test_host_logic.py compares the two lists)
 EXPORTS = [
-    "ksr_version", "ksr_last_error", "ksr_set_precision", "ksr_get_precision", "ksr_set_f32_split", "ksr_get_f32_split",
+    "ksr_version", "ksr_last_error", "ksr_set_precision", "ksr_get_precision", "ksr_set_f32_split", "ksr_get_f32_split", "ksr_tx2_single_fwd",
     "ksr_reduce_defer", "ksr_reduce_flush", "ksr_reduce_pending", "ksr_dwconv_wgrad_groups",
     "ksr_batch_tx_layer_bwd_mlp_wg", "ksr_batch_tx_layer_bwd_ln1_wg", "ksr_feed_kan_bwd_lnf",
     "ksr_sm_conv_fwd", "ksr_sm_layernorm_fwd", "ksr_sm_resize_add_fwd", "ksr_sm_route_fwd", "ksr_sm_experts_fwd",

@@ -7,6 +7,7 @@ needs, and the backward itself lives in autograd.py (one torch.autograd.Function
 from __future__ import annotations
 
 import ctypes
+import os
 import threading
 from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
 from typing import Dict, Optional, Sequence
@@ -66,6 +67,7 @@ def _dims(g: Geometry):
     return c_int(g.B), c_int(g.H), c_int(g.W)
 
 
+FUSE_SINGLE_IMAGE_LAYERS = os.environ.get("KSR_FUSE_TX2", "1") != "0"
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16s": 2}
 _tls = threading.local()          # the library keeps the mode per calling thread; so does this mirror of it
 
@@ -145,6 +147,14 @@ def encoder_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], pre: str, g: Ge
     if keep:
         saves.update(v=v, ab=ab, t2=t2, g2=g2, x3=x3, t3=t3, a4=a4, x4=x4, t5=t5, g6=g6, x6=x6)
     s = x6
+    if g.B == 1 and not keep and adt == torch.float32 and getattr(_tls, "precision", "fp32") == "fp32" and p_drop == 0.0 and FUSE_SINGLE_IMAGE_LAYERS:
+        # one image, eval: both layers and the final norm in one launch (the tensor between the layers is never written)
+        q0, q1 = f"{pre}encoder.layers.0.", f"{pre}encoder.layers.1."
+        out = new(N, 64)
+        check(L.ksr_tx2_single_fwd(ptr(s), ptr(out), _ptr_array([p[q0 + n] for n in TX_PARAM_NAMES]),
+                                   _ptr_array([p[q1 + n] for n in TX_PARAM_NAMES]), ptr(p[pre + "encoder.norm.weight"]),
+                                   ptr(p[pre + "encoder.norm.bias"]), c_int64(N), c_float(LN_EPS), stream()), "ksr_tx2_single_fwd")
+        return out
     for li in range(2):
         q = f"{pre}encoder.layers.{li}."
         plist = [p[q + n] for n in TX_PARAM_NAMES]
