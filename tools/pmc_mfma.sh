@@ -8,5 +8,5 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/infer -o infer -- python3 $R/bench.py --workload infer --steps 3 --warmup 1 --no-cpu-baseline > $OUT/infer.json 2> $OUT/infer.log || exit 1
 echo "infer done"
-timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/train -o train -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/train.json 2> $OUT/train.log || exit 1
+timeout -s KILL 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/train -o train -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --headline-only > $OUT/train.json 2> $OUT/train.log || exit 1
 echo "train done"
