@@ -33,6 +33,16 @@ __global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
     const int HW = a.H * a.W;
     const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
     const long ntiles = (long)a.B * tiles_y * tiles_x;
+    // bf16 tensors: the halo of the next (tile, group) is requested before the current one's arithmetic (without it every
+    // group of every tile exposed one full memory latency: 806 MB per launch moved at 3.4 TB/s)
+    constexpr bool HAHEAD = sizeof(ST) == 2;
+    KsrHalo<ST> hr;
+    auto fetch = [&](long t, int gi) {
+        const int ftx = (int)(t % tiles_x), fty = (int)((t / tiles_x) % tiles_y);
+        const int fb = (int)(t / ((long)tiles_x * tiles_y));
+        ksr_halo_fetch<ST>(a.in, a.ld, 64 * gi, fb, fty * 4, ftx * 32, a.H, a.W, tid, hr);
+    };
+    if (HAHEAD && (long)blockIdx.x < ntiles) fetch(blockIdx.x, 0);
     for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const int b = (int)(tile / ((long)tiles_x * tiles_y));
@@ -40,8 +50,13 @@ __global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
         const int y = y0 + wv;
         for (int gi = 0; gi < a.groups; ++gi) {
             __syncthreads();
-            ksr_stage_halo<ST>(halo, a.in, a.ld, 64 * gi, b, y0, x0, a.H, a.W, tid);
+            if (!HAHEAD) fetch(tile, gi);
+            ksr_halo_commit<ST>(halo, tid, hr);
             __syncthreads();
+            if (HAHEAD) {
+                if (gi + 1 < a.groups) fetch(tile, gi + 1);
+                else if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, 0);
+            }
             float g[32];
 #pragma unroll
             for (int i = 0; i < 32; ++i) g[i] = dwb[gi * 64 + 32 * h + i];
