@@ -195,13 +195,16 @@ struct SoftArgs {
     int P;
 };
 
+// grid (B, ny): every workgroup of an image forms the 64 x 64 softmax (cheap) and takes a chunk of M's rows; the first one
+// also writes A, S and the norms.  (One workgroup per image left the P x 64 x 64 product to 4 waves on 64 of 256 CUs.)
 __global__ void __launch_bounds__(256) chan_soft_fwd_kernel(SoftArgs a) {
     __shared__ float As[64][65];
     __shared__ float nq[64], nk[64];
     const int tid = threadIdx.x, b = blockIdx.x;
+    const bool first = blockIdx.y == 0;
     if (tid < 128) {
         const float raw = sqrtf(a.tail[(long)b * 192 + 64 + tid]);
-        a.nrm[(long)b * 128 + tid] = raw;
+        if (first) a.nrm[(long)b * 128 + tid] = raw;
         const float cl = fmaxf(raw, 1e-12f);
         if (tid < 64) nq[tid] = cl; else nk[tid - 64] = cl;
     }
@@ -227,20 +230,24 @@ __global__ void __launch_bounds__(256) chan_soft_fwd_kernel(SoftArgs a) {
     for (int j = 0; j < 16; ++j) {
         const float p = e[j] * inv;
         As[c][part * 16 + j] = p;
-        a.A[(long)b * 4096 + c * 64 + part * 16 + j] = p;
-        a.S[(long)b * 4096 + c * 64 + part * 16 + j] = s[j];
+        if (first) {
+            a.A[(long)b * 4096 + c * 64 + part * 16 + j] = p;
+            a.S[(long)b * 4096 + c * 64 + part * 16 + j] = s[j];
+        }
     }
     __syncthreads();
-    // M = W_a A: a wave owns rows p = wave + 4 k, lane = column cc; A's column stays in registers, W_a's row is read through
-    // wave-uniform (scalar) loads; two rows at a time for two independent chains (each row's sum keeps its order)
+    // M = W_a A: a wave owns rows p = p_lo + wave + 4 k, lane = column cc; A's column stays in registers, W_a's row is read
+    // through wave-uniform (scalar) loads; two rows at a time for two independent chains (each row's sum keeps its order)
     {
+        const int chunk = (((a.P + (int)gridDim.y - 1) / (int)gridDim.y) + 7) & ~7;
+        const int p_lo = (int)blockIdx.y * chunk, p_hi = p_lo + chunk < a.P ? p_lo + chunk : a.P;
         const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6), cc = tid & 63;
         float ar[64];
 #pragma unroll
         for (int ci = 0; ci < 64; ++ci) ar[ci] = As[ci][cc];
         float* Mb = a.M + (long)b * a.P * 64;
-        int p = w0;
-        for (; p + 4 < a.P; p += 8) {
+        int p = p_lo + w0;
+        for (; p + 4 < p_hi; p += 8) {
             const float* wa = a.Wa + p * 64;
             const float* wb = wa + 4 * 64;
             float acc0 = 0.f, acc1 = 0.f;
@@ -249,7 +256,7 @@ __global__ void __launch_bounds__(256) chan_soft_fwd_kernel(SoftArgs a) {
             Mb[p * 64 + cc] = acc0;
             Mb[(p + 4) * 64 + cc] = acc1;
         }
-        for (; p < a.P; p += 4) {
+        for (; p < p_hi; p += 4) {
             const float* wa = a.Wa + p * 64;
             float acc0 = 0.f;
 #pragma unroll
@@ -267,28 +274,49 @@ struct SoftBwdArgs {
     int P;
 };
 
-// One workgroup of 1024 threads per image (the batch is the only grid dimension: with 256 threads a batch of 64 images
-// left three quarters of the GPU's SIMDs without a wave).
+// grid (B, 1 + K), 1024 threads: workgroup (b, 0) forms dS and Mqk of image b, workgroups (b, 1..K) a chunk each of the
+// image's dW_a contribution (which needs only A and Gd).
 __global__ void __launch_bounds__(1024) chan_soft_bwd_kernel(SoftBwdArgs a) {
     __shared__ float As[64][65], Ss[64][65], dS[64][65];
     __shared__ float nq[64], nk[64], pq[64], pk[64], r[64], rp[64];
     const int tid = threadIdx.x, b = blockIdx.x;
-    for (int idx = tid; idx < 4096; idx += 1024) {
-        As[idx >> 6][idx & 63] = a.A[(long)b * 4096 + idx];
-        Ss[idx >> 6][idx & 63] = a.S[(long)b * 4096 + idx];
+    const float* Gd = a.Gd + (long)b * a.P * 64;
+    for (int idx = tid; idx < 4096; idx += 1024) As[idx >> 6][idx & 63] = a.A[(long)b * 4096 + idx];
+    if (blockIdx.y > 0) {
+        // dW_a contribution of this image: Gd A^T.  A wave owns rows p = p_lo + wave + 16 k, lane = column c: row c of A stays
+        // in registers, Gd's row is read through wave-uniform (scalar) loads
+        __syncthreads();
+        const int K = (int)gridDim.y - 1;
+        const int chunk = (((a.P + K - 1) / K) + 15) & ~15;
+        const int p_lo = ((int)blockIdx.y - 1) * chunk, p_hi = p_lo + chunk < a.P ? p_lo + chunk : a.P;
+        const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
+        float ar[64];
+#pragma unroll
+        for (int cc = 0; cc < 64; ++cc) ar[cc] = As[c][cc];
+        for (int p = p_lo + w0; p < p_hi; p += 16) {
+            const float* g = Gd + p * 64;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 64; cc += 4) {
+                s0 += g[cc] * ar[cc]; s1 += g[cc + 1] * ar[cc + 1]; s2 += g[cc + 2] * ar[cc + 2]; s3 += g[cc + 3] * ar[cc + 3];
+            }
+            a.dWa_part[(long)b * a.P * 64 + p * 64 + c] = (s0 + s1) + (s2 + s3);
+        }
+        return;
     }
+    for (int idx = tid; idx < 4096; idx += 1024) Ss[idx >> 6][idx & 63] = a.S[(long)b * 4096 + idx];
     if (tid < 128) {
         const float raw = a.nrm[(long)b * 128 + tid];
         const float cl = fmaxf(raw, 1e-12f), pr = raw >= 1e-12f ? 1.f : 0.f;
         if (tid < 64) { nq[tid] = cl; pq[tid] = pr; } else { nk[tid - 64] = cl; pk[tid - 64] = pr; }
     }
-    const float* Gd = a.Gd + (long)b * a.P * 64;
     // dA = W_a^T Gd: a wave owns rows c = wave + 16 k (k < 4), lane = column; per p one coalesced read of Gd's row and four
-    // wave-uniform (scalar) reads of W_a feed four independent sums
+    // wave-uniform (scalar) reads of W_a feed four independent sums; eight p in flight at a time (the loop is a chain of
+    // memory latencies otherwise)
     {
         const int c0 = __builtin_amdgcn_readfirstlane(tid >> 6), cc = tid & 63;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll 8
         for (int p = 0; p < a.P; ++p) {
             const float gv = Gd[p * 64 + cc];
             const float* wr = a.Wa + p * 64 + c0;
@@ -340,31 +368,20 @@ __global__ void __launch_bounds__(1024) chan_soft_bwd_kernel(SoftBwdArgs a) {
         }
         Mqk[idx] = v;
     }
-    // dW_a contribution of this image: Gd A^T.  A wave owns rows p = wave + 16 k, lane = column c: row c of A stays in
-    // registers, Gd's row is read through wave-uniform (scalar) loads
-    {
-        const int w0 = __builtin_amdgcn_readfirstlane(tid >> 6), c = tid & 63;
-        float ar[64];
-#pragma unroll
-        for (int cc = 0; cc < 64; ++cc) ar[cc] = As[c][cc];
-        for (int p = w0; p < a.P; p += 16) {
-            const float* g = Gd + p * 64;
-            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-            for (int cc = 0; cc < 64; cc += 4) {
-                s0 += g[cc] * ar[cc]; s1 += g[cc + 1] * ar[cc + 1]; s2 += g[cc + 2] * ar[cc + 2]; s3 += g[cc + 3] * ar[cc + 3];
-            }
-            a.dWa_part[(long)b * a.P * 64 + p * 64 + c] = (s0 + s1) + (s2 + s3);
-        }
-    }
 }
 
-// out[i] = sum_g in[g][i]  (fixed order)
+// out[i] = sum_g in[g][i]  (fixed order); four entries in flight per thread
 __global__ void __launch_bounds__(256) sum_entries_kernel(const float* in, int G, long stride, int n, float* out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += in[(long)g * stride + i];
+    int g = 0;
+    for (; g + 4 <= G; g += 4) {
+        const float v0 = in[(long)g * stride + i], v1 = in[(long)(g + 1) * stride + i];
+        const float v2 = in[(long)(g + 2) * stride + i], v3 = in[(long)(g + 3) * stride + i];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; g < G; ++g) s += in[(long)g * stride + i];
     out[i] = s;
 }
 
@@ -415,7 +432,9 @@ extern "C" int ksr_chan_soft_fwd(const float* G, const float* tail, const float*
                                  float* nrm, float* M, int n_out, int B, hipStream_t stream) {
     KSR_CHECK_ARG(G && tail && a_proj_w && A && S && nrm && M && n_out > 0 && B > 0, "chan_soft_fwd: bad argument");
     SoftArgs a{G, tail, a_proj_w, A, S, nrm, M, n_out};
-    hipLaunchKernelGGL(chan_soft_fwd_kernel, dim3(B), dim3(256), 0, stream, a);
+    int ny = (n_out + 47) / 48;
+    if (ny > 8) ny = 8;
+    hipLaunchKernelGGL(chan_soft_fwd_kernel, dim3(B, ny), dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("chan_soft_fwd");
     return KSR_OK;
 }
@@ -427,7 +446,9 @@ extern "C" int ksr_chan_soft_bwd(const float* Gd, const float* A, const float* S
                                  hipStream_t stream) {
     KSR_CHECK_ARG(Gd && A && S && nrm && a_proj_w && Mqk && dWa_part && dWa && n_out > 0 && B > 0, "chan_soft_bwd: bad argument");
     SoftBwdArgs a{Gd, A, S, nrm, a_proj_w, Mqk, dWa_part, n_out};
-    hipLaunchKernelGGL(chan_soft_bwd_kernel, dim3(B), dim3(1024), 0, stream, a);
+    int K = (n_out + 63) / 64;
+    if (K > 8) K = 8;
+    hipLaunchKernelGGL(chan_soft_bwd_kernel, dim3(B, 1 + K), dim3(1024), 0, stream, a);
     KSR_LAUNCH_CHECK("chan_soft_bwd");
     const int n = n_out * 64;
     hipLaunchKernelGGL(sum_entries_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dWa_part, B, (long)n, n, dWa);

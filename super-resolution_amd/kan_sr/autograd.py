@@ -6,7 +6,7 @@ import contextlib
 import os
 
 from ctypes import c_float, c_int, c_int64, c_uint64, c_void_p
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 
@@ -632,20 +632,20 @@ class _TrunkFn(torch.autograd.Function):
     than the fused feed+KAN kernel."""
 
     @staticmethod
-    def forward(ctx, x, pre, g, p_drop, seed, names, precision, *params):
+    def forward(ctx, x, pre, g, p_drop, seed, names, precision, sink, *params):
         p = dict(zip(names, params))
         sv: dict = {}
         feat = engine.encoder_forward(x, p, pre, g, sv, p_drop, seed)
         ctx.sv, ctx.x, ctx.p = sv, x, p
-        ctx.cfg = (pre, g, p_drop, seed, names, precision)
+        ctx.cfg = (pre, g, p_drop, seed, names, precision, sink)
         return feat
 
     @staticmethod
     def backward(ctx, gfeat):
-        pre, g, p_drop, seed, names, precision = ctx.cfg
+        pre, g, p_drop, seed, names, precision, sink = ctx.cfg
         engine.set_precision(precision)
         grads: Dict[str, torch.Tensor] = {}
-        ws = _Ws(ctx.x.device, None, g.N)
+        ws = _Ws(ctx.x.device, sink, g.N)
         try:
             trunk_backward(ws, gfeat.contiguous(), ctx.x, ctx.p, pre, g, ctx.sv, p_drop, seed, grads)
             gx = None
@@ -663,14 +663,20 @@ class _TrunkFn(torch.autograd.Function):
         out = []
         for n, t in zip(names, ctx.p.values()):
             gr = grads.get(n)
-            out.append(None if gr is None else gr.reshape(t.shape))
-        return (gx, None, None, None, None, None, None, *out)
+            # with a sink the kernels have written the gradient where the caller wants it: nothing for autograd to add
+            out.append(None if gr is None or sink is not None else gr.reshape(t.shape))
+        return (gx, None, None, None, None, None, None, None, *out)
 
 
-def trunk_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_drop: float, seed: int, precision: str = "fp32"):
+def trunk_train(x, p: Dict[str, torch.Tensor], pre: str, g: Geometry, p_drop: float, seed: int, precision: str = "fp32",
+                sink: Optional[Dict[str, torch.Tensor]] = None):
+    """sink: optional name -> tensor map covering every trunk parameter (adjacent in memory in PARAM_ORDER, as in a flat
+    buffer laid out in module order); the backward writes the parameter gradients there instead of returning them."""
     names = [pre + n for n in PARAM_ORDER if not n.startswith("feed.")]
     params = [p[n] for n in names]
     for t in params:
         if not t.is_contiguous():
             raise KsrError("parameters must be contiguous")
-    return _TrunkFn.apply(x, pre, g, p_drop, seed, names, precision, *params)
+    if sink is not None and any(n not in sink for n in names):
+        raise KsrError("trunk_train: the gradient sink must name every trunk parameter")
+    return _TrunkFn.apply(x, pre, g, p_drop, seed, names, precision, sink, *params)

@@ -72,6 +72,10 @@ class GazeTR(_Container):                   # conv_sep_kan/gazetr.py:69-98
         if attention:
             from .chan_attention import ConvSepKanAttention
             self.feed = ConvSepKanAttention(MID, MID, out_channels)
+            # optional name -> tensor map (names relative to this module): the trunk's backward on the autograd tape then
+            # writes each parameter gradient straight into its tensor and reports none to autograd (TrainStep: views of
+            # its flat gradient buffer, so no accumulation launch per parameter)
+            self.grad_sink = None
         else:
             self.feed = nn.Conv2d(MID, out_channels, kernel_size=1)
 
@@ -194,7 +198,9 @@ class ConvSepKan(nn.Module):
         with torch.set_grad_enabled(needs_grad):
             if needs_grad:
                 from .autograd import trunk_train
-                feat = trunk_train(x, p, pre, g, p_drop, seed, self.precision)
+                sink = self.layers[-1].encoder.encoder.grad_sink
+                feat = trunk_train(x, p, pre, g, p_drop, seed, self.precision,
+                                   None if sink is None else {pre + n: t for n, t in sink.items()})
             else:
                 feat = engine.encoder_forward(x, p, pre, g, None, p_drop, seed)
             if feat.dtype is not torch.float32 and not head_bf16s:

@@ -172,7 +172,9 @@ class TrainStep:
                 prm.grad = self.arena[self.pre + n]   # .grad is a view of the flat buffer
         if self.tape_backward and hasattr(layer, "grad_sink"):
             # the backbone's backward writes each parameter gradient straight into its view (no accumulation pass)
-            layer.grad_sink = {n: self.arena[self.pre + n] for n in self.order}
+            # (the GazeTR trunk under the channel-attention head: the head's own gradients still arrive through autograd)
+            layer.grad_sink = {n: self.arena[self.pre + n] for n in self.order
+                               if not (getattr(model, "attention", False) and n.startswith("feed."))}
         self._steps = 0
         if self.device_state:
             self._ctr = torch.zeros(1, device=dev, dtype=torch.int64)        # step counter = dropout stream word
@@ -383,7 +385,7 @@ class TrainStep:
         gfull = self._gfull
         outd = out.detach()
         self._loss_and_luma_gradient(outd, tgt, gfull, plane, (B, Hh, Wh), 3 * plane)
-        if getattr(m.layers[-1].encoder.encoder, "grad_sink", None) is None:
+        if getattr(m.layers[-1].encoder.encoder, "grad_sink", None) is None or getattr(m, "attention", False):
             self.flat_g.zero_()                   # autograd accumulates into the views
         out.backward(gfull)
         self.out = outd
