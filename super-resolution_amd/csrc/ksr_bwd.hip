@@ -409,7 +409,8 @@ __global__ void __launch_bounds__(256, 2) fn1_stem_bwd_kernel(StemBwdArgs a) {
         const int tb = (int)(t / ((long)tiles_x * tiles_y));
         ksr_halo_fetch<ST>(a.dgate, 64, 0, tb, ty * 4, tx * 32, a.H, a.W, tid, hr);
     };
-    if ((long)blockIdx.x < ntiles) fetch_halo(blockIdx.x);
+    const KsrTileWalk tw = ksr_xcd_tile_walk(ntiles);
+    if (tw.first < tw.end) fetch_halo(tw.first);
 
     // Column sums over tokens on the matrix cores (the scheme of ksr_wg_fuse.h): the wave's 32 x 64 tile of d goes to
     // LDS as swizzled bf16 rows and comes back transposed as the A operand (channels x tokens); the B operand's columns
@@ -425,7 +426,7 @@ __global__ void __launch_bounds__(256, 2) fn1_stem_bwd_kernel(StemBwdArgs a) {
     };
     union Op { s16x4 hv[2]; bf16x8 v; };
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long tile = tw.first; tile < tw.end; tile += tw.step) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const int b = (int)(tile / ((long)tiles_x * tiles_y));
         const int y0 = ty * 4, x0 = tx * 32;
@@ -437,7 +438,7 @@ __global__ void __launch_bounds__(256, 2) fn1_stem_bwd_kernel(StemBwdArgs a) {
         __syncthreads();
         ksr_halo_commit<ST>(sm.halo, tid, hr);
         __syncthreads();
-        if (tile + gridDim.x < ntiles) fetch_halo(tile + gridDim.x);     // in flight during this tile
+        if (tile + tw.step < tw.end) fetch_halo(tile + tw.step);     // in flight during this tile
         // this tile's value half and scalar: requested before the stencil, which covers their latency
         KsrTile<ST> tv;
         ksr_co_fetch<ST>(a.dt, n0w, nvalid, 128, 0, lane, tv);

@@ -42,8 +42,9 @@ __global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
         const int fb = (int)(t / ((long)tiles_x * tiles_y));
         ksr_halo_fetch<ST>(a.in, a.ld, 64 * gi, fb, fty * 4, ftx * 32, a.H, a.W, tid, hr);
     };
-    if (HAHEAD && (long)blockIdx.x < ntiles) fetch(blockIdx.x, 0);
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const KsrTileWalk tw = ksr_xcd_tile_walk(ntiles);
+    if (HAHEAD && tw.first < tw.end) fetch(tw.first, 0);
+    for (long tile = tw.first; tile < tw.end; tile += tw.step) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const int b = (int)(tile / ((long)tiles_x * tiles_y));
         const int y0 = ty * 4, x0 = tx * 32;
@@ -55,7 +56,7 @@ __global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
             __syncthreads();
             if (HAHEAD) {
                 if (gi + 1 < a.groups) fetch(tile, gi + 1);
-                else if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x, 0);
+                else if (tile + tw.step < tw.end) fetch(tile + tw.step, 0);
             }
             float g[32];
 #pragma unroll

@@ -179,6 +179,31 @@ __device__ __forceinline__ unsigned ksr_xcd_contiguous(unsigned wg, unsigned tot
     const unsigned per = total >> 3, rem = total & 7u, xcd = wg & 7u, slot = wg >> 3;
     return xcd < rem ? xcd * (per + 1) + slot : rem * (per + 1) + (xcd - rem) * per + slot;
 }
+// Tile walk of a persistent stencil kernel: for (t = first; t < end; t += step).  XCD x works through the contiguous eighth
+// [x per, (x+1) per) of the tiles, and its resident workgroups take NEIGHBOURING tiles at any one time, so the halo rows
+// and columns that adjacent tiles share are fetched by one L2 once (a plain grid-stride walk hands neighbouring tiles to
+// different XCDs: every L2 fetches the halo again).  A grid that is no multiple of 8 falls back to the grid-stride walk.
+struct KsrTileWalk { long first, end, step; };
+__device__ __forceinline__ KsrTileWalk ksr_xcd_tile_walk(long ntiles) {
+    const unsigned G = gridDim.x;
+    if (G & 7u) return {(long)blockIdx.x, ntiles, (long)G};
+    const long per = (ntiles + 7) >> 3;
+    const long lo = (long)(blockIdx.x & 7u) * per, hi = lo + per < ntiles ? lo + per : ntiles;
+    return {lo + (long)(blockIdx.x >> 3), hi, (long)(G >> 3)};
+}
+// The same walk behind a compile-time switch, for kernels whose template instances are partly stencils: with XCD = false
+// first() / step() are the hardware indices themselves, read where they are used (keeping them in registers of their own
+// made a 254-register instance spill).
+template <bool XCD>
+struct KsrTileWalkT {
+    long first_, end_, step_;
+    __device__ __forceinline__ explicit KsrTileWalkT(long ntiles) : first_(0), end_(ntiles), step_(0) {
+        if constexpr (XCD) { const KsrTileWalk w = ksr_xcd_tile_walk(ntiles); first_ = w.first; end_ = w.end; step_ = w.step; }
+    }
+    __device__ __forceinline__ long first() const { if constexpr (XCD) return first_; else return (long)blockIdx.x; }
+    __device__ __forceinline__ long end() const { return end_; }
+    __device__ __forceinline__ long step() const { if constexpr (XCD) return step_; else return (long)gridDim.x; }
+};
 
 // One hash serves two neighbouring keys (16 bits each): the keep probability is quantised to 1/65536.  `base` is
 // already a full hash of (seed, token, head); the key index enters as a Weyl step followed by ONE xorshift-multiply

@@ -92,7 +92,9 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
         const int nv = (N - n0) < 32 ? (int)(N - n0 > 0 ? N - n0 : 0) : 32;
         ksr_co_fetch<ST, true>(a.in, n0, nv, a.in_ld, 0, lane, ahead);
     };
-    if (AHEAD && (long)blockIdx.x < ntiles) fetch_tile(blockIdx.x);
+    // stencil kernels walk the tiles so that neighbours share an L2; the 1x1 kernels keep the plain grid-stride walk
+    const KsrTileWalkT<spatial> tw(ntiles);
+    if (AHEAD && tw.first() < tw.end()) fetch_tile(tw.first());
     // stencil kernels with bf16 storage: likewise for the halo tile (7 x 16 bytes per thread)
     constexpr bool HAHEAD = spatial && sizeof(ST) == 2;
     KsrHalo<ST> hr;
@@ -101,9 +103,9 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
         const int tb = (int)(t / ((long)tiles_x * tiles_y));
         ksr_halo_fetch<ST>(a.in, a.in_ld, (PRO == PRO_GATE) ? 64 : 0, tb, ty * 4, tx * 32, a.H, a.W, tid, hr);
     };
-    if (HAHEAD && (long)blockIdx.x < ntiles) fetch_halo(blockIdx.x);
+    if (HAHEAD && tw.first() < tw.end()) fetch_halo(tw.first());
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long tile = tw.first(); tile < tw.end(); tile += tw.step()) {
         int b, y, x;
         bool live;
         long n;
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             if (!HAHEAD) fetch_halo(tile);
             ksr_halo_commit<ST>(sm.halo, tid, hr);
             __syncthreads();
-            if (HAHEAD && tile + gridDim.x < ntiles) fetch_halo(tile + gridDim.x);     // in flight during this tile
+            if (HAHEAD && tile + tw.step() < tw.end()) fetch_halo(tile + tw.step());     // in flight during this tile
         } else {
             n = tile * 128 + wv * 32 + tok;
             live = n < N;
@@ -143,7 +145,7 @@ __global__ void __launch_bounds__(256, 2) conv_fwd_kernel(ConvArgs a) {
             if (AHEAD) {
                 if constexpr (PREC == KSR_F32X3) ksr_co_finish_half(xb, lane, ahead, op);
                 else ksr_co_finish<ST>(xb, lane, ahead, op);
-                if (tile + gridDim.x < ntiles) fetch_tile(tile + gridDim.x);
+                if (tile + tw.step() < tw.end()) fetch_tile(tile + tw.step());
             } else {
                 ksr_load32_co<ST>(xb, a.in, n0w, nvalid, a.in_ld, 0, lane, op);
             }
@@ -294,9 +296,10 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
             ynext[k] = in ? w1 * Y[(long)yy * a.W + xx] + b1 : 0.f;
         }
     };
-    if ((long)blockIdx.x < ntiles) fetch_y(blockIdx.x);
+    const KsrTileWalk tw = ksr_xcd_tile_walk(ntiles);
+    if (tw.first < tw.end) fetch_y(tw.first);
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (long tile = tw.first; tile < tw.end; tile += tw.step) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const int b = (int)(tile / ((long)tiles_x * tiles_y));
         const int y0 = ty * 4, x0 = tx * 32;
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(256, 2) stem_gate_fwd_kernel(StemGateArgs a) {
         __syncthreads();                       // the previous tile's readers of u / v are done
         sm.u[tid] = ynext[0];
         if (tid + 256 < SG_YH * SG_YW) sm.u[tid + 256] = ynext[1];
-        if (tile + gridDim.x < ntiles) fetch_y(tile + gridDim.x);     // in flight during this tile
+        if (tile + tw.step < tw.end) fetch_y(tile + tw.step);     // in flight during this tile
         __syncthreads();
         if (tid < SG_VH * SG_VW) {
             const int vy = tid / SG_VW, vx = tid % SG_VW;

@@ -585,8 +585,9 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
         }
     };
     const float Ac = AFF ? a.aff_ab[64 + c] : 0.f, Bc = AFF ? a.aff_ab[192 + c] : 0.f;
-    if ((long)blockIdx.x < ntiles) fetch(blockIdx.x);
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const KsrTileWalk tw = ksr_xcd_tile_walk(ntiles);
+    if (tw.first < tw.end) fetch(tw.first);
+    for (long tile = tw.first; tile < tw.end; tile += tw.step) {
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
         const int y0 = ty * 4, x0 = tx * 32;
         const int y = y0 + row;
@@ -598,7 +599,7 @@ __global__ void __launch_bounds__(256) dwgrad_kernel(DwgArgs a) {
         if constexpr (AFF) { if (tid < HALO_H * HALO_W) halo[tid] = vnext; }
         else ksr_halo_commit<T>(halo, tid, hr);
         __syncthreads();
-        if (tile + gridDim.x < ntiles) fetch(tile + gridDim.x);
+        if (tile + tw.step < tw.end) fetch(tile + tw.step);
         {
 #pragma unroll
             for (int col = 0; col < 32; ++col) {
