@@ -28,7 +28,9 @@ struct WgArgs {
 // accumulates groups of 4 neighbouring output channels of one (tap, ci) entry.  With few entries the lanes split the
 // pixels of a segment between them and the slices are summed through LDS at the end.
 __global__ void __launch_bounds__(256) unet_wgrad_kernel(WgArgs a) {
-    __shared__ __attribute__((aligned(16))) float tile[WG_TILE_FLOATS];
+    // sized by the launch to the tile of this layer (at most WG_TILE_FLOATS): the shallow levels need a third of the
+    // maximum, and the workgroups that then fit on a CU together are what hides the staging latency of each
+    extern __shared__ __attribute__((aligned(16))) float tile[];
     __shared__ float red[1024];
     const int b = blockIdx.z, t = threadIdx.x;
     const int ca = a.mode == 2 ? 1 : a.ca0 + a.ca1, cg4 = a.cg >> 2;
@@ -164,32 +166,43 @@ __global__ void __launch_bounds__(256) unet_wgrad_kernel(WgArgs a) {
 
 struct WgRedArgs { const float* partials; float* out; int B, chunks, E, per_image; };
 
-// 16 entries x 16 slices of the partial rows per workgroup; fixed summation order
-__global__ void __launch_bounds__(256) unet_wgrad_reduce_kernel(WgRedArgs a) {
-    const int le = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int e = blockIdx.x * 16 + le;
-    const long K = a.per_image ? a.chunks : (long)a.B * a.chunks;
-    const long base = a.per_image ? (long)blockIdx.y * a.chunks : 0;
-    __shared__ double red[16][16];
+// 16 entries x 16 slices of the partial rows per workgroup (64 contiguous bytes per row), eight rows in flight per thread;
+// fixed summation order
+constexpr int WGR_OUT = 16, WGR_SL = 16;
+__device__ __forceinline__ void unet_wgrad_reduce_body(const WgRedArgs& a, int block, long K, long base, float* dst) {
+    const int le = threadIdx.x & (WGR_OUT - 1), sl = threadIdx.x / WGR_OUT;
+    const int e = block * WGR_OUT + le;
+    __shared__ double red[WGR_SL][WGR_OUT];
     double s = 0.0;
     if (e < a.E) {
         const float* p = a.partials + base * a.E + e;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         long k = sl;
-        for (; k + 48 < K; k += 64) {
-            s0 += p[k * a.E]; s1 += p[(k + 16) * a.E]; s2 += p[(k + 32) * a.E]; s3 += p[(k + 48) * a.E];
+        for (; k + 7 * WGR_SL < K; k += 8 * WGR_SL) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = p[(k + i * WGR_SL) * a.E];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += v[i];
         }
-        for (; k < K; k += 16) s0 += p[k * a.E];
-        s = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+        for (; k < K; k += WGR_SL) acc[0] += p[k * a.E];
+        s = (((double)acc[0] + (double)acc[1]) + ((double)acc[2] + (double)acc[3])) +
+            (((double)acc[4] + (double)acc[5]) + ((double)acc[6] + (double)acc[7]));
     }
     red[sl][le] = s;
     __syncthreads();
     if (sl == 0 && e < a.E) {
         double tot = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) tot += red[k][le];
-        a.out[(a.per_image ? (long)blockIdx.y * a.E : 0) + e] = (float)tot;
+        for (int k = 0; k < WGR_SL; ++k) tot += red[k][le];
+        dst[e] = (float)tot;
     }
+}
+
+__global__ void __launch_bounds__(256) unet_wgrad_reduce_kernel(WgRedArgs a) {
+    const long K = a.per_image ? a.chunks : (long)a.B * a.chunks;
+    const long base = a.per_image ? (long)blockIdx.y * a.chunks : 0;
+    unet_wgrad_reduce_body(a, (int)blockIdx.x, K, base, a.out + (a.per_image ? (long)blockIdx.y * a.E : 0));
 }
 
 // Several of those reductions in one launch (the deferred form: ksr_reduce_defer / ksr_reduce_flush): workgroup -> (entry,
@@ -204,29 +217,7 @@ __global__ void __launch_bounds__(256) unet_wgrad_reduce_batch_kernel(WgRedBatch
     int i = 0;
     while (i + 1 < b.n && (int)blockIdx.x >= b.first[i + 1]) ++i;
     const WgRedArgs a = b.e[i];
-    const int le = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int e = ((int)blockIdx.x - b.first[i]) * 16 + le;
-    const long K = (long)a.B * a.chunks;
-    __shared__ double red[16][16];
-    double s = 0.0;
-    if (e < a.E) {
-        const float* p = a.partials + e;
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        long k = sl;
-        for (; k + 48 < K; k += 64) {
-            s0 += p[k * a.E]; s1 += p[(k + 16) * a.E]; s2 += p[(k + 32) * a.E]; s3 += p[(k + 48) * a.E];
-        }
-        for (; k < K; k += 16) s0 += p[k * a.E];
-        s = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
-    }
-    red[sl][le] = s;
-    __syncthreads();
-    if (sl == 0 && e < a.E) {
-        double tot = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tot += red[k][le];
-        a.out[e] = (float)tot;
-    }
+    unet_wgrad_reduce_body(a, (int)blockIdx.x - b.first[i], (long)a.B * a.chunks, 0, a.out);
 }
 thread_local WgRedBatch g_unet_red;
 
@@ -641,7 +632,7 @@ int ksr_unet_reduce_pending() { return g_unet_red.n; }
 void ksr_unet_reduce_clear() { g_unet_red.n = 0; }
 
 
-struct WgPlan { int cols, segs, nwg, E; };
+struct WgPlan { int cols, segs, nwg, E, tile_floats; };
 
 static bool wgrad_plan(int mode, int ks, int stride, int ca, int cg, int B, int Ha, int Wa, int Hg, int Wg, WgPlan& p) {
     const int Hi = mode == 1 ? Ha : Hg, Wi = mode == 1 ? Wa : Wg;
@@ -655,17 +646,21 @@ static bool wgrad_plan(int mode, int ks, int stride, int ca, int cg, int B, int 
     p.segs = (Wi + cols_max - 1) / cols_max;
     p.cols = (Wi + p.segs - 1) / p.segs;
     const int tiles = Hi * p.segs;
-    int per_image = 512 / B;
+    // as many workgroups as the GPU can hold at once (8 per CU when the tile is small), each with the same number of tiles
+    int per_image = 2048 / B;
     if (per_image < 1) per_image = 1;
-    p.nwg = tiles < per_image ? tiles : per_image;
+    const int rounds = (tiles + per_image - 1) / per_image;
+    p.nwg = (tiles + rounds - 1) / rounds;
     p.E = (mode == 2 ? 1 : ks * ks * ca) * cg;
+    const int a_w = mode == 0 ? (p.cols - 1) * stride + ks : p.cols;
+    p.tile_floats = g_rows * p.cols * gs * cg + (mode == 2 ? 0 : a_rows * a_w * ca) + 4;
     return true;
 }
 
 extern "C" int64_t ksr_unet_wgrad_slab_floats(int mode, int ks, int ca, int cg, int B, int Ha, int Wa, int Hg, int Wg) {
     const int taps = mode == 0 ? ks * ks : (mode == 1 ? 4 : 1);
     const int64_t E = (int64_t)taps * (mode == 2 ? 1 : ca) * cg;
-    const int per_image = 1024 / B > 0 ? 1024 / B : 1;      // upper bound of the workgroups per image
+    const int per_image = 2048 / B > 0 ? 2048 / B : 1;      // upper bound of the workgroups per image
     return (int64_t)B * per_image * E;
 }
 
@@ -693,8 +688,8 @@ extern "C" int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1
     p.E = (mode == 2 ? 1 : ks * ks * (ca + add_ones)) * cg;
     WgArgs a{a0, a1, ca0, ca1, a_scale, a_shift, g, cg, slab, ks, stride, reflect, mode, Ha, Wa, Hg, Wg, p.cols, p.segs, p.nwg, p.E, add_ones};
     const int E4 = p.E / 4;
-    hipLaunchKernelGGL(unet_wgrad_kernel, dim3((unsigned)p.nwg, (unsigned)((E4 + WG_ENTRIES4 - 1) / WG_ENTRIES4), (unsigned)B), dim3(256), 0,
-                       stream, a);
+    hipLaunchKernelGGL(unet_wgrad_kernel, dim3((unsigned)p.nwg, (unsigned)((E4 + WG_ENTRIES4 - 1) / WG_ENTRIES4), (unsigned)B), dim3(256),
+                       (size_t)p.tile_floats * sizeof(float), stream, a);
     KSR_LAUNCH_CHECK("unet_wgrad");
     WgRedArgs r{slab, out, B, p.nwg, p.E, per_image};
     if (!per_image && ksr_reduce_deferring()) {
@@ -705,11 +700,11 @@ extern "C" int ksr_unet_wgrad(const float* a0, int ca0, const float* a1, int ca1
         }
         if (b.n == 0) b.first[0] = 0;
         b.e[b.n] = r;
-        b.first[b.n + 1] = b.first[b.n] + (p.E + 15) / 16;
+        b.first[b.n + 1] = b.first[b.n] + (p.E + WGR_OUT - 1) / WGR_OUT;
         ++b.n;
         return KSR_OK;
     }
-    hipLaunchKernelGGL(unet_wgrad_reduce_kernel, dim3((unsigned)((p.E + 15) / 16), (unsigned)(per_image ? B : 1)), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(unet_wgrad_reduce_kernel, dim3((unsigned)((p.E + WGR_OUT - 1) / WGR_OUT), (unsigned)(per_image ? B : 1)), dim3(256), 0, stream, r);
     KSR_LAUNCH_CHECK("unet_wgrad_reduce");
     return KSR_OK;
 }
