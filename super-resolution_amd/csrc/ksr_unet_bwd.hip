@@ -83,31 +83,44 @@ __global__ void __launch_bounds__(256) unet_wgrad_kernel(WgArgs a) {
                 const int ca4 = ca >> 2;
                 const bool pow2 = (ca4 & (ca4 - 1)) == 0;
                 const int sh = 31 - __builtin_clz(ca4);
-                for (int r = 0; r < a_rows; ++r) {
-                    int iy = a.mode == 0 ? y * a.stride + r - pad : y;
-                    bool oky = true;
-                    if (a.reflect) iy = iy < 0 ? -iy : (iy >= a.Ha ? 2 * a.Ha - 2 - iy : iy);
-                    else oky = iy >= 0 && iy < a.Ha;
-                    for (int i = t; i < wcols * ca4; i += 256) {
-                        const int j = pow2 ? i >> sh : i / ca4, ch = (i - j * ca4) << 2;
-                        int ix = a.mode == 0 ? x0 * a.stride + j - pad : x0 + j;
-                        bool ok = oky;
-                        if (a.reflect) ix = ix < 0 ? -ix : (ix >= a.Wa ? 2 * a.Wa - 2 - ix : ix);
-                        else ok = ok && ix >= 0 && ix < a.Wa;
-                        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (ok) {
-                            const long pix = ((long)b * a.Ha + iy) * a.Wa + ix;
-                            if (ch < a.ca0) {
-                                v = *reinterpret_cast<const float4*>(a.a0 + pix * a.ca0 + ch);
-                                if (a.a_scale) {
-                                    const float4 s4 = *reinterpret_cast<const float4*>(a.a_scale + ch), t4 = *reinterpret_cast<const float4*>(a.a_shift + ch);
-                                    v = make_float4(fmaxf(fmaf(v.x, s4.x, t4.x), 0.f), fmaxf(fmaf(v.y, s4.y, t4.y), 0.f),
-                                                    fmaxf(fmaf(v.z, s4.z, t4.z), 0.f), fmaxf(fmaf(v.w, s4.w, t4.w), 0.f));
-                                }
-                            } else v = *reinterpret_cast<const float4*>(a.a1 + pix * a.ca1 + ch - a.ca0);
+                const int per_row = wcols * ca4, total = a_rows * per_row;
+                // all rows as one index space, four loads in flight per thread before the first is stored (a row of the
+                // shallow levels is 258 pixels: row by row, 256 threads took two dependent round trips for each)
+                for (int base = 0; base < total; base += 1024) {
+                    float4 v[4];
+                    int dsti[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = base + u * 256 + t;
+                        v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        dsti[u] = -1;
+                        if (i < total) {
+                            const int r = i / per_row, ir = i - r * per_row;
+                            const int j = pow2 ? ir >> sh : ir / ca4, ch = (ir - j * ca4) << 2;
+                            int iy = a.mode == 0 ? y * a.stride + r - pad : y;
+                            int ix = a.mode == 0 ? x0 * a.stride + j - pad : x0 + j;
+                            bool ok = true;
+                            if (a.reflect) {
+                                iy = iy < 0 ? -iy : (iy >= a.Ha ? 2 * a.Ha - 2 - iy : iy);
+                                ix = ix < 0 ? -ix : (ix >= a.Wa ? 2 * a.Wa - 2 - ix : ix);
+                            } else ok = iy >= 0 && iy < a.Ha && ix >= 0 && ix < a.Wa;
+                            dsti[u] = (r * a_w + j) * ca + ch;
+                            if (ok) {
+                                const long pix = ((long)b * a.Ha + iy) * a.Wa + ix;
+                                if (ch < a.ca0) {
+                                    v[u] = *reinterpret_cast<const float4*>(a.a0 + pix * a.ca0 + ch);
+                                    if (a.a_scale) {
+                                        const float4 s4 = *reinterpret_cast<const float4*>(a.a_scale + ch), t4 = *reinterpret_cast<const float4*>(a.a_shift + ch);
+                                        v[u] = make_float4(fmaxf(fmaf(v[u].x, s4.x, t4.x), 0.f), fmaxf(fmaf(v[u].y, s4.y, t4.y), 0.f),
+                                                           fmaxf(fmaf(v[u].z, s4.z, t4.z), 0.f), fmaxf(fmaf(v[u].w, s4.w, t4.w), 0.f));
+                                    }
+                                } else v[u] = *reinterpret_cast<const float4*>(a.a1 + pix * a.ca1 + ch - a.ca0);
+                            }
                         }
-                        *reinterpret_cast<float4*>(al + (r * a_w + j) * ca + ch) = v;
                     }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (dsti[u] >= 0) *reinterpret_cast<float4*>(al + dsti[u]) = v[u];
                 }
             } else
             for (int i = t; i < a_rows * wcols * ca; i += 256) {
@@ -134,7 +147,23 @@ __global__ void __launch_bounds__(256) unet_wgrad_kernel(WgArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (!live[k]) continue;
-            for (int x = slice; x < cols; x += nsl) {
+            // four pixels in flight (same order of the sums: the loop is a chain of LDS latencies otherwise)
+            int x = slice;
+            for (; x + 3 * nsl < cols; x += 4 * nsl) {
+                float av[4];
+                float4 gv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    av[u] = one[k] ? 1.f : al[a_off[k] + (x + u * nsl) * as * ca];
+                    gv[u] = *reinterpret_cast<const float4*>(gl + g_off[k] + (x + u * nsl) * gs * a.cg);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc[k][0] = fmaf(av[u], gv[u].x, acc[k][0]); acc[k][1] = fmaf(av[u], gv[u].y, acc[k][1]);
+                    acc[k][2] = fmaf(av[u], gv[u].z, acc[k][2]); acc[k][3] = fmaf(av[u], gv[u].w, acc[k][3]);
+                }
+            }
+            for (; x < cols; x += nsl) {
                 const float av = one[k] ? 1.f : al[a_off[k] + x * as * ca];
                 const float4 gv = *reinterpret_cast<const float4*>(gl + g_off[k] + x * gs * a.cg);
                 acc[k][0] = fmaf(av, gv.x, acc[k][0]); acc[k][1] = fmaf(av, gv.y, acc[k][1]);
