@@ -412,6 +412,14 @@ __global__ void __launch_bounds__(256) unet_s2_dgrad_kernel(S2Args a) {
     const bool live = pr < a.H * a.W;
     const int p = live ? pr : 0;                             // idle lanes redo pixel 0 (they take part in the butterfly)
     const int iy = p / a.W, ix = p - iy * a.W;
+    // this workgroup's slice of the weights, [9][cz][CT], in LDS: the innermost loop reads CT of them per gradient channel,
+    // which from global memory was a chain of cache latencies (49 us for 8 x 64 x 64 pixels, 80 -> 32 channels)
+    extern __shared__ __attribute__((aligned(16))) float s2w[];
+    for (int i = threadIdx.x; i < 9 * a.cz * (CT / 4); i += 256) {
+        const int row = i / (CT / 4), q = i - row * (CT / 4);
+        *reinterpret_cast<float4*>(s2w + row * CT + 4 * q) = *reinterpret_cast<const float4*>(a.weight + (long)row * a.cin + c0 + 4 * q);
+    }
+    __syncthreads();
     float acc[CT];
 #pragma unroll
     for (int i = 0; i < CT; ++i) acc[i] = 0.f;
@@ -428,14 +436,21 @@ __global__ void __launch_bounds__(256) unet_s2_dgrad_kernel(S2Args a) {
                     const int tx = rx + 1 - kx;
                     if (tx < 0 || (tx & 1) || (tx >> 1) >= a.Wo) continue;
                     const float* g = a.dz + (((long)b * a.Ho + (ty >> 1)) * a.Wo + (tx >> 1)) * a.cz;
-                    const float* w = a.weight + (long)(ky * 3 + kx) * a.cz * a.cin + c0;
+                    const float* w = s2w + (ky * 3 + kx) * a.cz * CT;
                     for (int co = 4 * sub; co < a.cz; co += 4 * LPP) {
                         const float4 g4 = *reinterpret_cast<const float4*>(g + co);
                         const float gv[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
+                        for (int e = 0; e < 4; ++e) {
+                            float wr[CT];
 #pragma unroll
-                            for (int i = 0; i < CT; ++i) acc[i] = fmaf(gv[e], w[(long)(co + e) * a.cin + i], acc[i]);
+                            for (int i = 0; i < CT; i += 4) {
+                                const float4 w4 = *reinterpret_cast<const float4*>(w + (co + e) * CT + i);
+                                wr[i] = w4.x; wr[i + 1] = w4.y; wr[i + 2] = w4.z; wr[i + 3] = w4.w;
+                            }
+#pragma unroll
+                            for (int i = 0; i < CT; ++i) acc[i] = fmaf(gv[e], wr[i], acc[i]);
+                        }
                     }
                 }
             }
@@ -475,6 +490,10 @@ __global__ void __launch_bounds__(256) unet_att_mix_bwd_kernel(MixBwdArgs a) {
     const int t = threadIdx.x;
     __shared__ float g[32 * 32 + 80], at_a[32 * 16], at_k[16 * 32], M[32 * 32], T1[32 * 32], dTs[32 * 32], dT1[32 * 32], dM[32 * 32];
     __shared__ float s_a[32 * 16], s_k[16 * 32], da[32 * 16], dk[16 * 32], dN[80], dtemp[2][32 + 16];
+    // the two c x c weights are read inside the products' inner loops: from global memory each of those loops was a chain
+    // of memory latencies (67 us for c = 32)
+    __shared__ float wvs[32 * 32], wps[32 * 32];
+    for (int i = t; i < cc; i += 256) { wvs[i] = a.wv[i]; wps[i] = a.wp[i]; }
     for (int e = t; e < E; e += 256) {
         int A, Bc;
         gram_entry(e, c, A, Bc);
@@ -524,7 +543,7 @@ __global__ void __launch_bounds__(256) unet_att_mix_bwd_kernel(MixBwdArgs a) {
     for (int idx = t; idx < cc; idx += 256) {      // T1[i][ci] = vscale * sum_i' M[i][i'] Wv[i'][ci]
         const int i = idx / c, ci = idx % c, h = i / ch;
         float s = 0.f;
-        for (int ii = 0; ii < ch; ++ii) s = fmaf(M[i * c + h * ch + ii], a.wv[(h * ch + ii) * c + ci], s);
+        for (int ii = 0; ii < ch; ++ii) s = fmaf(M[i * c + h * ch + ii], wvs[(h * ch + ii) * c + ci], s);
         T1[idx] = s * a.vscale;
     }
     __syncthreads();
@@ -535,7 +554,7 @@ __global__ void __launch_bounds__(256) unet_att_mix_bwd_kernel(MixBwdArgs a) {
         float s1 = 0.f, s2 = 0.f;
         for (int k = 0; k < c; ++k) {
             s1 = fmaf(dTs[k * c + r], T1[q * c + k], s1);          // dWp[co=r][i=q] = sum_ci dT[ci][co] T1[i][ci]
-            s2 = fmaf(a.wp[k * c + r], dTs[q * c + k], s2);         // dT1[i=r][ci=q] = sum_co Wp[co][i] dT[ci][co]
+            s2 = fmaf(wps[k * c + r], dTs[q * c + k], s2);         // dT1[i=r][ci=q] = sum_co Wp[co][i] dT[ci][co]
         }
         dpar[cc + idx] = s1;
         dT1[idx] = s2;
@@ -546,7 +565,7 @@ __global__ void __launch_bounds__(256) unet_att_mix_bwd_kernel(MixBwdArgs a) {
         float s1 = 0.f, s2 = 0.f;
         const bool same = r / ch == q / ch;
         for (int k = 0; k < c; ++k) {
-            if (same) s1 = fmaf(dT1[r * c + k], a.wv[q * c + k], s1);   // dM[i=r][i'=q] = vscale sum_ci dT1[i][ci] Wv[i'][ci]
+            if (same) s1 = fmaf(dT1[r * c + k], wvs[q * c + k], s1);   // dM[i=r][i'=q] = vscale sum_ci dT1[i][ci] Wv[i'][ci]
             s2 = fmaf(M[k * c + r], dT1[k * c + q], s2);                 // dWv[i'=r][ci=q] = vscale sum_i M[i][i'] dT1[i][ci]
         }
         dM[idx] = same ? s1 * a.vscale : 0.f;
@@ -776,15 +795,16 @@ extern "C" int ksr_unet_s2_dgrad(const float* dz, int cz, const float* weight, f
     KSR_CHECK_ARG(dz && weight && dx && B > 0 && H >= 2 && W >= 2, "unet_s2_dgrad: bad argument");
     KSR_UNSUPPORTED(cz % 4 != 0 || cin % 4 != 0, "unet_s2_dgrad: channel counts (%d, %d) must be multiples of 4", cz, cin);
     KSR_UNSUPPORTED(B > 65535, "unet_s2_dgrad: batch %d too large for one launch", B);
+    KSR_UNSUPPORTED((size_t)9 * cz * 8 * sizeof(float) > 64 * 1024, "unet_s2_dgrad: %d gradient channels do not fit the weight tile", cz);
     S2Args a{dz, weight, dx, cz, cin, H, W, (H - 1) / 2 + 1, (W - 1) / 2 + 1};
     const bool split = (long)B * H * W <= 32768 && cz >= 16;             // 4 lanes per pixel
     const unsigned gx = (unsigned)((H * W + (split ? 63 : 255)) / (split ? 64 : 256));
     if (cin % 8 == 0) {
-        if (split) hipLaunchKernelGGL((unet_s2_dgrad_kernel<8, 4>), dim3(gx, (unsigned)B, (unsigned)(cin / 8)), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((unet_s2_dgrad_kernel<8, 1>), dim3(gx, (unsigned)B, (unsigned)(cin / 8)), dim3(256), 0, stream, a);
+        if (split) hipLaunchKernelGGL((unet_s2_dgrad_kernel<8, 4>), dim3(gx, (unsigned)B, (unsigned)(cin / 8)), dim3(256), (size_t)9 * cz * 8 * sizeof(float), stream, a);
+        else hipLaunchKernelGGL((unet_s2_dgrad_kernel<8, 1>), dim3(gx, (unsigned)B, (unsigned)(cin / 8)), dim3(256), (size_t)9 * cz * 8 * sizeof(float), stream, a);
     } else {
-        if (split) hipLaunchKernelGGL((unet_s2_dgrad_kernel<4, 4>), dim3(gx, (unsigned)B, (unsigned)(cin / 4)), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((unet_s2_dgrad_kernel<4, 1>), dim3(gx, (unsigned)B, (unsigned)(cin / 4)), dim3(256), 0, stream, a);
+        if (split) hipLaunchKernelGGL((unet_s2_dgrad_kernel<4, 4>), dim3(gx, (unsigned)B, (unsigned)(cin / 4)), dim3(256), (size_t)9 * cz * 4 * sizeof(float), stream, a);
+        else hipLaunchKernelGGL((unet_s2_dgrad_kernel<4, 1>), dim3(gx, (unsigned)B, (unsigned)(cin / 4)), dim3(256), (size_t)9 * cz * 4 * sizeof(float), stream, a);
     }
     KSR_LAUNCH_CHECK("unet_s2_dgrad");
     return KSR_OK;
