@@ -42,15 +42,32 @@ def _gram(dz, dz_c0, J, a, a_c0, HW, B, want_sq):
     return out, tail
 
 
+# Layout of the q | k | v branches' parameters in one buffer: [192][64] projection weights, [192] biases, [192][9] depthwise
+# weights, [192] depthwise biases (offsets in floats; every block starts on a 16-byte boundary)
+_QKV_CAT = (0, 192 * 64, 192 * 64 + 192, 192 * 64 + 192 + 192 * 9, 192 * 64 + 192 + 192 * 9 + 192)
+_QKV_ROWS = (64 * 64, 64, 64 * 9, 64)          # floats per branch in each block
+
+
+def _qkv_views(buf):
+    o = _QKV_CAT
+    return buf[o[0]:o[1]].view(192, 64), buf[o[1]:o[2]], buf[o[2]:o[3]].view(192, 9), buf[o[3]:o[4]]
+
+
+def _qkv_pieces(buf):
+    """The twelve per-parameter pieces of such a buffer, in the order of ConvSepKanAttention._qkv_params()."""
+    return [buf[_QKV_CAT[k] + i * n:_QKV_CAT[k] + (i + 1) * n] for k, n in enumerate(_QKV_ROWS) for i in range(3)]
+
+
 class _QkvFn(torch.autograd.Function):
     """qkv [N,192] = dw3x3(pw(x)) for the three branches at once (weights concatenated q | k | v)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, dw_w, dw_b, dims, precision):
+    def forward(ctx, x, w, b, dw_w, dw_b, dims, precision, sink=None):
         B, H, W = dims
         engine.set_precision(precision)
         L = lib()
         N = x.shape[0]
+        ctx.sink = sink
         pq = _act(x.device, N, 192)
         check(L.ksr_pointwise_fwd(ptr(x), ptr(w), ptr(b), ptr(pq), c_int(192), c_int(0), c_int(B), c_int(H), c_int(W),
                                   stream()), "ksr_pointwise_fwd")
@@ -73,12 +90,18 @@ class _QkvFn(torch.autograd.Function):
         dpq = _act(dev, N, 192)
         check(L.ksr_chan_dw_bwd(ptr(dqkv), ptr(dw_w), ptr(dpq), c_int(192), c_int(3), c_int(B), c_int(H), c_int(W),
                                 stream()), "ksr_chan_dw_bwd")
-        g_dw_w, g_dw_b = _new(dev, 192, 9), _new(dev, 192)
+        sink = ctx.sink
+        if sink is not None:
+            # the four concatenated gradients in one buffer, handed to the twelve parameters' tensors by one multi-tensor copy
+            gcat = _new(dev, _QKV_CAT[-1])
+            g_w, g_b, g_dw_w, g_dw_b = _qkv_views(gcat)
+        else:
+            g_w, g_b = _new(dev, 192, 64), _new(dev, 192)
+            g_dw_w, g_dw_b = _new(dev, 192, 9), _new(dev, 192)
         slab = _new(dev, max(3 * 512 * 640, int(L.ksr_wgrad_slab_floats(c_int(192), c_int(64)))))
         # the three branches' depthwise weight gradients in one launch (channel groups q | k | v of the same two tensors)
         check(L.ksr_dwconv_wgrad_groups(ptr(pq), c_int(192), c_int(0), ptr(dqkv), c_int(192), c_int(0), c_int(3), ptr(slab),
                                         ptr(g_dw_w), ptr(g_dw_b), c_int(B), c_int(H), c_int(W), stream()), "ksr_dwconv_wgrad_groups")
-        g_w, g_b = _new(dev, 192, 64), _new(dev, 192)
         check(L.ksr_wgrad(ptr(dpq), c_int(192), c_int(0), c_int(192), ptr(x), c_int(64), c_int(0), c_int(64),
                           ptr(None), c_int(0), c_int(0), c_int64(N), ptr(slab), ptr(g_w), ptr(g_b), c_int(0), c_int(0),
                           stream()), "ksr_wgrad")
@@ -87,7 +110,10 @@ class _QkvFn(torch.autograd.Function):
             dx = _act(dev, N, 64)
             check(L.ksr_pointwise_bwd(ptr(dpq), c_int(192), ptr(w), ptr(dx), c_int(B), c_int(H), c_int(W), stream()),
                   "ksr_pointwise_bwd")
-        return dx, g_w, g_b, g_dw_w, g_dw_b, None, None
+        if sink is not None:
+            torch._foreach_copy_(sink, _qkv_pieces(gcat))
+            return dx, None, None, None, None, None, None, None
+        return dx, g_w, g_b, g_dw_w, g_dw_b, None, None, None
 
 
 class _AttnCoreFn(torch.autograd.Function):
@@ -142,9 +168,10 @@ class _AttnKanFn(torch.autograd.Function):
     map with one matrix per image, M_b = W_a softmax(q^ k^T), which the fused feed+KAN kernel takes as per-image weights."""
 
     @staticmethod
-    def forward(ctx, qkv, wa, ba, x, dims, precision, n_coef, knots, spline_order, r):
+    def forward(ctx, qkv, wa, ba, x, dims, precision, n_coef, knots, spline_order, r, sink=None):
         B, H, W = dims
         HW = H * W
+        ctx.sink = sink
         engine.set_precision(precision)
         L = lib()
         dev = qkv.device
@@ -199,14 +226,18 @@ class _AttnKanFn(torch.autograd.Function):
         Gd, colsum = _new(dev, B, P, 64), _new(dev, B, J)
         check(L.ksr_gram_batched_kan(ptr(gparam), c_int(J), ptr(qkv), c_int(192), c_int(128), c_int(64), c_int64(HW), c_int(B),
                                      ptr(slab), ptr(Gd), ptr(colsum), c_int(r), c_int(n_coef), stream()), "ksr_gram_batched_kan")
-        g_ba = _new(dev, P)
+        sink = ctx.sink                         # (gradient tensors of a_proj's weight [P,64] and bias [P]) or None
+        g_ba = _new(dev, P) if sink is None else sink[1]
         check(L.ksr_sum_entries(ptr(colsum), c_int(B), c_int64(J), c_int(P), ptr(g_ba), stream()), "ksr_sum_entries")
-        Mqk, part, g_wa = _new(dev, B, 128, 128), _new(dev, B, P, 64), _new(dev, P, 64)
+        Mqk, part = _new(dev, B, 128, 128), _new(dev, B, P, 64)
+        g_wa = _new(dev, P, 64) if sink is None else sink[0]
         check(L.ksr_chan_soft_bwd(ptr(Gd), ptr(A), ptr(S), ptr(nrm), ptr(wa), ptr(Mqk), ptr(part), ptr(g_wa), c_int(P),
                                   c_int(B), stream()), "ksr_chan_soft_bwd")
         check(L.ksr_chan_apply(ptr(qkv), c_int(192), c_int(0), c_int(128), ptr(Mqk), c_int(0), ptr(None), ptr(dqkv),
                                c_int(192), c_int(0), c_int(128), c_int(B), c_int(HW), stream()), "ksr_chan_apply")
-        return dqkv, g_wa, g_ba, gx, None, None, None, None, None, None
+        if sink is not None:
+            g_wa = g_ba = None
+        return dqkv, g_wa, g_ba, gx, None, None, None, None, None, None, None
 
 
 def _to_nhwc(t):
@@ -229,6 +260,14 @@ class ConvSepKanAttention(nn.Module):
         self.a_dw = nn.Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, groups=out_channels)
         self.in_channels, self.mid_channels, self.out_channels = in_channels, mid_channels, out_channels
         self.precision = "fp32"
+        # optional name -> tensor map (this module's parameter names): forward_kan's backward then writes the parameter
+        # gradients into those tensors and reports none to autograd (TrainStep: views of its flat gradient buffer)
+        self.grad_sink = None
+
+    def _qkv_params(self):
+        """The q | k | v branches' parameters, kind by kind: projection weights, biases, depthwise weights, depthwise biases."""
+        return [getattr(getattr(self, n + m), kind) for m, kind in (("_proj", "weight"), ("_proj", "bias"), ("_dw", "weight"),
+                                                                    ("_dw", "bias")) for n in "qkv"]
 
     def forward_nhwc(self, x, dims, q=None, k=None, v=None):
         """x [N,64] (N = B*H*W pixels, NHWC order) -> [N,out]; q, k, v optional precomputed [N,64] branches."""
@@ -250,6 +289,14 @@ class ConvSepKanAttention(nn.Module):
                                  self.precision)
 
     def _qkv(self, x, dims):
+        sink = self.grad_sink
+        if sink is not None and torch.is_grad_enabled():
+            # one concatenation for the four kernel operands; the gradients go straight to the sink
+            with torch.no_grad():
+                w, b, dw_w, dw_b = _qkv_views(torch.cat([t.reshape(-1) for t in self._qkv_params()]))
+            names = [n + m + "." + kind for m, kind in (("_proj", "weight"), ("_proj", "bias"), ("_dw", "weight"), ("_dw", "bias"))
+                     for n in "qkv"]
+            return _QkvFn.apply(x.contiguous(), w, b, dw_w, dw_b, dims, self.precision, [sink[n].view(-1) for n in names])
         w = torch.cat([getattr(self, n + "_proj").weight.reshape(64, 64) for n in "qkv"])
         b = torch.cat([getattr(self, n + "_proj").bias for n in "qkv"])
         dw_w = torch.cat([getattr(self, n + "_dw").weight.reshape(64, 9) for n in "qkv"])
@@ -268,6 +315,11 @@ class ConvSepKanAttention(nn.Module):
             raise KsrError(f"ConvSepKanAttention(precision={self.precision!r}) needs {want} GPU features (the HIP path is the "
                            "only path)")
         qkv = self._qkv(feat, dims)
+        sink = self.grad_sink
+        if sink is not None and torch.is_grad_enabled():
+            return _AttnKanFn.apply(qkv, self.a_proj.weight.detach().reshape(self.out_channels, 64), self.a_proj.bias.detach(),
+                                    x_img.contiguous(), dims, self.precision, n_coef, tuple(knots), spline_order, r,
+                                    (sink["a_proj.weight"].view(self.out_channels, 64), sink["a_proj.bias"]))
         return _AttnKanFn.apply(qkv, self.a_proj.weight.reshape(self.out_channels, 64), self.a_proj.bias, x_img.contiguous(),
                                 dims, self.precision, n_coef, tuple(knots), spline_order, r)
 

@@ -172,9 +172,14 @@ class TrainStep:
                 prm.grad = self.arena[self.pre + n]   # .grad is a view of the flat buffer
         if self.tape_backward and hasattr(layer, "grad_sink"):
             # the backbone's backward writes each parameter gradient straight into its view (no accumulation pass)
-            # (the GazeTR trunk under the channel-attention head: the head's own gradients still arrive through autograd)
+            # (the GazeTR trunk under the channel-attention head: the head has a sink of its own, for the fused head + KAN
+            # path; a_dw, which the reference's forward never uses, keeps the zeros the flat buffer starts with)
             layer.grad_sink = {n: self.arena[self.pre + n] for n in self.order
                                if not (getattr(model, "attention", False) and n.startswith("feed."))}
+            if getattr(model, "attention", False):
+                from .module import FUSED_ATTENTION_HEAD
+                if FUSED_ATTENTION_HEAD:
+                    layer.feed.grad_sink = {n[len("feed."):]: self.arena[self.pre + n] for n in self.order if n.startswith("feed.")}
         self._steps = 0
         if self.device_state:
             self._ctr = torch.zeros(1, device=dev, dtype=torch.int64)        # step counter = dropout stream word
@@ -385,7 +390,8 @@ class TrainStep:
         gfull = self._gfull
         outd = out.detach()
         self._loss_and_luma_gradient(outd, tgt, gfull, plane, (B, Hh, Wh), 3 * plane)
-        if getattr(m.layers[-1].encoder.encoder, "grad_sink", None) is None or getattr(m, "attention", False):
+        enc = m.layers[-1].encoder.encoder
+        if getattr(enc, "grad_sink", None) is None or (getattr(m, "attention", False) and enc.feed.grad_sink is None):
             self.flat_g.zero_()                   # autograd accumulates into the views
         out.backward(gfull)
         self.out = outd
