@@ -535,8 +535,21 @@ def main():
                     predict_rgb(model, xi)
                 torch.cuda.synchronize()
             tr = (time.perf_counter() - tr) / 20
+            # the same frame with bf16 activation storage (separately stated tolerance: Y' cosine >= 0.999, rel-L2 <= 2e-2
+            # against fp32, tests/test_gpu_benched_path.py); reported beside the fp32 number, never as `value`
+            model.precision = "bf16s"
+            with torch.no_grad():
+                for _ in range(5):
+                    model(xi)
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                for _ in range(20):
+                    model(xi)
+                torch.cuda.synchronize()
+            tb = (time.perf_counter() - tb) / 20
+            model.precision = "fp32"
             inference = {"value": round(3840 * 2160 / 1e6 / ti, 1), "unit": "MP/s", "ms_per_frame": round(ti * 1e3, 4),
-                         "ms_per_frame_rgb_in_rgb_out": round(tr * 1e3, 4),
+                         "ms_per_frame_rgb_in_rgb_out": round(tr * 1e3, 4), "ms_per_frame_bf16_storage": round(tb * 1e3, 4),
                          "workload": "x4 SR inference fp32 eval (split-fp32 products), 960x540 -> 3840x2160, 1 GPU (BASELINE configs[1])"}
             # the same step in the other precision modes (fresh model and step each; 3 warm-up + 10 timed steps), so that
             # the run that reports the bf16-storage headline also records the fp32-storage and exact-fp32 times

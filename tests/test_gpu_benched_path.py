@@ -116,6 +116,34 @@ def test_bf16_modes_vs_oracle_at_contract_tolerance(precision, B, H, W, seed):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("precision", ["bf16", "bf16s"])
+def test_bf16_inference_single_image_vs_oracle_and_fp32(precision):
+    """Inference (no autograd tape: engine.forward_infer, the single-image kernels of the 4K workload) with bf16 MFMA
+    operands ("bf16") and bf16 activation storage as well ("bf16s"), training-setup initialisation.  One 40 x 56 image
+    against the fp32 ORACLE, and one 270 x 480 frame (a quarter of BASELINE configs[1]) against this build's fp32 mode.
+    Stated tolerance (bf16 modes, forward): Y' plane cosine >= 0.999 and rel-L2 <= 2e-2; the chroma planes (bilinear
+    upsampling, fp32 in every mode) to 1e-6.  Measured on the full 960 x 540 frame with tools/infer_bf16s_probe.py: cosine
+    0.99999, rel-L2 5e-3 in both modes."""
+    m, x, _, yr, _ = _model_and_oracle_grads(1, 40, 56, seed=5, init="setup")
+    xc = x.cuda()
+
+    def check(y, ref):
+        a, b = y[:, 0].double().flatten().cpu(), ref[:, 0].double().flatten().cpu()
+        cos = float((a * b).sum() / (a.norm() * b.norm()))
+        assert cos >= 0.999 and rel_l2(a, b) <= 2e-2, (cos, rel_l2(a, b))
+        assert float((y[:, 1:].cpu() - ref[:, 1:].cpu()).abs().max()) <= 1e-6
+
+    with torch.no_grad():
+        m.precision = precision
+        y = m(xc)
+        check(y, yr)
+        big = torch.rand(1, 3, 270, 480, generator=torch.Generator().manual_seed(2)).cuda()
+        yb = m(big)
+        m.precision = "fp32"
+        check(yb, m(big))
+    assert y.dtype is torch.float32 and yb.shape == (1, 3, 1080, 1920)
+
+
 def test_cfg3_full_size_step_side_stream_on_off_bit_equal(monkeypatch):
     """BASELINE configs[2] at its full per-GPU size (64 patches of 128x128, bf16 storage, dropout live, reference
     loss): one TrainStep with the second stream on and one with it off, same dropout stream: the flat gradient
