@@ -220,7 +220,7 @@ def measured_traffic_unet(entry: str):
     """HBM bytes per launch of a UNet entry point, averaged over its kernel instances by their launch counts in the
     committed PMC summary (ksr_unet_wgrad: plus its reduce kernel), or None."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_train_unet_b8_pmc_hbm.csv")
+    path = os.path.join(ROOT, "profiles", "r03_train_unet_b8_pmc_hbm.csv")
     if entry not in UNET_ENTRY_KERNELS or not os.path.exists(path):
         return None
     with open(path) as fh:
@@ -501,7 +501,7 @@ def main():
             roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
         if unet and B == 8:
             roofline["traffic"] = measured_traffic_unet(dom)
-            roofline["traffic_source"] = "profiles/r01_train_unet_b8_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
+            roofline["traffic_source"] = "profiles/r03_train_unet_b8_pmc_hbm.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2)"
             roofline["algorithmic_bytes_per_launch"] = int(kmodel[2] * npx / max(1, len(prof[dom]) // nlaunch)) if kmodel else None
         roofline["avg_launch_ms"] = round(avg_ms, 4)
         roofline["launches_per_step"] = len(prof[dom]) // nlaunch
