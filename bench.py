@@ -47,10 +47,11 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4, train: bool = 
     # bf16 storage: the fn_2 (ffn2, ffn4) and ffn3.pointwise2 weight gradients are accumulated inside their data-gradient
     # kernels (ksr_gate_pw_bwd_wg / _v, ksr_pw2_bwd_wg), the in-projection's in ksr_in_proj_bwd_wg: they leave ksr_wgrad
     fused = act_bytes == 2
-    # ... out_proj's in ksr_batch_tx_layer_bwd_out_wg, ffn3.pointwise1's in ksr_pw1_bwd_wg
-    wg_jk = 64 * P + 2 * (64 * 32 + 32 * 64) + 128 * 64 + (0 if fused else 64 * 64 + 2 * 64 * 64 + 3 * 64 * 64 + 2 * 192 * 64)
-    wg_bytes = 4 * ((P + 64) + 2 * ((64 + 32) + (32 + 64)) + (128 + 64)
-                    + (0 if fused else (64 + 64) + 2 * (64 + 64) + 2 * 64 * 3 + (64 + 64) + 2 * (192 + 64)))
+    # ... out_proj's in ksr_batch_tx_layer_bwd_out_wg, ffn3.pointwise1's in ksr_pw1_bwd_wg, linear1's and linear2's in
+    # ksr_batch_tx_layer_bwd_ln1_wg / _mlp_wg: ksr_wgrad keeps feed's (P x 64) and ffn4.fn_1's (128 x 64)
+    wg_jk = 64 * P + 128 * 64 + (0 if fused else 2 * (64 * 32 + 32 * 64) + 64 * 64 + 2 * 64 * 64 + 3 * 64 * 64 + 2 * 192 * 64)
+    wg_bytes = 4 * ((P + 64) + (128 + 64)
+                    + (0 if fused else 2 * ((64 + 32) + (32 + 64)) + (64 + 64) + 2 * (64 + 64) + 2 * 64 * 3 + (64 + 64) + 2 * (192 + 64)))
     lin_post = 2 * (64 * 64 + 64 * 32 + 32 * 64)
     models = {
         # forward
@@ -84,6 +85,10 @@ def kernel_models(S: int, P: int, bf16: bool, act_bytes: int = 4, train: bool = 
         "ksr_batch_tx_layer_bwd_token": (("hbm", 2 * (lin_post - 64 * 64), 2048 + 1280, pk) if fused else
                                          ("hbm", 2 * lin_post, 2048 + 2304, pk)),
         "ksr_batch_tx_layer_bwd_out_wg": ("hbm", 2 * 2 * 2 * 64 * 64, 2 * 768, pk),
+        # the token backward in two kernels (both layers): LayerNorm 2 + linear2 (+ its weight gradient): dy, xhat2, hmid in,
+        # du2, dpre out; then linear1 + LayerNorm 1 (+ linear1's weight gradient against xhat1): du2, dpre, xhat1 in, du1 out
+        "ksr_batch_tx_layer_bwd_mlp_wg": ("hbm", 2 * 2 * 2 * 64 * 32, 2 * 4 * ((64 + 64 + 32) + (64 + 32)), pk),
+        "ksr_batch_tx_layer_bwd_ln1_wg": ("hbm", 2 * 2 * 2 * 64 * 32, 2 * 4 * ((64 + 32 + 64) + 64), pk),
         # bf16 storage: the forward's output is not read (rowsum(dO * O) comes from the recomputed probabilities)
         "ksr_batch_attn_bwd": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + (0 if fused else 64) + 64 + 192), f32),
         "ksr_batch_tx_layer_bwd_attn": ("hbm" if bf16 else "mfma", 2 * 640 * S, 2 * 4 * (192 + 64 + 64 + 192), f32),
