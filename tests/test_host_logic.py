@@ -362,3 +362,26 @@ def test_reference_seemore_cannot_be_constructed():
     for lr_space in ("linear", "exp", "double"):
         with pytest.raises(TypeError, match="mlp_ratio"):
             mod.SeemoRe(lr_space=lr_space)                         # RME passes mlp_ratio to GatedFFN (:176 vs :355-358)
+
+
+def test_attention_head_parameter_buffer_layout():
+    """The q | k | v branches' twelve parameters in one buffer (ConvSepKanAttention._qkv with a gradient sink): the four views
+    the kernels take equal the per-kind concatenations of the plain path, and piece i of the buffer is parameter i of
+    _qkv_params() — the order in which the backward's multi-tensor copy hands the gradients to the sink."""
+    from kan_sr import chan_attention as ca
+    torch.manual_seed(0)
+    head = ca.ConvSepKanAttention(64, 64, 40)
+    params = head._qkv_params()
+    assert len(params) == 12
+    buf = torch.cat([t.detach().reshape(-1) for t in params])
+    assert buf.numel() == ca._QKV_CAT[-1] and all(o % 4 == 0 for o in ca._QKV_CAT)
+    w, b, dw_w, dw_b = ca._qkv_views(buf)
+    assert torch.equal(w, torch.cat([getattr(head, n + "_proj").weight.detach().reshape(64, 64) for n in "qkv"]))
+    assert torch.equal(b, torch.cat([getattr(head, n + "_proj").bias.detach() for n in "qkv"]))
+    assert torch.equal(dw_w, torch.cat([getattr(head, n + "_dw").weight.detach().reshape(64, 9) for n in "qkv"]))
+    assert torch.equal(dw_b, torch.cat([getattr(head, n + "_dw").bias.detach() for n in "qkv"]))
+    named = dict(head.named_parameters())
+    names = [n + m + "." + kind for m, kind in (("_proj", "weight"), ("_proj", "bias"), ("_dw", "weight"), ("_dw", "bias")) for n in "qkv"]
+    for piece, prm, name in zip(ca._qkv_pieces(buf), params, names):
+        assert prm is named[name]
+        assert torch.equal(piece, prm.detach().reshape(-1)), name
