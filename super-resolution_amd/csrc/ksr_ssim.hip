@@ -13,6 +13,7 @@
 #include "ksr_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -77,10 +78,14 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
     const int nruns = (wo + SV_RUN - 1) / SV_RUN;
     const float c1 = 0.01f * 0.01f, c2 = 0.03f * 0.03f;
     float sum = 0.f;
-    for (int t = t_begin; t < t_end; ++t) {
-        // channel fastest: a workgroup's chunk of tasks holds the planes of one (strip, band, image) - the luma plane, which
-        // also writes the derivative maps, costs 1.4 x a chroma plane, and every workgroup is resident from the start
-        const int c = t % a.C, strip = (t / a.C) % ns, band = (t / (a.C * ns)) % nb, b = t / (a.C * ns * nb);
+    // One (strip, band, image, plane) task.  LUMA: the plane whose derivative maps the gradient kernel reads: five filtered
+    // quantities (p, t, pp, tt, pt), the two variances clamped at zero one by one, as the gradient needs the sign of the
+    // prediction's.  The chroma planes only contribute their value, in which the variances appear as their sum: four
+    // quantities (p, t, pp + tt, pt), a third fewer multiply-adds in both filter passes and no second LDS row; the sum is
+    // clamped as a whole, which differs from the separate clamps only where a window is flat to rounding (|d| < 1e-8
+    // against c2 = 9e-4).
+    auto task = [&](auto luma_tag, int strip, int band, int b, int c) {
+        constexpr bool LUMA = decltype(luma_tag)::value;
         const int x0 = strip * wo, y0 = band * bh;
         const int xo_end = min(Wi, x0 + wo), yo_end = min(Hi, y0 + bh);      // windows [y0, yo_end) x [x0, xo_end)
         const int y_in_end = yo_end + SS_K - 1;                                  // input rows [y0, y_in_end)
@@ -102,9 +107,9 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
         };
         fetch(0);
         f32x2 sa[SS_K], sb[SS_K];
-        float sc[SS_K];
+        float sc[LUMA ? SS_K : 1];
 #pragma unroll
-        for (int j = 0; j < SS_K; ++j) { sa[j] = f32x2{0.f, 0.f}; sb[j] = f32x2{0.f, 0.f}; sc[j] = 0.f; }
+        for (int j = 0; j < SS_K; ++j) { sa[j] = f32x2{0.f, 0.f}; sb[j] = f32x2{0.f, 0.f}; if constexpr (LUMA) sc[j] = 0.f; }
         for (int m = 0; m < nbatch; ++m) {
             // ---- vertical: input row y0 + 11 m + rr is tap k of window row y - k, kept in register set (rr - k) mod 11
 #pragma unroll
@@ -112,21 +117,22 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
                 const f32x2 x = {clamp01(pv[rr]), clamp01(tv[rr])};
                 const f32x2 xx = x * x;
                 const float pt = x[0] * x[1];
+                const f32x2 y2 = LUMA ? xx : f32x2{xx[0] + xx[1], pt};      // chroma: (pp + tt, pt)
 #pragma unroll
                 for (int k = 0; k < SS_K; ++k) {
                     const int j = (rr - k + SS_K) % SS_K;
                     const float g = w.g[k < 6 ? k : 10 - k];      // the window is symmetric: six weights live in scalar registers
-                    if (k == 0) { sa[j] = g * x; sb[j] = g * xx; sc[j] = g * pt; }
-                    else { sa[j] += g * x; sb[j] += g * xx; sc[j] += g * pt; }
+                    if (k == 0) { sa[j] = g * x; sb[j] = g * y2; if constexpr (LUMA) sc[j] = g * pt; }
+                    else { sa[j] += g * x; sb[j] += g * y2; if constexpr (LUMA) sc[j] += g * pt; }
                 }
                 const int jc = (rr + 1) % SS_K;             // window row y - 10 is complete
                 v4[rr][tid] = make_float4(sa[jc][0], sa[jc][1], sb[jc][0], sb[jc][1]);
-                v1[rr][tid] = sc[jc];
+                if constexpr (LUMA) v1[rr][tid] = sc[jc];
             }
             if (m + 1 < nbatch) fetch(m + 1);
             __syncthreads();
             // ---- horizontal: thread = (batch row rr, run j of 11 windows), j fastest
-            const bool want_maps = a.maps && c == 0;        // uniform over the workgroup
+            const bool want_maps = LUMA && a.maps;         // uniform over the workgroup
             const int hrr = tid / nruns, hj = tid - hrr * nruns, q0 = hj * SV_RUN;
             const int uy = y0 + SV_R * m + hrr - (SS_K - 1);
             const bool hrow = tid < SV_R * nruns && uy >= y0 && uy < yo_end;
@@ -134,22 +140,24 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
             if (hrow) {
                 const int rr = hrr;
                 f32x2 ha[SV_RUN], hb[SV_RUN];
-                float hc[SV_RUN];
+                float hc[LUMA ? SV_RUN : 1];
 #pragma unroll
-                for (int o = 0; o < SV_RUN; ++o) { ha[o] = f32x2{0.f, 0.f}; hb[o] = f32x2{0.f, 0.f}; hc[o] = 0.f; }
+                for (int o = 0; o < SV_RUN; ++o) { ha[o] = f32x2{0.f, 0.f}; hb[o] = f32x2{0.f, 0.f}; if constexpr (LUMA) hc[o] = 0.f; }
 #pragma unroll
                 for (int i = 0; i < SV_SPAN; ++i) {
                     // at most four columns' reads ahead of their use: hoisting all 21 costs 100 registers
                     if (i % 4 == 0) __builtin_amdgcn_sched_barrier(0);
                     const int q = q0 + i;        // < SV_V1_LD; columns past the strip only feed windows past it
                     const float4 v = v4[rr][q];
-                    const float vc = v1[rr][q];
+                    float vc = 0.f;
+                    if constexpr (LUMA) vc = v1[rr][q];
                     const f32x2 va = {v.x, v.y}, vb = {v.z, v.w};
 #pragma unroll
                     for (int o = 0; o < SV_RUN; ++o) {
                         if (i - o < 0 || i - o >= SS_K) continue;
                         const float g = w.g[i - o < 6 ? i - o : 10 - (i - o)];
-                        ha[o] += g * va; hb[o] += g * vb; hc[o] += g * vc;
+                        ha[o] += g * va; hb[o] += g * vb;
+                        if constexpr (LUMA) hc[o] += g * vc;
                     }
                 }
 #pragma unroll
@@ -157,12 +165,21 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
                     const int ux = x0 + q0 + o;
                     dmap[o][0] = dmap[o][1] = dmap[o][2] = 0.f;
                     if (ux >= xo_end) continue;
-                    const float m1 = ha[o][0], m2 = ha[o][1], e11 = hb[o][0], e22 = hb[o][1], e12 = hc[o];
-                    const float vp_raw = e11 - m1 * m1, vt_raw = e22 - m2 * m2;
-                    const float vp = fmaxf(vp_raw, 0.f), vt = fmaxf(vt_raw, 0.f);
-                    const float cov = e12 - m1 * m2;
+                    const float m1 = ha[o][0], m2 = ha[o][1];
+                    float vp_raw = 0.f, cov, D2;
+                    if constexpr (LUMA) {
+                        const float e11 = hb[o][0], e22 = hb[o][1], e12 = hc[o];
+                        vp_raw = e11 - m1 * m1;
+                        const float vt_raw = e22 - m2 * m2;
+                        cov = e12 - m1 * m2;
+                        D2 = fmaxf(vp_raw, 0.f) + fmaxf(vt_raw, 0.f) + c2;
+                    } else {
+                        // the two variances enter S only as their sum: one filtered quantity E[pp + tt] for both
+                        cov = hb[o][1] - m1 * m2;
+                        D2 = fmaxf(hb[o][0] - m1 * m1 - m2 * m2, 0.f) + c2;
+                    }
                     const float N1 = 2.f * m1 * m2 + c1, D1 = m1 * m1 + m2 * m2 + c1;
-                    const float N2 = 2.f * cov + c2, D2 = vp + vt + c2;
+                    const float N2 = 2.f * cov + c2;
                     const float i1 = __builtin_amdgcn_rcpf(D1), i2 = __builtin_amdgcn_rcpf(D2);
                     const float inv = i1 * i2;
                     const float S = N1 * N2 * inv;
@@ -200,6 +217,12 @@ __global__ void __launch_bounds__(SV_T, 2) ssim_fwd_cols_kernel(SsimArgs a, Ssim
             }
             __syncthreads();       // the next batch's vertical pass overwrites v4 / v1
         }
+    };
+    for (int t = t_begin; t < t_end; ++t) {
+        // channel fastest: a workgroup's chunk of tasks holds the planes of one (strip, band, image) - the luma plane, which
+        // also writes the derivative maps, costs 1.4 x a chroma plane, and every workgroup is resident from the start
+        const int c = t % a.C, strip = (t / a.C) % ns, band = (t / (a.C * ns)) % nb, b = t / (a.C * ns * nb);
+        if (c == 0) task(std::true_type{}, strip, band, b, c); else task(std::false_type{}, strip, band, b, c);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
