@@ -163,7 +163,7 @@ def measured_traffic(entry: str):
 # entry point -> device kernel names (prefix match) of the attention-head workload, for the PMC lookup
 ATTN_ENTRY_KERNELS = {
     "ksr_feed_kan_fwd_img": ("feed_kan_fwd_kernel",), "ksr_feed_kan_bwd_img": ("feed_kan_bwd_kernel",),
-    "ksr_chan_dw_fwd": ("chan_dw_kernel",), "ksr_chan_dw_bwd": ("chan_dw_kernel",), "ksr_chan_apply": ("chan_apply_kernel",),
+    "ksr_chan_dw_fwd": ("chan_dw_kernel",), "ksr_chan_dw_bwd": ("chan_dw_kernel",), "ksr_chan_dw_bwd_dx": ("chan_dw_bwd_dx_kernel",), "ksr_chan_apply": ("chan_apply_kernel",),
     "ksr_batch_attn_bwd": ("attn_bwd_dma_kernel",), "ksr_batch_tx_layer_bwd_token": ("tx_bwd_token_kernel",),
     "ksr_batch_qkv_attn_fwd": ("qkv_attn_fwd_dma_kernel",), "ksr_in_proj_bwd_wg": ("inproj_bwd_fused_kernel",),
     "ksr_batch_tx_layer_post_fwd": ("tx_layer_fwd_kernel",), "ksr_ssim_fwd": ("ssim_fwd_cols_kernel",),
@@ -215,6 +215,8 @@ def attn_head_kernel_models(P: int, act_bytes: int):
         "ksr_feed_kan_fwd_img": ("hbm", 2 * 64 * P + 400, a + 4 + 4 * 16 + 128, pk),        # v in, Y' and (uw, S) out
         "ksr_feed_kan_bwd_img": ("hbm", 2 * 64 * P + 800, 64 + 4 + 128 + a + lane, pk),    # dY', x, (uw, S) in, dv and gparam out
         "ksr_pointwise_bwd": ("hbm", 2 * 192 * 64, 3 * a + a, pk),
+        # bf16 storage: the two above in one kernel (dqkv in; dpq for the weight gradients and dx out)
+        "ksr_chan_dw_bwd_dx": ("hbm", 2 * 9 * 192 + 2 * 192 * 64, 3 * a + 3 * a + a, pk),
     }
 
 

@@ -492,7 +492,8 @@ int ksr_bilinear_up_to_rgb(const float* x_lr, const float* y_hr, int64_t y_batch
  * Forward:  ksr_pointwise_fwd(n_out=192) -> ksr_chan_dw_fwd -> ksr_gram_batched(q, k, want_sq) ->
  *           ksr_chan_soft_fwd -> ksr_chan_apply(v, M).
  * Backward: ksr_gram_batched(dy, v) -> ksr_chan_soft_bwd -> ksr_chan_apply(dy, M^T) / ksr_chan_apply([q|k], Mqk)
- *           -> ksr_chan_dw_bwd -> ksr_dwconv_wgrad x3, ksr_wgrad, ksr_pointwise_bwd.
+ *           -> ksr_chan_dw_bwd -> ksr_dwconv_wgrad x3, ksr_wgrad, ksr_pointwise_bwd (bf16 storage: ksr_chan_dw_bwd_dx
+ *           does the first and the last in one kernel).
  * In the bf16-storage mode (ksr_set_precision) the [N, C] tensors of ksr_chan_dw_fwd / _bwd and ksr_chan_apply are bf16 like
  * those of every other kernel of the chain (channel counts, row lengths and offsets then multiples of 8); the per-image
  * matrices stay fp32.
@@ -505,6 +506,12 @@ int ksr_chan_dw_fwd(const float* in, const float* dw_w, const float* dw_b, float
 /* Its data gradient (transposed depthwise conv). */
 int ksr_chan_dw_bwd(const float* dout, const float* dw_w, float* din, int ld, int groups, int B, int H, int W,
                     ksr_stream_t stream);
+/* The same for q | k | v at once (ld = 192, groups = 3) with the data gradient of the three 1x1 projections
+ * (conv_sep_kan_attention.py:16-37, q_proj / k_proj / v_proj) in the kernel's epilogue: din [N,192] = convT(dout),
+ * dx [N,64] = din W, pw_w = W [192][64] (the projections' weights, q | k | v).  Replaces ksr_chan_dw_bwd followed by
+ * ksr_pointwise_bwd(n_out = 192) in the bf16-storage mode (the only mode it supports), bit-equal to that pair. */
+int ksr_chan_dw_bwd_dx(const float* dout, const float* dw_w, const float* pw_w, float* din, float* dx, int B, int H, int W,
+                       ksr_stream_t stream);
 
 /* Batched Gram product over pixels (the q k^T of conv_sep_kan_attention.py:65 and the dy^T v of its
  * backward): for each of nb entries (consecutive runs of tokens_per_entry pixels)

@@ -80,6 +80,77 @@ __global__ void __launch_bounds__(256, 2) chan_dw_kernel(DwArgs a) {
     }
 }
 
+// ---- transposed depthwise 3x3 of q | k | v with the data gradient of their 1x1 projections in the epilogue (bf16 storage) ----
+// din [N,192] = convT(dout) as chan_dw_kernel<__bf16, true>, and dx [N,64] = din W (W [192][64]: the three projections'
+// weights, q | k | v): a lane's 32 results per group are already the token-per-lane operand of ksr_wave_gemm (half h holds
+// channels 64 g + 32 h + i: MapHL{96}, the layout ksr_pointwise_bwd's kernel uses, so the sums keep its order), which
+// saves that kernel's pass over din (402 MB per launch at 64 x 128 x 128 pixels).  LDS: the halo tile, the 192 x 64 weight
+// fragments (24 KB) and nothing else - the depthwise table of the current group lives in the halo tile's padding and is
+// restaged with every group's halo (its 576 weights are requested together with that halo, one (tile, group) ahead).
+struct DwDxArgs { const float* dout; const float* dw_w; const float* pw_w; float* din; float* dx; int B, H, W; };
+
+__global__ void __launch_bounds__(256, 2) chan_dw_bwd_dx_kernel(DwDxArgs a) {
+    using ST = __bf16;
+    __shared__ __attribute__((aligned(16))) float halo[HALO_FLOATS];
+    __shared__ __attribute__((aligned(16))) float frag[ksr_frag_floats_p<KSR_BF16S>(96, 2)];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tok = lane & 31, h = lane >> 5;
+    ksr_stage_weights<KSR_BF16S, 96, 2, true>(frag, nullptr, a.pw_w, 64, nullptr, MapHL{32}, MapHL{96}, tid, 256);
+    const int HW = a.H * a.W;
+    const int tiles_x = (a.W + 31) / 32, tiles_y = (a.H + 3) / 4;
+    const long ntiles = (long)a.B * tiles_y * tiles_x;
+    KsrHalo<ST> hr;
+    float twr[3];
+    auto fetch = [&](long t, int gi) {
+        const int ftx = (int)(t % tiles_x), fty = (int)((t / tiles_x) % tiles_y);
+        const int fb = (int)(t / ((long)tiles_x * tiles_y));
+        ksr_halo_fetch<ST>(a.dout, 192, 64 * gi, fb, fty * 4, ftx * 32, a.H, a.W, tid, hr);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int i = tid + 256 * k;                // element i = tap * 64 + channel of the [tap][channel] table, taps flipped
+            twr[k] = i < 9 * 64 ? a.dw_w[gi * 576 + (i & 63) * 9 + (8 - (i >> 6))] : 0.f;
+        }
+    };
+    const KsrTileWalk tw = ksr_xcd_tile_walk(ntiles);
+    if (tw.first < tw.end) fetch(tw.first, 0);
+    for (long tile = tw.first; tile < tw.end; tile += tw.step) {
+        const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y);
+        const int b = (int)(tile / ((long)tiles_x * tiles_y));
+        const int y0 = ty * 4, x0 = tx * 32;
+        const int y = y0 + wv, x = x0 + tok;
+        float xall[96];
+#pragma unroll
+        for (int gi = 0; gi < 3; ++gi) {
+            __syncthreads();           // the previous group's readers (and the previous tile's transposers) are done
+            ksr_halo_commit<ST>(halo, tid, hr);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int i = tid + 256 * k;
+                if (i < 9 * 64) halo[(i >> 2) * HALO_LD + 64 + (i & 3)] = twr[k];
+            }
+            __syncthreads();
+            if (gi + 1 < 3) fetch(tile, gi + 1);
+            else if (tile + tw.step < tw.end) fetch(tile + tw.step, 0);
+            float g[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) g[i] = 0.f;
+            ksr_dwconv_lane_pad(halo, wv, tok, h, g);
+            if (y < a.H && x < a.W) ksr_storen<ST, 32>(a.din, ((long)b * HW + (long)y * a.W + x) * 192 + 64 * gi + 32 * h, g);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) xall[32 * gi + i] = g[i];
+        }
+        __syncthreads();               // every wave is done with the halo tile: its pixel rows serve as the transposers
+        f32x16 acc[2];
+        ksr_wave_gemm<KSR_BF16S, 96, 2>(frag, nullptr, xall, acc, lane);
+        float o[32];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { o[q] = acc[0][q]; o[16 + q] = acc[1][q]; }
+        const long n0w = (long)b * HW + (long)y * a.W + x0;
+        const int nvalid = (y < a.H) ? (a.W - x0 < 32 ? a.W - x0 : 32) : 0;
+        ksr_store32_co<ST>(halo + wv * KSR_XPOSE_FLOATS, a.dx, n0w, nvalid, 64, 0, lane, o);
+    }
+}
+
 // ---- per-image 1x1 conv: out[n, :NOUT] = W_b(n) in[n, :KIN] + bias -----------------------------------
 // Lane half h holds input channels [h*kin_h, (h+1)*kin_h) and produces outputs [h*nout_h, (h+1)*nout_h).
 struct ApArgs {
@@ -423,6 +494,21 @@ extern "C" int ksr_chan_dw_bwd(const float* dout, const float* dw_w, float* din,
     if (st16) hipLaunchKernelGGL((chan_dw_kernel<__bf16, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((chan_dw_kernel<float, true>), grid, dim3(256), 0, stream, a);
     KSR_LAUNCH_CHECK("chan_dw_bwd");
+    return KSR_OK;
+}
+
+// ksr_chan_dw_bwd for the three branches at once (ld = 192, groups = 3) followed by the data gradient of their 1x1
+// projections, in one kernel: din [N,192] = convT(dout), dx [N,64] = din W with pw_w = W [192][64] (the q | k | v projection
+// weights).  bf16-storage mode only (every [N, C] tensor bf16).
+extern "C" int ksr_chan_dw_bwd_dx(const float* dout, const float* dw_w, const float* pw_w, float* din, float* dx, int B, int H,
+                                  int W, hipStream_t stream) {
+    KSR_CHECK_ARG(dout && dw_w && pw_w && din && dx, "chan_dw_bwd_dx: null pointer");
+    KSR_UNSUPPORTED(ksr_prec() != KSR_BF16S, "chan_dw_bwd_dx: bf16-storage mode only (ksr_chan_dw_bwd + ksr_pointwise_bwd otherwise)");
+    if (int rc = dims_ok(B, H, W, "chan_dw_bwd_dx")) return rc;
+    DwDxArgs a{dout, dw_w, pw_w, din, dx, B, H, W};
+    const long ntiles = (long)B * ((H + 3) / 4) * ((W + 31) / 32);
+    hipLaunchKernelGGL(chan_dw_bwd_dx_kernel, dim3((unsigned)(ntiles < 512 ? ntiles : 512)), dim3(256), 0, stream, a);
+    KSR_LAUNCH_CHECK("chan_dw_bwd_dx");
     return KSR_OK;
 }
 

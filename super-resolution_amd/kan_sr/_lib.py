@@ -36,7 +36,7 @@ class _Proxy:
 
     def __getattr__(self, name):
         fn = getattr(self._cdll, name)
-        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad", "_finalize", "_mix", "_merge", "_dgrad", "_batch", "_wg", "_v", "_l1", "_input", "_img", "_kan", "_flush", "_groups", "_lnf")):
+        if PROFILE is None or not name.endswith(("_fwd", "_bwd", "_up", "_wgrad", "_sum", "colreduce", "_token", "_attn", "_loss", "_step", "outer2", "_batched", "_apply", "_entries", "_ycbcr", "_rgb", "_grad", "_finalize", "_mix", "_merge", "_dgrad", "_batch", "_wg", "_v", "_l1", "_input", "_img", "_kan", "_flush", "_groups", "_lnf", "_bwd_dx")):
             return fn
 
         def timed(*args):
@@ -99,7 +99,7 @@ EXPORTS = [
     "ksr_wgrad_slab_floats", "ksr_wgrad", "ksr_colreduce", "ksr_dwconv_wgrad", "ksr_stem_scalar_wgrad", "ksr_outer2",
     "ksr_l1_y_loss", "ksr_l1_y_loss_static", "ksr_adam_step", "ksr_adam_step_dev", "ksr_set_dropout_seed_source", "ksr_comm_unique_id", "ksr_comm_init", "ksr_allreduce_sum", "ksr_comm_nranks",
     "ksr_comm_destroy",
-    "ksr_pointwise_bwd", "ksr_chan_dw_fwd", "ksr_chan_dw_bwd", "ksr_gram_slab_floats", "ksr_gram_batched",
+    "ksr_pointwise_bwd", "ksr_chan_dw_fwd", "ksr_chan_dw_bwd", "ksr_chan_dw_bwd_dx", "ksr_gram_slab_floats", "ksr_gram_batched",
     "ksr_chan_soft_fwd", "ksr_chan_soft_bwd", "ksr_sum_entries", "ksr_chan_apply",
     "ksr_rgb_to_ycbcr", "ksr_ycbcr_to_rgb", "ksr_bilinear_up_to_rgb",
     "ksr_ssim_slab_floats", "ksr_ssim_fwd", "ksr_ssim_y_grad", "ksr_ssim_l1_slab_floats", "ksr_ssim_y_grad_l1",

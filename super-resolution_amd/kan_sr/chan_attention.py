@@ -58,6 +58,10 @@ def _qkv_pieces(buf):
     return [buf[_QKV_CAT[k] + i * n:_QKV_CAT[k] + (i + 1) * n] for k, n in enumerate(_QKV_ROWS) for i in range(3)]
 
 
+# bf16 storage: ksr_chan_dw_bwd and ksr_pointwise_bwd of the q | k | v branches as one kernel (False: the two launches)
+FUSED_DW_BWD_DX = True
+
+
 class _QkvFn(torch.autograd.Function):
     """qkv [N,192] = dw3x3(pw(x)) for the three branches at once (weights concatenated q | k | v)."""
 
@@ -88,8 +92,17 @@ class _QkvFn(torch.autograd.Function):
         N = x.shape[0]
         dqkv = dqkv.contiguous()
         dpq = _act(dev, N, 192)
-        check(L.ksr_chan_dw_bwd(ptr(dqkv), ptr(dw_w), ptr(dpq), c_int(192), c_int(3), c_int(B), c_int(H), c_int(W),
-                                stream()), "ksr_chan_dw_bwd")
+        # bf16 storage: the projections' data gradient in the epilogue of the transposed depthwise conv (dpq is not read again
+        # for it)
+        dx = None
+        fused_dx = FUSED_DW_BWD_DX and ctx.needs_input_grad[0] and dpq.dtype is torch.bfloat16
+        if fused_dx:
+            dx = _act(dev, N, 64)
+            check(L.ksr_chan_dw_bwd_dx(ptr(dqkv), ptr(dw_w), ptr(w), ptr(dpq), ptr(dx), c_int(B), c_int(H), c_int(W), stream()),
+                  "ksr_chan_dw_bwd_dx")
+        else:
+            check(L.ksr_chan_dw_bwd(ptr(dqkv), ptr(dw_w), ptr(dpq), c_int(192), c_int(3), c_int(B), c_int(H), c_int(W),
+                                    stream()), "ksr_chan_dw_bwd")
         sink = ctx.sink
         if sink is not None:
             # the four concatenated gradients in one buffer, handed to the twelve parameters' tensors by one multi-tensor copy
@@ -105,8 +118,7 @@ class _QkvFn(torch.autograd.Function):
         check(L.ksr_wgrad(ptr(dpq), c_int(192), c_int(0), c_int(192), ptr(x), c_int(64), c_int(0), c_int(64),
                           ptr(None), c_int(0), c_int(0), c_int64(N), ptr(slab), ptr(g_w), ptr(g_b), c_int(0), c_int(0),
                           stream()), "ksr_wgrad")
-        dx = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and not fused_dx:
             dx = _act(dev, N, 64)
             check(L.ksr_pointwise_bwd(ptr(dpq), c_int(192), ptr(w), ptr(dx), c_int(B), c_int(H), c_int(W), stream()),
                   "ksr_pointwise_bwd")

@@ -281,3 +281,43 @@ def test_attention_head_model_bf16_storage_vs_oracle():
             cos = float(torch.dot(got, ref) / (got.norm() * ref.norm() + 1e-30))
             assert cos >= 0.99, (n, cos)
             assert rel_l2(got, ref) <= 0.15, (n, rel_l2(got, ref))
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 32, 32), (3, 9, 21), (1, 5, 70)])
+def test_fused_dw_bwd_and_projection_gradient_is_bit_equal_to_the_two_kernels(B, H, W):
+    """bf16 storage: ksr_chan_dw_bwd_dx (transposed depthwise conv of q | k | v with the projections' data gradient in its
+    epilogue) against ksr_chan_dw_bwd followed by ksr_pointwise_bwd on the same inputs: both outputs bit-equal (the same
+    products in the same order), on sizes with ragged tiles; and the pair itself is held to the oracle by the head's
+    gradient tests above."""
+    from ctypes import c_int
+    from kan_sr import engine
+    from kan_sr._lib import check, lib, ptr, stream
+    torch.manual_seed(B * 100 + W)
+    N = B * H * W
+    dqkv = torch.randn(N, 192, device="cuda").to(torch.bfloat16)
+    dw_w = torch.randn(192, 9, device="cuda") * 0.3
+    w = torch.randn(192, 64, device="cuda") * 0.1
+    L = lib()
+    engine.set_precision("bf16s")
+    try:
+        dpq_a = torch.empty(N, 192, device="cuda", dtype=torch.bfloat16)
+        dx_a = torch.empty(N, 64, device="cuda", dtype=torch.bfloat16)
+        check(L.ksr_chan_dw_bwd(ptr(dqkv), ptr(dw_w), ptr(dpq_a), c_int(192), c_int(3), c_int(B), c_int(H), c_int(W), stream()),
+              "ksr_chan_dw_bwd")
+        check(L.ksr_pointwise_bwd(ptr(dpq_a), c_int(192), ptr(w), ptr(dx_a), c_int(B), c_int(H), c_int(W), stream()),
+              "ksr_pointwise_bwd")
+        dpq_b = torch.full((N, 192), float("nan"), device="cuda", dtype=torch.bfloat16)
+        dx_b = torch.full((N, 64), float("nan"), device="cuda", dtype=torch.bfloat16)
+        check(L.ksr_chan_dw_bwd_dx(ptr(dqkv), ptr(dw_w), ptr(w), ptr(dpq_b), ptr(dx_b), c_int(B), c_int(H), c_int(W), stream()),
+              "ksr_chan_dw_bwd_dx")
+        torch.cuda.synchronize()
+    finally:
+        engine.set_precision("fp32")
+    assert torch.equal(dpq_a, dpq_b)
+    assert torch.equal(dx_a, dx_b)
+    # and against a plain evaluation of the projection gradient from the stored (bf16) depthwise gradient
+    ref = dpq_a.float() @ w.to(torch.bfloat16).float()
+    assert rel_l2(dx_b.float().cpu(), ref.cpu()) <= 1e-2
+    # the fp32 mode refuses
+    rc = L.ksr_chan_dw_bwd_dx(ptr(dqkv), ptr(dw_w), ptr(w), ptr(dpq_b), ptr(dx_b), c_int(B), c_int(H), c_int(W), stream())
+    assert rc != 0
