@@ -21,3 +21,15 @@ x, t = torch.rand(B, 3, 128, 128, device=dev), torch.rand(B, 3, 512, 512, device
 for _ in range(8):
     ts.step(x, t)
 torch.cuda.synchronize()
+
+# host time of a step (enqueue only) against the time the GPU needs for it: with the host slower, the step is bound by the
+# Python launch path, not by the kernels
+import time  # noqa: E402
+N = 50
+t0 = time.perf_counter()
+for _ in range(N):
+    ts.step(x, t)
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"B={B}: host enqueue {t_host / N * 1e3:.3f} ms/step, with the GPU drained {t_all / N * 1e3:.3f} ms/step", flush=True)
