@@ -66,7 +66,9 @@ __global__ void __launch_bounds__(256, 2) dgrad_kernel(BwdArgs a) {
     __shared__ BwdSmem<PREC, KIN, BPRO> sm;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int tok = lane & 31, h = lane >> 5;
-    ksr_stage_weights<PREC, KH, 2, true>(sm.frag, nullptr, a.wt, 64, nullptr, MapHL{32}, MapHL{KH}, tid, 256);
+    // the fused-weight-gradient instances sit at the register limit: with the 16-wide staging prologue the allocator
+    // placed their spills in the tile loop (gate_pw_bwd_v 0.131 -> 0.158 ms), so they keep the narrow one
+    ksr_stage_weights<PREC, KH, 2, true, WGF ? 1 : 16>(sm.frag, nullptr, a.wt, 64, nullptr, MapHL{32}, MapHL{KH}, tid, 256);
     if (BPRO != BPRO_PLAIN) ksr_stage_dw<true>(sm.dww, a.dw_w, tid);
     if (BEPI == BEPI_STEM && tid < 64) sm.p2w[tid] = a.p2w[tid];
     if (AFF) sm.aff[tid] = a.aff_ab[tid];

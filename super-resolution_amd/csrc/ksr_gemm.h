@@ -94,33 +94,50 @@ __host__ __device__ constexpr int ksr_bias_floats(int NB) { return NB * 32; }
 // fragment order.  frag[((blk*(KH/4) + s/4)*64 + lane)*4 + s%4] = W(out(h(rho), 16*blk+q(rho)), in(hh, s))
 // for lane = rho + 32*hh.  biasfrag[(blk*2 + h)*16 + q] = bias[out(h, 16*blk+q)].
 // Called by all threads of the workgroup; caller synchronises afterwards.
-template <int PREC, int KH, int NB, bool TRANS, class OutMap, class InMap>
+template <int PREC, int KH, int NB, bool TRANS, int CH = 16, class OutMap, class InMap>
 __device__ __forceinline__ void ksr_stage_weights(float* __restrict__ frag, float* __restrict__ biasfrag,
                                                   const float* __restrict__ W, int ldw,
                                                   const float* __restrict__ bias, OutMap om, InMap im,
                                                   int tid, int nthreads) {
     static_assert(KH % 8 == 0, "KH must be a multiple of 8");
-    const int total = NB * KH * 64;
+    constexpr int total = NB * KH * 64;
     __bf16* frag16 = reinterpret_cast<__bf16*>(frag);
-    for (int idx = tid; idx < total; idx += nthreads) {
-        // fp32: idx = ((blk*(KH/4) + s/4)*64 + lane)*4 + s%4 ; bf16: ((blk*(KH/8) + s/8)*64 + lane)*8 + s%8
-        constexpr int G = (PREC != KSR_F32) ? 8 : 4;
-        const int s_lo = idx % G;
-        const int lane = (idx / G) & 63;
-        const int rest = idx / (G * 64);
-        const int s = (rest % (KH / G)) * G + s_lo;
-        const int blk = rest / (KH / G);
-        const int rho = lane & 31, hh = lane >> 5;
-        const int o = om(ksr_row_half(rho), 16 * blk + ksr_row_reg(rho));
-        const int i = im(hh, s);
-        float v = 0.f;
-        if (o >= 0 && i >= 0) v = TRANS ? W[(long)i * ldw + o] : W[(long)o * ldw + i];
-        if (PREC == KSR_F32X3) {
-            __bf16 t[3];
-            ksr_split3(v, t);
-            frag16[idx] = t[0]; frag16[total + idx] = t[1]; frag16[2 * total + idx] = t[2];
-        } else if (PREC != KSR_F32) frag16[idx] = (__bf16)v;
-        else frag[idx] = v;
+    // Sixteen elements per thread are requested before the first is converted and stored: the gather is one 4-byte load
+    // per element, and element by element (the compiler kept four in flight) a 64 x 64 weight took eight dependent trips
+    // to the L2 at the head of every launch of every kernel with weights - 5 of the ~9 us a launch costs before its first
+    // tile, whatever the batch.  (CH = 1 is the element-by-element loop: for a kernel at the register limit whose allocation
+    // the wider prologue upsets.)
+    for (int base = tid; base < total; base += CH * nthreads) {
+        float v[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int idx = base + u * nthreads;
+            v[u] = 0.f;
+            if (idx < total) {
+                // fp32: idx = ((blk*(KH/4) + s/4)*64 + lane)*4 + s%4 ; bf16: ((blk*(KH/8) + s/8)*64 + lane)*8 + s%8
+                constexpr int G = (PREC != KSR_F32) ? 8 : 4;
+                const int s_lo = idx % G;
+                const int lane = (idx / G) & 63;
+                const int rest = idx / (G * 64);
+                const int s = (rest % (KH / G)) * G + s_lo;
+                const int blk = rest / (KH / G);
+                const int rho = lane & 31, hh = lane >> 5;
+                const int o = om(ksr_row_half(rho), 16 * blk + ksr_row_reg(rho));
+                const int i = im(hh, s);
+                if (o >= 0 && i >= 0) v[u] = TRANS ? W[(long)i * ldw + o] : W[(long)o * ldw + i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int idx = base + u * nthreads;
+            if (idx >= total) continue;
+            if (PREC == KSR_F32X3) {
+                __bf16 t[3];
+                ksr_split3(v[u], t);
+                frag16[idx] = t[0]; frag16[total + idx] = t[1]; frag16[2 * total + idx] = t[2];
+            } else if (PREC != KSR_F32) frag16[idx] = (__bf16)v[u];
+            else frag[idx] = v[u];
+        }
     }
     if (biasfrag) {
         for (int idx = tid; idx < NB * 32; idx += nthreads) {
