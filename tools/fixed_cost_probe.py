@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Fixed cost of a launch of the persistent MFMA kernels: ksr_pointwise_fwd (64 -> n_out, one 128-pixel tile: weight
-staging + one tile + launch) against an empty-ish launch (ksr_bilinear_up on a 4 x 32 image), in every precision mode.
+"""Time per launch of ksr_pointwise_fwd (64 -> n_out) from one 128-pixel tile (weight staging + one tile + launch) to 8 x 128 x
+128 pixels, in the fp32 and the bf16-storage mode.  Back-to-back launches from Python: below ~6 us the host's launch rate
+is what is measured; GPU-side durations come from `rocprofv3 --kernel-trace` (tools/step_timeline.py).
 Usage: python tools/fixed_cost_probe.py"""
 import os
 import sys
@@ -33,14 +34,14 @@ def timeit(fn, n=200):
 for prec in ("fp32", "bf16s"):
     engine.set_precision(prec)
     dt = engine.act_dtype()
-    for n_out in (64, 128, 192):
+    for n_out, act in ((64, 0), (128, 1), (192, 0)):            # the supported (outputs, activation) pairs
         for (B, H, W) in ((1, 4, 32), (1, 32, 32), (8, 128, 128)):
             N = B * H * W
             x = torch.randn(N, 64, device=dev).to(dt)
             w = torch.randn(n_out, 64, device=dev) * 0.1
             b = torch.zeros(n_out, device=dev)
             y = torch.empty(N, n_out, device=dev, dtype=dt)
-            us = timeit(lambda: check(L.ksr_pointwise_fwd(ptr(x), ptr(w), ptr(b), ptr(y), c_int(n_out), c_int(0), c_int(B), c_int(H),
+            us = timeit(lambda: check(L.ksr_pointwise_fwd(ptr(x), ptr(w), ptr(b), ptr(y), c_int(n_out), c_int(act), c_int(B), c_int(H),
                                                             c_int(W), stream()), "pw"))
             print(f"{prec} pointwise 64->{n_out} N={N}: {us:.1f} us per launch", flush=True)
 engine.set_precision("fp32")
