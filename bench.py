@@ -215,6 +215,8 @@ def attn_head_kernel_models(P: int, act_bytes: int):
         "ksr_feed_kan_fwd_img": ("hbm", 2 * 64 * P + 400, a + 4 + 4 * 16 + 128, pk),        # v in, Y' and (uw, S) out
         "ksr_feed_kan_bwd_img": ("hbm", 2 * 64 * P + 800, 64 + 4 + 128 + a + lane, pk),    # dY', x, (uw, S) in, dv and gparam out
         "ksr_pointwise_bwd": ("hbm", 2 * 192 * 64, 3 * a + a, pk),
+        # the trunk's ffn4.fn_1 (64 -> 128) and the head's q | k | v projections (64 -> 192)
+        "ksr_pointwise_fwd": ("hbm", 2 * 64 * 128 + 2 * 64 * 192, 3 * a + 4 * a, pk),
         # bf16 storage: the two above in one kernel (dqkv in; dpq for the weight gradients and dx out)
         "ksr_chan_dw_bwd_dx": ("hbm", 2 * 9 * 192 + 2 * 192 * 64, 3 * a + 3 * a + a, pk),
     }
